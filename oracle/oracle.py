@@ -1,0 +1,175 @@
+"""ctypes front end to the CPU oracle and (when built) the reference library.
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (pyjac_amd) never imports
+this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def build(native: bool = False) -> str:
+    """Compile oracle/pyjac_oracle.c (gcc) if missing or stale."""
+    name = 'libpyjac_oracle_native.so' if native else 'libpyjac_oracle.so'
+    out = os.path.join(HERE, '_build', name)
+    src = os.path.join(HERE, 'pyjac_oracle.c')
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-s', '-C', HERE, 'native' if native else 'all'])
+    return out
+
+
+class Oracle:
+    """Table-driven CPU restatement of pyJac's generated C."""
+
+    def __init__(self, tables, native: bool = False):
+        self.lib = ctypes.CDLL(build(native))
+        L = self.lib
+        L.pjo_create.restype = ctypes.c_void_p
+        L.pjo_create.argtypes = [_ip, ctypes.c_long, _dp, ctypes.c_long]
+        self.I = np.ascontiguousarray(tables.I, dtype=np.int32)
+        self.D = np.ascontiguousarray(tables.D, dtype=np.float64)
+        self.h = L.pjo_create(self.I.ctypes.data_as(_ip), self.I.size, _p(self.D), self.D.size)
+        if not self.h:
+            raise RuntimeError('oracle rejected the mechanism tables')
+        self.h = ctypes.c_void_p(self.h)
+        self.nsp, self.nrxn = tables.nsp, tables.nrxn
+        self.nrev, self.npres = tables.nrev, tables.npres
+        vp, d = ctypes.c_void_p, ctypes.c_double
+        L.pjo_eval_conc.argtypes = [vp, d, d, _dp, _dp, _dp, _dp, _dp]
+        L.pjo_eval_rxn_rates.argtypes = [vp, d, d, _dp, _dp, _dp]
+        L.pjo_get_rxn_pres_mod.argtypes = [vp, d, d, _dp, _dp]
+        L.pjo_eval_spec_rates.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
+        L.pjo_dydt.argtypes = [vp, d, d, _dp, _dp]
+        L.pjo_eval_jacob.argtypes = [vp, d, d, _dp, _dp]
+        L.pjo_batch_jacob.argtypes = [vp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
+        L.pjo_batch_dydt.argtypes = [vp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
+
+    def __del__(self):
+        try:
+            self.lib.pjo_destroy(self.h)
+        except Exception:
+            pass
+
+    # ---- per-state, same argument meaning as pyjacob.py_* ----
+    def eval_all(self, pres: float, y: np.ndarray):
+        """y = [T, Y_0..Y_{NSP-2}].  Returns dict of every intermediate array
+        in the order the functional tester calls them (test.py:1299-1327)."""
+        n = self.nsp
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        T = float(y[0])
+        conc = np.zeros(n)
+        yN, mw, rho = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self.lib.pjo_eval_conc(self.h, T, pres, _p(y[1:].copy()), ctypes.byref(yN),
+                               ctypes.byref(mw), ctypes.byref(rho), _p(conc))
+        fwd = np.zeros(self.nrxn)
+        rev = np.zeros(max(self.nrev, 1))
+        pm = np.zeros(max(self.npres, 1))
+        self.lib.pjo_eval_rxn_rates(self.h, T, pres, _p(conc), _p(fwd), _p(rev))
+        self.lib.pjo_get_rxn_pres_mod(self.h, T, pres, _p(conc), _p(pm))
+        sr = np.zeros(n)
+        self.lib.pjo_eval_spec_rates(self.h, _p(fwd), _p(rev), _p(pm), _p(sr),
+                                     ctypes.cast(sr.ctypes.data + 8 * (n - 1), _dp))
+        dy = np.zeros(n)
+        self.lib.pjo_dydt(self.h, 0.0, pres, _p(y), _p(dy))
+        jac = np.zeros(n * n)
+        self.lib.pjo_eval_jacob(self.h, 0.0, pres, _p(y), _p(jac))
+        return dict(conc=conc, fwd=fwd, rev=rev, pres_mod=pm, spec_rates=sr, dydt=dy, jac=jac)
+
+    # ---- batch (state-major) ----
+    def batch_jacob(self, pres: np.ndarray, y_aos: np.ndarray, nthreads: int = 0) -> np.ndarray:
+        num = pres.shape[0]
+        y_aos = np.ascontiguousarray(y_aos, dtype=np.float64)
+        pres = np.ascontiguousarray(pres, dtype=np.float64)
+        jac = np.empty((num, self.nsp * self.nsp))
+        self.lib.pjo_batch_jacob(self.h, num, _p(pres), _p(y_aos), _p(jac), nthreads)
+        return jac
+
+    def batch_dydt(self, pres: np.ndarray, y_aos: np.ndarray, nthreads: int = 0) -> np.ndarray:
+        num = pres.shape[0]
+        y_aos = np.ascontiguousarray(y_aos, dtype=np.float64)
+        pres = np.ascontiguousarray(pres, dtype=np.float64)
+        dy = np.empty((num, self.nsp))
+        self.lib.pjo_batch_dydt(self.h, num, _p(pres), _p(y_aos), _p(dy), nthreads)
+        return dy
+
+
+class Reference:
+    """The reference's own generated C for one mechanism (oracle/_ref/*.so,
+    built by oracle/build_ref.py in the container that has /root/reference)."""
+
+    def __init__(self, name: str):
+        path = os.path.join(HERE, '_ref', 'libpyjac_ref_%s.so' % name)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = L = ctypes.CDLL(path)
+        self.nsp = L.ref_nsp()
+        self.nrxn = L.ref_fwd_rates()
+        self.nrev = L.ref_rev_rates()
+        self.npres = L.ref_pres_mod_rates()
+        d = ctypes.c_double
+        L.eval_conc.argtypes = [d, d, _dp, _dp, _dp, _dp, _dp]
+        L.eval_rxn_rates.argtypes = [d, d, _dp, _dp, _dp]
+        if self.npres:
+            L.get_rxn_pres_mod.argtypes = [d, d, _dp, _dp]
+        L.eval_spec_rates.argtypes = [_dp, _dp, _dp, _dp, _dp]
+        L.dydt.argtypes = [d, d, _dp, _dp]
+        L.eval_jacob.argtypes = [d, d, _dp, _dp]
+        L.ref_batch_jacob.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
+        L.ref_batch_dydt.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
+
+    @staticmethod
+    def available(name: str) -> bool:
+        return os.path.exists(os.path.join(HERE, '_ref', 'libpyjac_ref_%s.so' % name))
+
+    def eval_all(self, pres: float, y: np.ndarray):
+        n = self.nsp
+        L = self.lib
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        T = float(y[0])
+        conc = np.zeros(n)
+        yN, mw, rho = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        L.eval_conc(T, pres, _p(y[1:].copy()), ctypes.byref(yN), ctypes.byref(mw),
+                    ctypes.byref(rho), _p(conc))
+        fwd = np.zeros(self.nrxn)
+        rev = np.zeros(max(self.nrev, 1))
+        pm = np.zeros(max(self.npres, 1))
+        L.eval_rxn_rates(T, pres, _p(conc), _p(fwd), _p(rev))
+        if self.npres:
+            L.get_rxn_pres_mod(T, pres, _p(conc), _p(pm))
+        sr = np.zeros(n)
+        L.eval_spec_rates(_p(fwd), _p(rev), _p(pm), _p(sr),
+                          ctypes.cast(sr.ctypes.data + 8 * (n - 1), _dp))
+        dy = np.zeros(n)
+        L.dydt(0.0, pres, _p(y), _p(dy))
+        jac = np.zeros(n * n)
+        L.eval_jacob(0.0, pres, _p(y), _p(jac))
+        return dict(conc=conc, fwd=fwd, rev=rev, pres_mod=pm, spec_rates=sr, dydt=dy, jac=jac)
+
+    def batch_jacob(self, pres, y_aos, nthreads: int = 0):
+        num = pres.shape[0]
+        y_aos = np.ascontiguousarray(y_aos, dtype=np.float64)
+        pres = np.ascontiguousarray(pres, dtype=np.float64)
+        jac = np.empty((num, self.nsp * self.nsp))
+        self.lib.ref_batch_jacob(num, _p(pres), _p(y_aos), _p(jac), nthreads)
+        return jac
+
+    def batch_dydt(self, pres, y_aos, nthreads: int = 0):
+        num = pres.shape[0]
+        y_aos = np.ascontiguousarray(y_aos, dtype=np.float64)
+        pres = np.ascontiguousarray(pres, dtype=np.float64)
+        dy = np.empty((num, self.nsp))
+        self.lib.ref_batch_dydt(num, _p(pres), _p(y_aos), _p(dy), nthreads)
+        return dy
