@@ -1,0 +1,109 @@
+/*
+ * pyjac_amd.h -- C ABI of libpyjac_hip.so: MI355X-native batched species-rate
+ * and analytical-Jacobian evaluation behind pyJac's pywrap boundary.
+ *
+ * What this replaces (paths relative to the reference tree):
+ *   - the per-mechanism generated C evaluator that pyjac/pywrap/pyjacob_wrapper.pyx:4-16
+ *     binds (dydt, eval_jacob, eval_rxn_rates, eval_spec_rates, get_rxn_pres_mod,
+ *     eval_conc)                                   -> pj_dydt ... pj_eval_conc
+ *   - the CUDA batch driver pyjac/pywrap/pyjacob.cuh:6-10 / pyjacob.cu:84-188
+ *     (init / run / cleanup)                       -> pj_init / pj_run / pj_cleanup
+ *   - the CUDA speed-test inner loop pyjac/performance_tester/tester.cu.in:109-156
+ *     (device-resident evaluation)                 -> pj_eval_*_dev, pj_time_jacobian_dev
+ * pyJac compiles one library per mechanism (NSP etc. are macros); here the
+ * mechanism is data, so every entry point takes a mechanism handle first.
+ * Everything else (argument order, units, layouts, side effects) is pyJac's.
+ *
+ * Conventions
+ *   - fp64 everywhere, SI units (Pa, K, kmol, m^3, s, J) as docs/faqs.rst:92-103.
+ *   - State vector y = [T, Y_0 .. Y_{NSP-2}] (last species eliminated).
+ *   - Jacobian block is NSP x NSP, column-major per state: entry (r, c) at r + NSP*c
+ *     (create_jacobian.py:2880, docs/faqs.rst:82-87).  Every entry is written; the
+ *     caller does NOT need to pre-zero (pyJac's callers must, tester.c.in:27).
+ *   - PJ_LAYOUT_SOA: element (i, s) at base[i*n + s]  (pyJac's batch layout,
+ *     pyjacob.cu:139-187, test.py:655-660).  PJ_LAYOUT_AOS: base[s*rows + i]
+ *     (pyJac's per-state C layout repeated per state).
+ *   - All functions return 0 on success, a negative PJ_E* code otherwise;
+ *     pj_last_error() describes the last failure of the calling thread.
+ *     (pyJac's own C/CUDA code has no error channel and exit()s:
+ *      mech_auxiliary.py:425-436, pyjacob.cu:108-112.)
+ *   - No CPU fallback: if no HIP device is usable every evaluation call fails
+ *     with PJ_ENODEV.
+ */
+#ifndef PYJAC_AMD_H
+#define PYJAC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pj_mech pj_mech;
+
+enum { PJ_LAYOUT_SOA = 0, PJ_LAYOUT_AOS = 1 };
+enum { PJ_OK = 0, PJ_EINVAL = -1, PJ_ENODEV = -2, PJ_EHIP = -3, PJ_ENOMEM = -4,
+       PJ_EUNSUPPORTED = -5, PJ_EIO = -6 };
+
+const char* pj_last_error(void);
+const char* pj_version(void);
+
+/* ---- mechanism (replaces compile-time mechanism.h: NSP, FWD_RATES, REV_RATES,
+ *      PRES_MOD_RATES; mech_auxiliary.py:136-161) ---- */
+/* I/D: the table blob of pyjac_amd/tables.py (int32 header+arrays, fp64 arrays). */
+int pj_mech_create(const int32_t* I, long nI, const double* D, long nD, pj_mech** out);
+/* file written by MechTables.save(): [u64 nI][u64 nD][I][D], little endian */
+int pj_mech_load(const char* path, pj_mech** out);
+void pj_mech_destroy(pj_mech* m);
+int pj_mech_nsp(const pj_mech* m);
+int pj_mech_fwd_rates(const pj_mech* m);
+int pj_mech_rev_rates(const pj_mech* m);
+int pj_mech_pres_mod_rates(const pj_mech* m);
+/* 0 (default): keep the reference's J_nplusone assignment quirk
+ * (create_jacobian.py:2786-2818) so jac[0] equals pyJac's; 1: sum all reactions. */
+int pj_mech_set_sum_last_species(pj_mech* m, int on);
+/* launch tuning: states per workgroup tile (power of two <= 64, 0 = auto),
+ * threads per workgroup (multiple of 64, 0 = auto) */
+int pj_mech_set_launch(pj_mech* m, int tile_states, int threads);
+int pj_mech_get_launch(const pj_mech* m, int* tile_states, int* threads, int* lds_bytes);
+
+/* ---- device-resident batch evaluation (pointers are device pointers on the
+ *      current HIP device; stream is a hipStream_t or NULL) ---- */
+int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y,
+                         int y_layout, double* d_jac, int jac_layout, void* stream);
+/* any output pointer may be NULL; outputs are SoA with leading dimension n:
+ * conc[NSP], fwd[FWD_RATES], rev[REV_RATES], pres_mod[PRES_MOD_RATES],
+ * spec_rates[NSP], dy[NSP] = [dT/dt, dY_0/dt ..] */
+int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
+                      double* d_conc, double* d_fwd, double* d_rev, double* d_pres_mod,
+                      double* d_spec_rates, double* d_dy, void* stream);
+/* Launch the Jacobian kernel `iters` times on `stream` bracketed by HIP events
+ * recorded on that stream; *ms_per_launch receives the average. */
+int pj_time_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y,
+                         int y_layout, double* d_jac, int jac_layout, void* stream,
+                         int iters, double* ms_per_launch);
+
+/* ---- host-pointer batch driver: pyjacob.cuh:6-10 init / run / cleanup ---- */
+/* returns padded (>= 1, multiple of 64; may be < num when device memory is
+ * short, the caller then chunks as test.py:709-714 does) or a negative code */
+int pj_init(pj_mech* m, int num);
+/* pyjacob.cu:134-188: all arrays SoA with leading dimension num */
+int pj_run(pj_mech* m, int num, int padded, const double* pres, const double* y,
+           double* conc, double* fwd_rxn_rates, double* rev_rxn_rates, double* pres_mod,
+           double* spec_rates, double* dy, double* jac);
+int pj_cleanup(pj_mech* m);
+
+/* ---- per-state host functions: the prototypes of pyjacob_wrapper.pyx:4-16 ---- */
+int pj_dydt(pj_mech* m, double t, double pres, const double* y, double* dy);
+int pj_eval_jacob(pj_mech* m, double t, double pres, const double* y, double* jac);
+int pj_eval_rxn_rates(pj_mech* m, double T, double pres, const double* C, double* fwd, double* rev);
+int pj_eval_spec_rates(pj_mech* m, const double* fwd, const double* rev, const double* pres_mod,
+                       double* sp_rates, double* dy_N);
+int pj_get_rxn_pres_mod(pj_mech* m, double T, double pres, const double* C, double* pres_mod);
+int pj_eval_conc(pj_mech* m, double T, double pres, const double* mass_frac, double* y_N,
+                 double* mw_avg, double* rho, double* conc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

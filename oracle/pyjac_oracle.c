@@ -322,6 +322,9 @@ void pjo_dydt(const pjo_mech *m, double t, double pres, const double *y, double 
     free(buf);
 }
 
+static int g_sum_last = 0;
+void pjo_set_sum_last_species(int on) { g_sum_last = on; }
+
 static double sum_nu(const double *nu, int p0, int p1)
 {
     double s = 0.0;
@@ -512,7 +515,13 @@ void pjo_eval_jacob(const pjo_mech *m, double t, double pres, const double *y, d
             for (int p = m->net_ptr[i]; p < m->net_ptr[i + 1]; ++p) {
                 int k = m->net_sp[p];
                 double v = j_temp * m->net_nu[p] * m->mw[k];
-                if (k == last) J_nplusone += v;
+                /* Reference quirk kept for parity: the emitter tests
+                 * touched[k_sp + 1] with k_sp + 1 == NSP (never set), so every
+                 * reaction ASSIGNS J_nplusone ('=' not '+=',
+                 * create_jacobian.py:2786-2793, 2817-2818): only the last
+                 * reaction with net production of the last species survives
+                 * into jac[0].  pjo_set_sum_last_species(1) restores the sum. */
+                if (k == last) J_nplusone = g_sum_last ? J_nplusone + v : v;
                 else jac[k + 1] += v;
             }
         }

@@ -1,0 +1,560 @@
+// pj_api.hip -- HIP kernels + C ABI (include/pyjac_amd.h) for gfx950.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define PJ_DEV __device__ __forceinline__
+#include "pj_kernel.h"
+#include "../../include/pyjac_amd.h"
+
+using namespace pj;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? PJ_ENODEV \
+                                                                              : PJ_EHIP, \
+                        std::string(#call) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+constexpr int MODE_JAC = 1, MODE_CONC_IN = 2;
+
+// conc-input variant of phase 0: the caller supplies concentrations
+// (eval_rxn_rates / get_rxn_pres_mod prototypes, pyjacob_wrapper.pyx:10-13)
+template <int TS>
+PJ_DEV void phase0c(const DevMech& M, const Batch& B, const double* cin, const double* Tin, double* V,
+                    int tid, int NT, long tile, Lane& L)
+{
+    const int s = tid % TS, u = tid / TS, NU = NT / TS;
+    long gs = tile * TS + s;
+    L.valid = gs < B.n;
+    if (!L.valid) gs = B.n - 1;
+    L.gs = gs;
+    const double T = Tin[gs], p = B.pres[gs];
+    L.T = T; L.p = p; L.logT = log(T); L.invT = 1.0 / T; L.logp = log(p);
+    L.Wbar = 1.0; L.rho = 1.0; L.invrho = 1.0; L.m = p / (RU_ * T); L.yN = 0.0;
+    for (int k = u; k < M.nsp; k += NU) {
+        V[(M.v.C + k) * TS + s] = cin[k * B.o_ld + gs];
+        V[(M.v.HW + k) * TS + s] = 0.0;
+        V[(M.v.CP + k) * TS + s] = 0.0;
+        V[(M.v.YC + k) * TS + s] = 0.0;
+        V[(M.v.YD + k) * TS + s] = 0.0;
+    }
+    if (u == 0) V[M.v.ONE * TS + s] = 1.0;
+}
+
+template <int TS>
+__global__ void __launch_bounds__(256)
+k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, double* aux)
+{
+    extern __shared__ __attribute__((aligned(16))) double V[];
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const long ntiles = (B.n + TS - 1) / TS;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        Lane L;
+        if (mode & MODE_CONC_IN) {
+            phase0c<TS>(M, B, cin, Tin, V, tid, NT, tile, L);
+        } else {
+            phase0<TS>(M, B, V, tid, NT, tile, L);
+            if (aux && tid / TS == 0 && L.valid) {
+                // y_N, mw_avg, rho of eval_conc (rate_subs.py:1595-1597)
+                aux[0 * B.o_ld + L.gs] = L.yN;
+                aux[1 * B.o_ld + L.gs] = L.Wbar;
+                aux[2 * B.o_ld + L.gs] = L.rho;
+            }
+        }
+        __syncthreads();
+        phase2<TS>(M, B, V, tid, NT, L);
+        __syncthreads();
+        if (!(mode & MODE_CONC_IN)) {
+            phase3<TS>(M, B, V, tid, NT, L);
+            __syncthreads();
+            phase3b<TS>(M, B, V, tid, NT, L);
+            __syncthreads();
+            phase_dy0<TS>(M, B, V, tid, NT, L);
+            if (mode & MODE_JAC) phase4<TS>(M, B, V, tid, NT, L);
+        }
+        __syncthreads();
+    }
+}
+
+// eval_spec_rates from caller-supplied rates (pyjacob_wrapper.pyx:11); one thread per state
+__global__ void k_spec_rates(DevMech M, long n, const double* fwd, const double* rev,
+                             const double* pm, double* sr)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    for (int k = 0; k < M.nsp; ++k) {
+        double om = 0.0;
+        for (int q = M.sp_ptr[k]; q < M.sp_ptr[k + 1]; ++q) {
+            const int32_t* ri = M.ri + M.sp_rxn[q] * RIW;
+            double R = fwd[ri[RI_ORIG] * n + s];
+            if (ri[RI_REV_IDX] >= 0) R -= rev[ri[RI_REV_IDX] * n + s];
+            if (ri[RI_PRES_IDX] >= 0) R *= pm[ri[RI_PRES_IDX] * n + s];
+            om += M.sp_nu[q] * R;
+        }
+        sr[k * n + s] = om;
+    }
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t upload(const std::vector<T>& h)
+    {
+        n = h.size();
+        hipError_t e = hipMalloc((void**)&p, sizeof(T) * (n ? n : 1));
+        if (e != hipSuccess) return e;
+        if (n) e = hipMemcpy(p, h.data(), sizeof(T) * n, hipMemcpyHostToDevice);
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct Workspace {
+    long cap = 0;
+    double *pres = nullptr, *y = nullptr, *conc = nullptr, *fwd = nullptr, *rev = nullptr,
+           *pm = nullptr, *sr = nullptr, *dy = nullptr, *jac = nullptr, *aux = nullptr, *T = nullptr;
+    void release()
+    {
+        double** all[] = {&pres, &y, &conc, &fwd, &rev, &pm, &sr, &dy, &jac, &aux, &T};
+        for (auto pp : all) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct pj_mech {
+    Programs P;
+    DevMech M;
+    bool on_device = false;
+    int device = -1;
+    DevBuf<double> sp, rd, eff_am1, kcg, plog, net_nu, sp_nu, ct_c;
+    DevBuf<int32_t> ri, eff_sp, net_sp, sp_ptr, sp_rxn, en_ptr, ct_a, ct_b;
+    int ts = 0, nt = 0;       // 0 = auto
+    int num_cu = 256;
+    Workspace ws, ws1;
+};
+
+namespace {
+
+size_t bytes_per_state(const pj_mech* m)
+{
+    const size_t nsp = m->P.nsp, R = m->P.nrxn, Rr = m->P.nrev > 0 ? m->P.nrev : 1,
+                 Rp = m->P.npres > 0 ? m->P.npres : 1;
+    return 8 * (1 + nsp + nsp + R + Rr + Rp + nsp + nsp + nsp * nsp + 3 + 1);
+}
+
+int ensure_device(pj_mech* m)
+{
+    if (m->on_device) return PJ_OK;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(PJ_ENODEV, "no HIP device available (the product path has no CPU fallback)");
+    HIPCHK(hipGetDevice(&m->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, m->device));
+    m->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    Programs& P = m->P;
+    HIPCHK(m->sp.upload(P.sp)); HIPCHK(m->ri.upload(P.ri)); HIPCHK(m->rd.upload(P.rd));
+    HIPCHK(m->eff_sp.upload(P.eff_sp)); HIPCHK(m->eff_am1.upload(P.eff_am1));
+    HIPCHK(m->kcg.upload(P.kcg)); HIPCHK(m->plog.upload(P.plog));
+    HIPCHK(m->net_sp.upload(P.net_sp)); HIPCHK(m->net_nu.upload(P.net_nu));
+    HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
+    HIPCHK(m->en_ptr.upload(P.en_ptr)); HIPCHK(m->ct_a.upload(P.ct_a)); HIPCHK(m->ct_b.upload(P.ct_b));
+    HIPCHK(m->ct_c.upload(P.ct_c));
+    DevMech& M = m->M;
+    M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
+    M.kcg = m->kcg.p; M.plog = m->plog.p; M.net_sp = m->net_sp.p; M.net_nu = m->net_nu.p;
+    M.sp_ptr = m->sp_ptr.p; M.sp_rxn = m->sp_rxn.p; M.sp_nu = m->sp_nu.p;
+    M.en_ptr = m->en_ptr.p; M.ct_a = m->ct_a.p; M.ct_b = m->ct_b.p; M.ct_c = m->ct_c.p;
+    m->on_device = true;
+    return PJ_OK;
+}
+
+void pick_launch(const pj_mech* m, int* ts, int* nt, size_t* lds)
+{
+    const size_t per_state = (size_t)m->P.vm.NV * 8;
+    int t = m->ts;
+    if (t <= 0) {
+        // largest tile whose working set leaves room for two workgroups per CU
+        size_t budget = 80 * 1024;
+        if (const char* e = getenv("PJ_LDS_BUDGET")) budget = (size_t)atol(e);
+        t = 64;
+        while (t > 1 && per_state * t > budget) t >>= 1;
+    }
+    int n = m->nt > 0 ? m->nt : 256;
+    *ts = t; *nt = n; *lds = per_state * t;
+}
+
+template <int TS>
+int launch_ts(pj_mech* m, const Batch& B, int mode, const double* cin, const double* Tin, double* aux,
+              int nt, size_t lds, hipStream_t st)
+{
+    static thread_local size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_eval<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    const long ntiles = (B.n + TS - 1) / TS;
+    long grid = (long)m->num_cu * 8;
+    if (grid > ntiles) grid = ntiles;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((k_eval<TS>), dim3((unsigned)grid), dim3(nt), lds, st, m->M, B, mode, cin, Tin, aux);
+    HIPCHK(hipGetLastError());
+    return PJ_OK;
+}
+
+int launch(pj_mech* m, const Batch& B, int mode, const double* cin, const double* Tin, double* aux,
+           hipStream_t st)
+{
+    if (B.n <= 0) return PJ_OK;
+    int rc = ensure_device(m);
+    if (rc) return rc;
+    int ts, nt;
+    size_t lds;
+    pick_launch(m, &ts, &nt, &lds);
+    if (lds > 160 * 1024)
+        return fail(PJ_EUNSUPPORTED, "mechanism working set exceeds 160 KiB of LDS per state");
+    switch (ts) {
+        case 64: return launch_ts<64>(m, B, mode, cin, Tin, aux, nt, lds, st);
+        case 32: return launch_ts<32>(m, B, mode, cin, Tin, aux, nt, lds, st);
+        case 16: return launch_ts<16>(m, B, mode, cin, Tin, aux, nt, lds, st);
+        case 8: return launch_ts<8>(m, B, mode, cin, Tin, aux, nt, lds, st);
+        case 4: return launch_ts<4>(m, B, mode, cin, Tin, aux, nt, lds, st);
+        case 2: return launch_ts<2>(m, B, mode, cin, Tin, aux, nt, lds, st);
+        case 1: return launch_ts<1>(m, B, mode, cin, Tin, aux, nt, lds, st);
+    }
+    return fail(PJ_EINVAL, "tile_states must be a power of two <= 64");
+}
+
+void set_layout(long n, int rows, int layout, long* si, long* ss)
+{
+    if (layout == PJ_LAYOUT_AOS) { *si = 1; *ss = rows; }
+    else { *si = n; *ss = 1; }
+}
+
+int alloc_ws(pj_mech* m, Workspace& w, long cap)
+{
+    if (w.cap >= cap) return PJ_OK;
+    w.release();
+    const size_t nsp = m->P.nsp, R = m->P.nrxn, Rr = m->P.nrev > 0 ? m->P.nrev : 1,
+                 Rp = m->P.npres > 0 ? m->P.npres : 1;
+    struct { double** p; size_t rows; } a[] = {
+        {&w.pres, 1}, {&w.y, nsp}, {&w.conc, nsp}, {&w.fwd, R}, {&w.rev, Rr}, {&w.pm, Rp},
+        {&w.sr, nsp}, {&w.dy, nsp}, {&w.jac, nsp * nsp}, {&w.aux, 3}, {&w.T, 1}};
+    for (auto& x : a) {
+        hipError_t e = hipMalloc((void**)x.p, sizeof(double) * x.rows * (size_t)cap);
+        if (e != hipSuccess) {
+            w.release();
+            return fail(PJ_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
+    }
+    w.cap = cap;
+    return PJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pj_last_error(void) { return g_err.c_str(); }
+const char* pj_version(void) { return "pyjac_amd 0.1 (gfx950)"; }
+
+int pj_mech_create(const int32_t* I, long nI, const double* D, long nD, pj_mech** out)
+{
+    if (!I || !D || !out) return fail(PJ_EINVAL, "null argument");
+    pj_mech* m = new pj_mech();
+    if (!build_programs(I, nI, D, nD, m->P)) {
+        std::string e = m->P.error;
+        delete m;
+        return fail(PJ_EUNSUPPORTED, e);
+    }
+    DevMech& M = m->M;
+    memset(&M, 0, sizeof(M));
+    M.nsp = m->P.nsp; M.nrxn = m->P.nrxn; M.ng = m->P.ng; M.ne = m->P.ne; M.nv = m->P.vm.NV;
+    M.lastq_rxn = m->P.lastq_rxn; M.sum_last = 0; M.v = m->P.vm;
+    if (const char* e = getenv("PJ_TS")) m->ts = atoi(e);
+    if (const char* e = getenv("PJ_NT")) m->nt = atoi(e);
+    *out = m;
+    return PJ_OK;
+}
+
+int pj_mech_load(const char* path, pj_mech** out)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(PJ_EIO, std::string("cannot open ") + path);
+    uint64_t hdr[2];
+    if (fread(hdr, sizeof(uint64_t), 2, f) != 2) { fclose(f); return fail(PJ_EIO, "short table file"); }
+    std::vector<int32_t> I(hdr[0]);
+    std::vector<double> D(hdr[1]);
+    bool ok = fread(I.data(), 4, I.size(), f) == I.size() && fread(D.data(), 8, D.size(), f) == D.size();
+    fclose(f);
+    if (!ok) return fail(PJ_EIO, "short table file");
+    return pj_mech_create(I.data(), (long)I.size(), D.data(), (long)D.size(), out);
+}
+
+void pj_mech_destroy(pj_mech* m)
+{
+    if (!m) return;
+    if (m->on_device) {
+        m->sp.release(); m->rd.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release();
+        m->net_nu.release(); m->sp_nu.release(); m->ct_c.release(); m->ri.release(); m->eff_sp.release();
+        m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release(); m->en_ptr.release();
+        m->ct_a.release(); m->ct_b.release();
+        m->ws.release(); m->ws1.release();
+    }
+    delete m;
+}
+
+int pj_mech_nsp(const pj_mech* m) { return m->P.nsp; }
+int pj_mech_fwd_rates(const pj_mech* m) { return m->P.nrxn; }
+int pj_mech_rev_rates(const pj_mech* m) { return m->P.nrev; }
+int pj_mech_pres_mod_rates(const pj_mech* m) { return m->P.npres; }
+
+int pj_mech_set_sum_last_species(pj_mech* m, int on) { m->M.sum_last = on ? 1 : 0; return PJ_OK; }
+
+int pj_mech_set_launch(pj_mech* m, int tile_states, int threads)
+{
+    if (tile_states < 0 || tile_states > 64 || (tile_states & (tile_states - 1)))
+        return fail(PJ_EINVAL, "tile_states must be 0 or a power of two <= 64");
+    if (threads < 0 || threads > 256 || threads % 64)
+        return fail(PJ_EINVAL, "threads must be 0 or a multiple of 64 <= 256");
+    m->ts = tile_states; m->nt = threads;
+    return PJ_OK;
+}
+
+int pj_mech_get_launch(const pj_mech* m, int* tile_states, int* threads, int* lds_bytes)
+{
+    int ts, nt; size_t lds;
+    pick_launch(m, &ts, &nt, &lds);
+    if (tile_states) *tile_states = ts;
+    if (threads) *threads = nt;
+    if (lds_bytes) *lds_bytes = (int)lds;
+    return PJ_OK;
+}
+
+int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
+                         double* d_jac, int jac_layout, void* stream)
+{
+    if (!m || !d_pres || !d_y || !d_jac || n < 0) return fail(PJ_EINVAL, "bad argument");
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    B.n = n; B.pres = d_pres; B.y = d_y; B.jac = d_jac; B.o_ld = n;
+    set_layout(n, m->P.nsp, y_layout, &B.y_si, &B.y_ss);
+    set_layout(n, m->P.nsp * m->P.nsp, jac_layout, &B.j_si, &B.j_ss);
+    return launch(m, B, MODE_JAC, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
+                      double* d_conc, double* d_fwd, double* d_rev, double* d_pres_mod,
+                      double* d_spec_rates, double* d_dy, void* stream)
+{
+    if (!m || !d_pres || !d_y || n < 0) return fail(PJ_EINVAL, "bad argument");
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    B.n = n; B.pres = d_pres; B.y = d_y; B.o_ld = n;
+    set_layout(n, m->P.nsp, y_layout, &B.y_si, &B.y_ss);
+    B.conc = d_conc; B.fwd = d_fwd; B.rev = d_rev; B.pres_mod = d_pres_mod;
+    B.spec_rates = d_spec_rates; B.dy = d_dy;
+    return launch(m, B, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int pj_time_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
+                         double* d_jac, int jac_layout, void* stream, int iters, double* ms_per_launch)
+{
+    if (iters < 1 || !ms_per_launch) return fail(PJ_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) {
+        int rc = pj_eval_jacobian_dev(m, n, d_pres, d_y, y_layout, d_jac, jac_layout, stream);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / iters;
+    return PJ_OK;
+}
+
+// ---- pyjacob.cu:84-188 ----
+int pj_init(pj_mech* m, int num)
+{
+    if (!m || num < 1) return fail(PJ_EINVAL, "bad argument");
+    int rc = ensure_device(m);
+    if (rc) return rc;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t per = bytes_per_state(m);
+    long max_states = (long)(0.8 * (double)free_b / (double)per);   // USE_MEM 0.8, pyjacob.cu:82
+    long padded = num < max_states ? num : max_states;
+    padded = (padded + 63) / 64 * 64;
+    if (padded > max_states) padded = max_states / 64 * 64;
+    if (padded <= 0) return fail(PJ_ENOMEM, "mechanism is too large to fit one tile into device memory");
+    if (padded > 2147483584L) padded = 2147483584L;
+    rc = alloc_ws(m, m->ws, padded);
+    if (rc) return rc;
+    return (int)padded;
+}
+
+static int run_ws(pj_mech* m, Workspace& w, int num, const double* pres, const double* y, double* conc,
+                  double* fwd, double* rev, double* pres_mod, double* spec_rates, double* dy,
+                  double* jac, double* aux)
+{
+    const size_t nsp = m->P.nsp, n = (size_t)num;
+    HIPCHK(hipMemcpy(w.pres, pres, 8 * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w.y, y, 8 * n * nsp, hipMemcpyHostToDevice));
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    B.n = num; B.pres = w.pres; B.y = w.y; B.y_si = num; B.y_ss = 1; B.o_ld = num;
+    B.jac = w.jac; B.j_si = num; B.j_ss = 1;
+    B.conc = w.conc; B.fwd = w.fwd; B.rev = w.rev; B.pres_mod = w.pm; B.spec_rates = w.sr; B.dy = w.dy;
+    int rc = launch(m, B, jac ? MODE_JAC : 0, nullptr, nullptr, aux ? w.aux : nullptr, 0);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (conc) HIPCHK(hipMemcpy(conc, w.conc, 8 * n * nsp, hipMemcpyDeviceToHost));
+    if (fwd) HIPCHK(hipMemcpy(fwd, w.fwd, 8 * n * m->P.nrxn, hipMemcpyDeviceToHost));
+    if (rev && m->P.nrev) HIPCHK(hipMemcpy(rev, w.rev, 8 * n * m->P.nrev, hipMemcpyDeviceToHost));
+    if (pres_mod && m->P.npres) HIPCHK(hipMemcpy(pres_mod, w.pm, 8 * n * m->P.npres, hipMemcpyDeviceToHost));
+    if (spec_rates) HIPCHK(hipMemcpy(spec_rates, w.sr, 8 * n * nsp, hipMemcpyDeviceToHost));
+    if (dy) HIPCHK(hipMemcpy(dy, w.dy, 8 * n * nsp, hipMemcpyDeviceToHost));
+    if (jac) HIPCHK(hipMemcpy(jac, w.jac, 8 * n * nsp * nsp, hipMemcpyDeviceToHost));
+    if (aux) HIPCHK(hipMemcpy(aux, w.aux, 8 * n * 3, hipMemcpyDeviceToHost));
+    return PJ_OK;
+}
+
+int pj_run(pj_mech* m, int num, int padded, const double* pres, const double* y, double* conc,
+           double* fwd_rxn_rates, double* rev_rxn_rates, double* pres_mod, double* spec_rates,
+           double* dy, double* jac)
+{
+    if (!m || !pres || !y || num < 1) return fail(PJ_EINVAL, "bad argument");
+    if (m->ws.cap < num || padded < num)
+        return fail(PJ_EINVAL, "pj_run: num exceeds the capacity returned by pj_init");
+    return run_ws(m, m->ws, num, pres, y, conc, fwd_rxn_rates, rev_rxn_rates, pres_mod, spec_rates, dy,
+                  jac, nullptr);
+}
+
+int pj_cleanup(pj_mech* m)
+{
+    if (m) m->ws.release();
+    return PJ_OK;
+}
+
+// ---- per-state functions (pyjacob_wrapper.pyx:4-16), evaluated on the GPU ----
+static int one(pj_mech* m)
+{
+    int rc = ensure_device(m);
+    if (rc) return rc;
+    return alloc_ws(m, m->ws1, 64);
+}
+
+int pj_dydt(pj_mech* m, double t, double pres, const double* y, double* dy)
+{
+    (void)t;
+    int rc = one(m);
+    if (rc) return rc;
+    return run_ws(m, m->ws1, 1, &pres, y, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr);
+}
+
+int pj_eval_jacob(pj_mech* m, double t, double pres, const double* y, double* jac)
+{
+    (void)t;
+    int rc = one(m);
+    if (rc) return rc;
+    return run_ws(m, m->ws1, 1, &pres, y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, jac, nullptr);
+}
+
+int pj_eval_conc(pj_mech* m, double T, double pres, const double* mass_frac, double* y_N,
+                 double* mw_avg, double* rho, double* conc)
+{
+    int rc = one(m);
+    if (rc) return rc;
+    std::vector<double> y(m->P.nsp);
+    y[0] = T;
+    for (int k = 0; k < m->P.nsp - 1; ++k) y[k + 1] = mass_frac[k];
+    double aux[3];
+    rc = run_ws(m, m->ws1, 1, &pres, y.data(), conc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, aux);
+    if (rc) return rc;
+    if (y_N) *y_N = aux[0];
+    if (mw_avg) *mw_avg = aux[1];
+    if (rho) *rho = aux[2];
+    return PJ_OK;
+}
+
+static int rates_from_conc(pj_mech* m, double T, double pres, const double* C, double* fwd, double* rev,
+                           double* pm)
+{
+    int rc = one(m);
+    if (rc) return rc;
+    Workspace& w = m->ws1;
+    HIPCHK(hipMemcpy(w.pres, &pres, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w.T, &T, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w.conc, C, 8 * (size_t)m->P.nsp, hipMemcpyHostToDevice));
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    B.n = 1; B.pres = w.pres; B.y = w.y; B.y_si = 1; B.y_ss = 1; B.o_ld = 1;
+    B.fwd = w.fwd; B.rev = w.rev; B.pres_mod = w.pm;
+    rc = launch(m, B, MODE_CONC_IN, w.conc, w.T, nullptr, 0);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (fwd) HIPCHK(hipMemcpy(fwd, w.fwd, 8 * (size_t)m->P.nrxn, hipMemcpyDeviceToHost));
+    if (rev && m->P.nrev) HIPCHK(hipMemcpy(rev, w.rev, 8 * (size_t)m->P.nrev, hipMemcpyDeviceToHost));
+    if (pm && m->P.npres) HIPCHK(hipMemcpy(pm, w.pm, 8 * (size_t)m->P.npres, hipMemcpyDeviceToHost));
+    return PJ_OK;
+}
+
+int pj_eval_rxn_rates(pj_mech* m, double T, double pres, const double* C, double* fwd, double* rev)
+{
+    return rates_from_conc(m, T, pres, C, fwd, rev, nullptr);
+}
+
+int pj_get_rxn_pres_mod(pj_mech* m, double T, double pres, const double* C, double* pres_mod)
+{
+    return rates_from_conc(m, T, pres, C, nullptr, nullptr, pres_mod);
+}
+
+int pj_eval_spec_rates(pj_mech* m, const double* fwd, const double* rev, const double* pres_mod,
+                       double* sp_rates, double* dy_N)
+{
+    int rc = one(m);
+    if (rc) return rc;
+    Workspace& w = m->ws1;
+    HIPCHK(hipMemcpy(w.fwd, fwd, 8 * (size_t)m->P.nrxn, hipMemcpyHostToDevice));
+    if (m->P.nrev) HIPCHK(hipMemcpy(w.rev, rev, 8 * (size_t)m->P.nrev, hipMemcpyHostToDevice));
+    if (m->P.npres) HIPCHK(hipMemcpy(w.pm, pres_mod, 8 * (size_t)m->P.npres, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_spec_rates, dim3(1), dim3(64), 0, 0, m->M, 1L, w.fwd, w.rev, w.pm, w.sr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> sr(m->P.nsp);
+    HIPCHK(hipMemcpy(sr.data(), w.sr, 8 * sr.size(), hipMemcpyDeviceToHost));
+    // eval_spec_rates writes sp_rates[0..NSP-2] and the last species through dy_N
+    for (int k = 0; k < m->P.nsp - 1; ++k) sp_rates[k] = sr[k];
+    if (dy_N) *dy_N = sr[m->P.nsp - 1];
+    return PJ_OK;
+}
+
+}  // extern "C"

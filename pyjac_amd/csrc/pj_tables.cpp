@@ -1,0 +1,284 @@
+// pj_tables.cpp -- canonical mechanism blob -> device programs (host, C++).
+#include "pj_tables.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace pj {
+
+namespace {
+struct Blob {
+    const int32_t* I;
+    const double* D;
+    const int32_t* ia(int j) const { return I + I[16 + j]; }
+    const double* da(int j) const { return D + I[48 + j]; }
+};
+
+int kind_rank(int fl)
+{
+    if ((fl & F_PDEP) && (fl & F_TROE)) return 0;
+    if (fl & F_PDEP) return 1;
+    if (fl & F_THD) return 2;
+    if (fl & F_PLOG) return 3;
+    if (fl & F_REV) return 4;
+    return 5;
+}
+}  // namespace
+
+bool build_programs(const int32_t* I, long nI, const double* D, long nD, Programs& p)
+{
+    if (nI < HDR || I[0] != MAGIC || I[1] != 1 || I[12] != nI || I[13] != nD) {
+        p.error = "malformed mechanism table blob";
+        return false;
+    }
+    Blob B{I, D};
+    const int nsp = I[2], nrxn = I[3];
+    p.nsp = nsp; p.nrxn = nrxn; p.nrev = I[4]; p.npres = I[5];
+    const int last = nsp - 1;
+
+    const int32_t *flags = B.ia(IA_FLAGS), *reac_ptr = B.ia(IA_REAC_PTR), *reac_sp = B.ia(IA_REAC_SP),
+                  *prod_ptr = B.ia(IA_PROD_PTR), *prod_sp = B.ia(IA_PROD_SP), *net_ptr = B.ia(IA_NET_PTR),
+                  *net_sp = B.ia(IA_NET_SP), *eff_ptr = B.ia(IA_EFF_PTR), *eff_sp = B.ia(IA_EFF_SP),
+                  *plog_ptr = B.ia(IA_PLOG_PTR), *kc_ptr = B.ia(IA_KC_PTR), *pdep_sp = B.ia(IA_PDEP_SP),
+                  *rev_idx = B.ia(IA_REV_IDX), *pres_idx = B.ia(IA_PRES_IDX);
+    const double *mw = B.da(DA_MW), *tmid = B.da(DA_TMID), *lo = B.da(DA_LO), *hi = B.da(DA_HI),
+                 *A = B.da(DA_A), *b = B.da(DA_B), *E = B.da(DA_E), *reac_nu = B.da(DA_REAC_NU),
+                 *prod_nu = B.da(DA_PROD_NU), *net_nu = B.da(DA_NET_NU), *eff = B.da(DA_EFF),
+                 *troe = B.da(DA_TROE), *plog = B.da(DA_PLOG), *kcg = B.da(DA_KCG),
+                 *kcpref = B.da(DA_KCPREF), *infs = B.da(DA_INFS), *plog4 = B.da(DA_PLOG4);
+
+    // ---- species ----
+    p.sp.assign((size_t)nsp * SPW, 0.0);
+    for (int k = 0; k < nsp; ++k) {
+        double* s = &p.sp[(size_t)k * SPW];
+        s[0] = 1.0 / mw[k]; s[1] = mw[k]; s[2] = tmid[k]; s[3] = mw[k] / mw[last];
+        for (int c = 0; c < 7; ++c) { s[4 + c] = lo[7 * k + c]; s[11 + c] = hi[7 * k + c]; }
+    }
+
+    // ---- device order ----
+    std::vector<int> order(nrxn);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int x, int y) { return kind_rank(flags[x]) < kind_rank(flags[y]); });
+    std::vector<int> dev_of(nrxn);
+    for (int d = 0; d < nrxn; ++d) dev_of[order[d]] = d;
+
+    // quirk: which reaction's d/dT survives in J_nplusone (create_jacobian.py:2786-2818)
+    auto no_dt = [&](int i) {
+        const int fl = flags[i];
+        if ((fl & F_REV) || (fl & F_PLOG)) return false;
+        double nr = 0;
+        for (int q = reac_ptr[i]; q < reac_ptr[i + 1]; ++q) nr += reac_nu[q];
+        return std::fabs(b[i]) <= 1e-90 && std::fabs(E[i]) <= 1e-90 && nr == 1.0;
+    };
+    int lastq_orig = -1;
+    for (int i = 0; i < nrxn; ++i) {
+        if (no_dt(i)) continue;
+        for (int q = net_ptr[i]; q < net_ptr[i + 1]; ++q)
+            if (net_sp[q] == last && net_nu[q] != 0.0) lastq_orig = i;
+    }
+
+    const int ONE = nsp;
+    p.ri.assign((size_t)nrxn * RIW, 0);
+    p.rd.assign((size_t)nrxn * RDW, 0.0);
+    int ng = 0;
+    // per reaction (device order): species of each g slot, and alpha_ij - 1 list
+    std::vector<std::vector<int>> gslot_sp(nrxn);
+    std::vector<std::vector<std::pair<int, double>>> effs(nrxn);
+
+    for (int d = 0; d < nrxn; ++d) {
+        const int i = order[d];
+        int fl = flags[i];
+        int32_t* ri = &p.ri[(size_t)d * RIW];
+        double* rd = &p.rd[(size_t)d * RDW];
+        if (fl & F_SRI) { p.error = "SRI falloff is out of scope"; return false; }
+
+        auto slots = [&](const int32_t* ptr, const int32_t* sp, const double* nu, int* out, double& total) {
+            int n = 0;
+            total = 0;
+            for (int q = ptr[i]; q < ptr[i + 1]; ++q) {
+                if (nu[q] != std::floor(nu[q]) || nu[q] < 0) return -1;
+                total += nu[q];
+                for (int r = 0; r < (int)nu[q]; ++r) {
+                    if (n >= 3) return -1;
+                    out[n++] = sp[q];
+                }
+            }
+            for (int r = n; r < 3; ++r) out[r] = ONE;
+            return n;
+        };
+        int rs[3], ps[3];
+        double nr, np_;
+        const int nrs = slots(reac_ptr, reac_sp, reac_nu, rs, nr);
+        const int nps = slots(prod_ptr, prod_sp, prod_nu, ps, np_);
+        if (nrs < 0 || nps < 0) { p.error = "more than 3 molecules on one side of a reaction (or fractional nu)"; return false; }
+        for (int r = 0; r < 3; ++r) { ri[RI_R0 + r] = rs[r]; ri[RI_P0 + r] = ps[r]; }
+
+        const int col = pdep_sp[i];
+        if ((fl & F_PDEP) && col >= 0) fl |= F_COLLIDER;
+        if (((fl & F_THD) || ((fl & F_PDEP) && col < 0)) && (fl & F_HAS_EFF)) fl |= F_EFFTYPE;
+        if (no_dt(i)) fl |= F_NO_DT;
+        if (i == lastq_orig) { fl |= F_LASTQ; p.lastq_rxn = d; }
+        ri[RI_FLAGS] = fl;
+        ri[RI_COLLIDER] = col;
+
+        // enhanced colliders (alpha != 1), first occurrence wins
+        ri[RI_EFF_PTR] = (int)p.eff_sp.size();
+        double anm1 = 0.0;
+        for (int q = eff_ptr[i]; q < eff_ptr[i + 1]; ++q) {
+            if (eff[q] == 1.0) continue;
+            bool dup = false;
+            for (auto& e : effs[d]) dup |= (e.first == eff_sp[q]);
+            if (dup) continue;
+            effs[d].push_back({eff_sp[q], eff[q] - 1.0});
+            p.eff_sp.push_back(eff_sp[q]);
+            p.eff_am1.push_back(eff[q] - 1.0);
+            if (eff_sp[q] == last) anm1 = eff[q] - 1.0;
+        }
+        ri[RI_EFF_CNT] = (int)effs[d].size();
+        if (!(fl & F_EFFTYPE)) anm1 = 0.0;
+        rd[RD_ANM1] = anm1;
+
+        // rate constant (rate_subs.py:27-146); generic form sgn*exp(lnA + b logT - Ta/T)
+        auto set_rate = [&](double Av, double bv, double Ev, double* lnA, double* bb, double* Ta, double* sgn) {
+            if (Av == 0.0) return false;
+            *sgn = Av > 0 ? 1.0 : -1.0;
+            *lnA = std::log(std::fabs(Av));
+            *bb = bv; *Ta = Ev;
+            // reference quirk: A<0, E==0, negative integer b -> plain A
+            if (Av < 0 && Ev == 0.0 && bv != 0.0 && bv == std::floor(bv) && bv < 0) *bb = 0.0;
+            return true;
+        };
+        if (!(fl & F_PLOG)) {
+            if (!set_rate(A[i], b[i], E[i], &rd[RD_LNA], &rd[RD_B], &rd[RD_TA], &rd[RD_SGN])) {
+                p.error = "reaction with A == 0"; return false;
+            }
+        } else {
+            rd[RD_SGN] = 1.0;
+        }
+        rd[RD_NR] = nr;
+        rd[RD_NP] = np_;
+
+        ri[RI_KC_PTR] = (int)(p.kcg.size() / KCW);
+        if (fl & F_REV) {
+            for (int g = kc_ptr[i]; g < kc_ptr[i + 1]; ++g)
+                p.kcg.insert(p.kcg.end(), kcg + (size_t)KCW * g, kcg + (size_t)KCW * (g + 1));
+            rd[RD_LNPREF] = std::log(kcpref[i]);
+        }
+        ri[RI_KC_CNT] = (int)(p.kcg.size() / KCW) - ri[RI_KC_PTR];
+
+        ri[RI_PLOG_PTR] = (int)(p.plog.size() / PLW);
+        if (fl & F_PLOG) {
+            for (int q = plog_ptr[i]; q < plog_ptr[i + 1]; ++q) {
+                const double* r = plog + 4 * (size_t)q;
+                if (r[1] <= 0.0) { p.error = "PLOG with A <= 0"; return false; }
+                p.plog.push_back(plog4[q]);
+                p.plog.push_back(std::log(r[0]));
+                p.plog.push_back(std::log(r[1]));
+                p.plog.push_back(r[2]);
+                p.plog.push_back(r[3]);
+            }
+        }
+        ri[RI_PLOG_CNT] = (int)(p.plog.size() / PLW) - ri[RI_PLOG_PTR];
+
+        if (fl & F_PDEP) {
+            const double* in = infs + 4 * (size_t)i;
+            if (in[0] <= 0.0) { p.error = "falloff with non-positive k0/kinf ratio"; return false; }
+            rd[RD_LNAR] = std::log(in[0]); rd[RD_B0] = in[1]; rd[RD_E0] = in[2]; rd[RD_B04] = in[3];
+            if (fl & F_TROE) {
+                const double* t = troe + 4 * (size_t)i;
+                rd[RD_TRA] = t[0]; rd[RD_T3] = t[1]; rd[RD_T1] = t[2]; rd[RD_T2] = t[3];
+            }
+        }
+
+        // g slots: reactant molecules, product molecules (reversible), collider
+        ri[RI_GBASE] = ng;
+        for (int r = 0; r < nrs; ++r) gslot_sp[d].push_back(rs[r]);
+        if (fl & F_REV) for (int r = 0; r < nps; ++r) gslot_sp[d].push_back(ps[r]);
+        if (fl & F_COLLIDER) gslot_sp[d].push_back(col);
+        ng += (int)gslot_sp[d].size();
+
+        ri[RI_NET_PTR] = (int)p.net_sp.size();
+        for (int q = net_ptr[i]; q < net_ptr[i + 1]; ++q) {
+            p.net_sp.push_back(net_sp[q]);
+            p.net_nu.push_back(net_nu[q]);
+        }
+        ri[RI_NET_CNT] = (int)p.net_sp.size() - ri[RI_NET_PTR];
+        ri[RI_ORIG] = i;
+        ri[RI_REV_IDX] = rev_idx[i];
+        ri[RI_PRES_IDX] = pres_idx[i];
+    }
+    p.ng = ng;
+
+    // ---- V map ----
+    VMap& v = p.vm;
+    v.nsp = nsp; v.nrxn = nrxn; v.ng = ng;
+    int o = 0;
+    v.C = o; o += nsp; v.ONE = o; o += 1;
+    v.HW = o; o += nsp; v.CP = o; o += nsp; v.YC = o; o += nsp; v.YD = o; o += nsp;
+    v.RQ = o; o += nrxn; v.RTH = o; o += nrxn; v.RA = o; o += nrxn; v.RB = o; o += nrxn;
+    v.RGN = o; o += nrxn; v.RHN = o; o += nrxn;
+    v.G = o; o += ng;
+    v.AP = o; o += nsp; v.AQ = o; o += nsp; v.AJT = o; o += nsp; v.AOM = o; o += nsp;
+    v.X = o; o += 5 * nsp;
+    v.S = o; o += S_COUNT;
+    v.NV = o;
+
+    // ---- P3: per species gather (device reaction order) ----
+    p.sp_ptr.assign(nsp + 1, 0);
+    {
+        std::vector<std::vector<std::pair<int, double>>> lists(nsp);
+        for (int d = 0; d < nrxn; ++d) {
+            const int32_t* ri = &p.ri[(size_t)d * RIW];
+            for (int q = 0; q < ri[RI_NET_CNT]; ++q)
+                lists[p.net_sp[ri[RI_NET_PTR] + q]].push_back({d, p.net_nu[ri[RI_NET_PTR] + q]});
+        }
+        for (int k = 0; k < nsp; ++k) {
+            for (auto& e : lists[k]) { p.sp_rxn.push_back(e.first); p.sp_nu.push_back(e.second); }
+            p.sp_ptr[k + 1] = (int)p.sp_rxn.size();
+        }
+    }
+
+    // ---- P4: per entry gather ----
+    const int ne = nsp * nsp;
+    p.ne = ne;
+    std::vector<std::vector<int32_t>> ea(ne), eb(ne);
+    std::vector<std::vector<double>> ec(ne);
+    for (int d = 0; d < nrxn; ++d) {
+        const int32_t* ri = &p.ri[(size_t)d * RIW];
+        const int fl = ri[RI_FLAGS];
+        const int gb = ri[RI_GBASE];
+        // column contributions of this reaction: (column j, V index, coef)
+        struct Col { int j; int a; double c; };
+        std::vector<Col> cols;
+        for (size_t t = 0; t < gslot_sp[d].size(); ++t)
+            if (gslot_sp[d][t] < last) cols.push_back({gslot_sp[d][t], v.G + gb + (int)t, 1.0});
+        if (fl & F_EFFTYPE)
+            for (auto& e : effs[d])
+                if (e.first < last) cols.push_back({e.first, v.RB + d, e.second});
+        for (auto& c : cols) {
+            for (int q = 0; q < ri[RI_NET_CNT]; ++q) {
+                const int k = p.net_sp[ri[RI_NET_PTR] + q];
+                if (k == last) continue;
+                const int e = (k + 1) + nsp * (c.j + 1);
+                ea[e].push_back(c.a); eb[e].push_back(v.ONE);
+                ec[e].push_back(c.c * p.net_nu[ri[RI_NET_PTR] + q]);
+            }
+            if (ri[RI_NET_CNT] > 0) {
+                const int e = nsp * (c.j + 1);   // energy row
+                ea[e].push_back(v.RHN + d); eb[e].push_back(c.a); ec[e].push_back(c.c);
+            }
+        }
+    }
+    p.en_ptr.assign(ne + 1, 0);
+    for (int e = 0; e < ne; ++e) {
+        p.ct_a.insert(p.ct_a.end(), ea[e].begin(), ea[e].end());
+        p.ct_b.insert(p.ct_b.end(), eb[e].begin(), eb[e].end());
+        p.ct_c.insert(p.ct_c.end(), ec[e].begin(), ec[e].end());
+        p.en_ptr[e + 1] = (int)p.ct_a.size();
+    }
+    return true;
+}
+
+}  // namespace pj

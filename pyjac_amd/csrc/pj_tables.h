@@ -1,0 +1,83 @@
+// pj_tables.h -- device-side mechanism "programs" and their host builder.
+//
+// The canonical mechanism blob (pyjac_amd/tables.py) is what crosses the C-ABI.
+// build_programs() turns it into the flat arrays the HIP kernels walk:
+// reaction records sorted by kind, per-species gather lists and per-Jacobian-
+// entry gather lists.  Everything here is plain C++ (no HIP types) so the same
+// code serves the device path and the thread-emulation test harness.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pj {
+
+// canonical blob constants (pyjac_amd/tables.py)
+constexpr int HDR = 96;
+constexpr int32_t MAGIC = 0x314D4A50;
+enum { F_REV = 1, F_THD = 2, F_PDEP = 4, F_LOW = 8, F_HIGH = 16, F_TROE = 32,
+       F_SRI = 64, F_PLOG = 128, F_TROE4 = 256, F_SRI5 = 512, F_HAS_EFF = 1024,
+       // derived on the host:
+       F_NO_DT = 2048,     // reference emits no d/dT line (create_jacobian.py:1512-1529)
+       F_EFFTYPE = 4096,   // [M] carries enhanced efficiencies -> b_i acts on every column
+       F_COLLIDER = 8192,  // falloff with a specific collider species
+       F_LASTQ = 16384 };  // the one reaction whose d/dT survives in J_nplusone (quirk)
+enum { IA_FLAGS, IA_REAC_PTR, IA_REAC_SP, IA_PROD_PTR, IA_PROD_SP, IA_NET_PTR,
+       IA_NET_SP, IA_EFF_PTR, IA_EFF_SP, IA_PLOG_PTR, IA_KC_PTR, IA_PDEP_SP,
+       IA_REV_IDX, IA_PRES_IDX, IA_SEEN };
+enum { DA_MW, DA_TMID, DA_LO, DA_HI, DA_A, DA_B, DA_E, DA_REAC_NU, DA_PROD_NU,
+       DA_NET_NU, DA_EFF, DA_PD, DA_TROE, DA_SRI, DA_PLOG, DA_KCG, DA_KCPREF,
+       DA_INFS, DA_TROE8, DA_PLOG4 };
+
+// ---- record widths ----
+constexpr int SPW = 18;   // species: invW, W, tmid, w=W/W_N, lo[7], hi[7]
+constexpr int RIW = 20;   // reaction ints
+constexpr int RDW = 16;   // reaction doubles
+enum { RI_FLAGS, RI_R0, RI_R1, RI_R2, RI_P0, RI_P1, RI_P2, RI_EFF_PTR, RI_EFF_CNT,
+       RI_COLLIDER, RI_KC_PTR, RI_KC_CNT, RI_PLOG_PTR, RI_PLOG_CNT, RI_GBASE,
+       RI_NET_PTR, RI_NET_CNT, RI_ORIG, RI_REV_IDX, RI_PRES_IDX };
+enum { RD_LNA, RD_B, RD_TA, RD_SGN, RD_NR, RD_NP, RD_LNPREF, RD_LNAR, RD_B0, RD_E0,
+       RD_B04, RD_TRA, RD_T3, RD_T1, RD_T2, RD_ANM1 };
+constexpr int PLW = 5;    // plog row: P ('%.4e'), lnP, lnA, b, Ta
+constexpr int KCW = 15;   // kc group: tmid, lo[7], hi[7]
+
+// V-array slot map (per-state working set, doubles)
+struct VMap {
+    int nsp = 0, nrxn = 0, ng = 0;
+    int C = 0, ONE = 0, HW = 0, CP = 0, YC = 0, YD = 0;
+    int RQ = 0, RTH = 0, RA = 0, RB = 0, RGN = 0, RHN = 0;   // [nrxn] each
+    int G = 0;                                               // [ng]
+    int AP = 0, AQ = 0, AJT = 0, AOM = 0;                    // [nsp] each
+    int X = 0;                                               // [5][nsp]
+    int S = 0;                                               // 7 scalars
+    int NV = 0;
+};
+enum { S_H, S_HP, S_HQ, S_SCP, S_SJT, S_CPAVG, S_DCP, S_COUNT };
+
+struct Programs {
+    int nsp = 0, nrxn = 0, nrev = 0, npres = 0, ng = 0, ne = 0;
+    VMap vm;
+    std::vector<double> sp;        // [nsp*SPW]
+    std::vector<int32_t> ri;       // [nrxn*RIW]  (device order)
+    std::vector<double> rd;        // [nrxn*RDW]
+    std::vector<int32_t> eff_sp;   // enhanced colliders (alpha != 1 only)
+    std::vector<double> eff_am1;   // alpha - 1
+    std::vector<double> kcg;       // [n*KCW]
+    std::vector<double> plog;      // [n*PLW]
+    std::vector<int32_t> net_sp;   // per-reaction net list
+    std::vector<double> net_nu;
+    // P3: per species gather over reactions
+    std::vector<int32_t> sp_ptr, sp_rxn;
+    std::vector<double> sp_nu;
+    // P4: per Jacobian entry (row + nsp*col) gather list
+    std::vector<int32_t> en_ptr, ct_a, ct_b;
+    std::vector<double> ct_c;
+    int lastq_rxn = -1;            // device index of the F_LASTQ reaction
+    std::string error;
+};
+
+// Returns false (and sets p.error) when the blob is malformed or uses a
+// feature outside the hot-path scope.
+bool build_programs(const int32_t* I, long nI, const double* D, long nD, Programs& p);
+
+}  // namespace pj

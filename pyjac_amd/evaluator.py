@@ -1,0 +1,129 @@
+"""Mechanism handle over the C ABI (host arrays and torch device tensors)."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import LAYOUT_AOS, LAYOUT_SOA, check, dptr
+from .mechanism import read_mech
+from .tables import MechTables, build_tables
+
+
+class Evaluator:
+    """One mechanism on the current HIP device.
+
+    Replaces "one compiled pyjacob module per mechanism"
+    (pyjac/pywrap/pywrap_gen.py:66-128): the mechanism is loaded as tables.
+    """
+
+    def __init__(self, mech, therm: str = None, last_spec: str = None):
+        if isinstance(mech, MechTables):
+            self.tables = mech
+            self.mechanism = None
+        elif isinstance(mech, str) and mech.endswith('.pjtab'):
+            self.tables = MechTables.load(mech)
+            self.mechanism = None
+        else:
+            self.mechanism = read_mech(mech, therm, last_spec)
+            self.tables = build_tables(self.mechanism)
+        L = _lib.lib()
+        I = np.ascontiguousarray(self.tables.I, dtype=np.int32)
+        D = np.ascontiguousarray(self.tables.D, dtype=np.float64)
+        h = ctypes.c_void_p()
+        check(L.pj_mech_create(I.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), I.size,
+                               dptr(D), D.size, ctypes.byref(h)))
+        self._h = h
+        self.nsp = L.pj_mech_nsp(h)
+        self.n_fwd = L.pj_mech_fwd_rates(h)
+        self.n_rev = L.pj_mech_rev_rates(h)
+        self.n_pres_mod = L.pj_mech_pres_mod_rates(h)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            _lib.lib().pj_mech_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tuning / options ----
+    def set_launch(self, tile_states: int = 0, threads: int = 0):
+        check(_lib.lib().pj_mech_set_launch(self._h, tile_states, threads))
+
+    def get_launch(self):
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(_lib.lib().pj_mech_get_launch(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return dict(tile_states=a.value, threads=b.value, lds_bytes=c.value)
+
+    def set_sum_last_species(self, on: bool):
+        check(_lib.lib().pj_mech_set_sum_last_species(self._h, int(on)))
+
+    # ---- bytes per unit of work ----
+    @property
+    def jacobian_bytes_per_state(self) -> int:
+        return 8 * (self.nsp + 1) + 8 * self.nsp * self.nsp
+
+    @property
+    def rates_bytes_per_state(self) -> int:
+        return 8 * (self.nsp + 1) + 8 * self.nsp
+
+    # ---- device tensors (torch is plumbing: memory + streams) ----
+    @staticmethod
+    def _stream():
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def jacobian(self, pres, y, y_layout=LAYOUT_SOA, out=None, jac_layout=LAYOUT_SOA):
+        """pres: (n,) cuda f64; y: SoA (NSP, n) or AoS (n, NSP) cuda f64.
+        Returns jac as SoA (NSP*NSP, n) or AoS (n, NSP*NSP)."""
+        import torch
+        n = pres.numel()
+        assert pres.is_cuda and y.is_cuda and pres.dtype == torch.float64 and y.dtype == torch.float64
+        assert y.is_contiguous() and pres.is_contiguous() and y.numel() == n * self.nsp
+        if out is None:
+            shape = (self.nsp * self.nsp, n) if jac_layout == LAYOUT_SOA else (n, self.nsp * self.nsp)
+            out = torch.empty(shape, dtype=torch.float64, device=pres.device)
+        check(_lib.lib().pj_eval_jacobian_dev(self._h, n, pres.data_ptr(), y.data_ptr(), y_layout,
+                                              out.data_ptr(), jac_layout, self._stream()))
+        return out
+
+    def rates(self, pres, y, y_layout=LAYOUT_SOA, want=('conc', 'fwd', 'rev', 'pres_mod',
+                                                          'spec_rates', 'dydt')):
+        """All SoA outputs of pyjacob.cu's k_dydt pass as a dict of (rows, n) tensors."""
+        import torch
+        n = pres.numel()
+        rows = dict(conc=self.nsp, fwd=self.n_fwd, rev=max(self.n_rev, 1),
+                    pres_mod=max(self.n_pres_mod, 1), spec_rates=self.nsp, dydt=self.nsp)
+        outs = {k: torch.zeros((rows[k], n), dtype=torch.float64, device=pres.device) for k in want}
+        p = lambda k: outs[k].data_ptr() if k in outs else None
+        check(_lib.lib().pj_eval_rates_dev(self._h, n, pres.data_ptr(), y.data_ptr(), y_layout,
+                                           p('conc'), p('fwd'), p('rev'), p('pres_mod'),
+                                           p('spec_rates'), p('dydt'), self._stream()))
+        return outs
+
+    def time_jacobian(self, pres, y, out, iters: int, y_layout=LAYOUT_SOA, jac_layout=LAYOUT_SOA):
+        """Average kernel time (ms) over `iters` launches, HIP events on the
+        launch stream (pj_time_jacobian_dev)."""
+        ms = ctypes.c_double()
+        check(_lib.lib().pj_time_jacobian_dev(self._h, pres.numel(), pres.data_ptr(), y.data_ptr(),
+                                              y_layout, out.data_ptr(), jac_layout, self._stream(),
+                                              iters, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- host batch driver: pyjacob.cu init / run / cleanup ----
+    def init(self, num: int) -> int:
+        return check(_lib.lib().pj_init(self._h, int(num)))
+
+    def run(self, num, padded, pres, y, conc, fwd, rev, pres_mod, spec_rates, dy, jac):
+        check(_lib.lib().pj_run(self._h, int(num), int(padded), dptr(pres), dptr(y), dptr(conc),
+                                dptr(fwd), dptr(rev), dptr(pres_mod), dptr(spec_rates), dptr(dy),
+                                dptr(jac)))
+
+    def cleanup(self):
+        check(_lib.lib().pj_cleanup(self._h))

@@ -1,0 +1,161 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and
+the reference's golden vectors.  Tolerance: BASELINE.json asks for rtol 1e-6 on
+Jacobian entries; measured with the reference functional tester's thresholded
+relative error (functional_tester/test.py:1446-1463)."""
+import numpy as np
+import pytest
+
+from conftest import MECHS, thresholded_rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+KEYS = ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _ev(name):
+    import pyjac_amd
+    return pyjac_amd.Evaluator(MECHS[name])
+
+
+def _batch_api(ev, pres, y_soa):
+    """The reference's CUDA-path call sequence (functional_tester/test.py:643-664)."""
+    from pyjac_amd import cu_pyjacob
+    cu_pyjacob.use_mechanism(ev)
+    n = pres.size
+    padded = cu_pyjacob.py_cuinit(n)
+    assert padded >= n and padded % 64 == 0
+    z = lambda r: np.zeros(r * n)
+    out = dict(conc=z(ev.nsp), fwd=z(ev.n_fwd), rev=z(max(ev.n_rev, 1)), pres_mod=z(max(ev.n_pres_mod, 1)),
+               spec_rates=z(ev.nsp), dydt=z(ev.nsp), jac=z(ev.nsp * ev.nsp))
+    cu_pyjacob.py_cujac(n, padded, pres, np.ascontiguousarray(y_soa).ravel(), out['conc'], out['fwd'],
+                        out['rev'], out['pres_mod'], out['spec_rates'], out['dydt'], out['jac'])
+    cu_pyjacob.py_cuclean()
+    return {k: v.reshape(-1, n).T for k, v in out.items()}
+
+
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])
+def test_batch_api_matches_reference_golden(name, golden, torch_cuda):
+    g = golden(name)
+    ev = _ev(name)
+    out = _batch_api(ev, g['pres'].copy(), g['y'].T)
+    rows = dict(conc=ev.nsp, fwd=ev.n_fwd, rev=ev.n_rev, pres_mod=ev.n_pres_mod, spec_rates=ev.nsp,
+                dydt=ev.nsp, jac=ev.nsp ** 2)
+    for k in KEYS:
+        if rows[k] == 0:
+            continue
+        mx, fro = thresholded_rel_err(out[k][:, :rows[k]], g[k][:, :rows[k]])
+        assert mx < RTOL and fro < 1e-9, (name, k, mx, fro)
+
+
+@pytest.mark.parametrize('ts', [64, 32, 16, 8, 4, 2, 1])
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_every_tile_mapping_and_layout(ts, layout, tables, torch_cuda):
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    name = 'synth_alltypes'
+    ev = _ev(name)
+    ev.set_launch(ts, 256)
+    n = 1000 + 37          # ragged tail
+    pres, y = synth.dist_b(n, ev.nsp, seed=9, Tlo=400, Thi=2800)
+    pres = 101325 * 10 ** np.random.default_rng(4).uniform(-1.5, 1.5, n)
+    d_p = torch.from_numpy(pres).cuda()
+    if layout == 'soa':
+        d_y = torch.from_numpy(y).cuda()
+        jac = ev.jacobian(d_p, d_y).cpu().numpy().T
+    else:
+        d_y = torch.from_numpy(np.ascontiguousarray(y.T)).cuda()
+        jac = ev.jacobian(d_p, d_y, y_layout=pyjac_amd.LAYOUT_AOS,
+                          jac_layout=pyjac_amd.LAYOUT_AOS).cpu().numpy()
+    ref = Oracle(tables(name)).batch_jacob(pres, np.ascontiguousarray(y.T))
+    assert np.isfinite(jac).all()
+    mx, fro = thresholded_rel_err(jac, ref)
+    assert mx < RTOL and fro < 1e-9, (ts, layout, mx, fro)
+
+
+def test_pasr_1020_states_all_outputs(tables, torch_cuda):
+    """Config C1 of BASELINE.json on the GPU path: the reference's PaSR fixture."""
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    ev = _ev('h2o2_n2')
+    P, Y, T = synth.pasr_states(10)
+    y = np.concatenate([T[:, None], Y[:, :-1]], axis=1)
+    out = _batch_api(ev, P.copy(), y.T)
+    o = Oracle(tables('h2o2_n2'))
+    mx, fro = thresholded_rel_err(out['jac'], o.batch_jacob(P, y))
+    assert mx < RTOL and fro < 1e-9, (mx, fro)
+    mx, _ = thresholded_rel_err(out['dydt'], o.batch_dydt(P, y))
+    assert mx < 1e-9
+
+
+def test_per_state_pyjacob_api(golden, torch_cuda):
+    """Call order and array sizes of functional_tester/test.py:1299-1327."""
+    from pyjac_amd import pyjacob
+    g = golden('synth_alltypes')
+    ev = pyjacob.use_mechanism(MECHS['synth_alltypes'])
+    nsp = ev.nsp
+    for s in (0, 17, 63):
+        P, y = float(g['pres'][s]), g['y'][s].copy()
+        mass_frac = np.concatenate([y[1:], [0.0]])
+        conc = np.zeros(nsp)
+        pyjacob.py_eval_conc(y[0], P, mass_frac, 0.0, 0.0, conc)
+        assert abs(mass_frac[-1] - (1.0 - y[1:].sum())) < 1e-15        # y_N side effect
+        fwd, rev = np.zeros(ev.n_fwd), np.zeros(ev.n_rev)
+        pyjacob.py_eval_rxn_rates(y[0], P, conc, fwd, rev)
+        pm = np.zeros(ev.n_pres_mod)
+        pyjacob.py_get_rxn_pres_mod(y[0], P, conc, pm)
+        sr = np.zeros(nsp)
+        pyjacob.py_eval_spec_rates(fwd, rev, pm, sr)
+        dy = np.zeros(nsp + 1)
+        pyjacob.py_dydt(0.0, P, np.concatenate([y, [0.0]]), dy)
+        jac = np.full(nsp * nsp, np.nan)       # no pre-zeroing needed
+        pyjacob.py_eval_jacobian(0.0, P, y, jac)
+        for k, v in (('conc', conc), ('fwd', fwd), ('rev', rev), ('pres_mod', pm), ('spec_rates', sr),
+                     ('dydt', dy[:nsp]), ('jac', jac)):
+            mx, fro = thresholded_rel_err(v, g[k][s][:v.size])
+            assert mx < RTOL, (s, k, mx)
+
+
+def test_full_size_batch_properties(tables, torch_cuda):
+    """1e6 states (BASELINE.json config 2): size-independent properties --
+    results do not depend on batch position / tiling, everything finite, and a
+    strided sample matches the oracle."""
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev('h2o2_n2')
+    n = 1_000_000
+    pres, y = synth.dist_a(n, ev.nsp)
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    jac = ev.jacobian(d_p, d_y)
+    assert torch.isfinite(jac).all()
+    # same states evaluated as a small batch at a different tile alignment
+    idx = torch.arange(5, n, 9973, device='cuda')
+    small = ev.jacobian(d_p[idx].contiguous(), d_y[:, idx].contiguous())
+    assert torch.equal(small, jac[:, idx])
+    ii = idx.cpu().numpy()
+    ref = Oracle(tables('h2o2_n2')).batch_jacob(pres[ii], np.ascontiguousarray(y[:, ii].T))
+    mx, fro = thresholded_rel_err(small.cpu().numpy().T, ref)
+    assert mx < RTOL and fro < 1e-9, (mx, fro)
+
+
+def test_empty_and_single_state(torch_cuda):
+    torch = torch_cuda
+    ev = _ev('h2o2_n2')
+    e = ev.jacobian(torch.empty(0, dtype=torch.float64, device='cuda'),
+                    torch.empty((ev.nsp, 0), dtype=torch.float64, device='cuda'))
+    assert e.shape == (ev.nsp ** 2, 0)
+    from pyjac_amd import synth
+    pres, y = synth.dist_a(1, ev.nsp)
+    j = ev.jacobian(torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda())
+    assert torch.isfinite(j).all()

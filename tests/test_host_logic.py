@@ -1,0 +1,138 @@
+"""CPU: Chemkin front end, table builder, C-ABI surface, and the kernel phases
+run through the thread-emulation harness (tests/emu) against the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import MECHS, ROOT, thresholded_rel_err
+from oracle.oracle import Oracle
+from pyjac_amd import synth
+from pyjac_amd.mechanism import read_mech
+from pyjac_amd.tables import MechTables, build_tables
+
+
+def test_parser_h2o2_counts_and_last_species():
+    m = read_mech(MECHS['h2o2'])
+    assert (m.nsp, m.n_fwd, m.n_rev, m.n_pres_mod) == (9, 28, 28, 6)      # mechanism.h of the reference
+    assert m.species_names()[-1] == 'AR'
+    m = read_mech(MECHS['h2o2_n2'])
+    assert m.nsp == 10 and m.species_names()[-1] == 'N2'
+    assert m.fwd_spec_map == list(range(10))                             # N2 already last: identity maps
+
+
+def test_parser_units_and_rev_split():
+    m = read_mech(MECHS['synth_alltypes'])
+    # explicit REV splits into two irreversible reactions (mech_interpret.py:693-713)
+    assert m.n_fwd == 34 + 1
+    r0 = m.reacs[0]                      # 2O+M<=>O2+M, A = 1.2e17 cm^6/mol^2/s -> /1000^2
+    assert r0.thd_body and r0.A == pytest.approx(1.2e17 / 1000.0 ** 2)
+    assert r0.E == 0.0
+    r2 = m.reacs[2]                      # E in cal/mol -> activation temperature
+    assert r2.E == pytest.approx(6260.0 * 4.184 / 8.3144621)
+
+
+def test_last_species_moved_to_end(tmp_path):
+    src = open(MECHS['h2o2_n2']).read().replace(
+        'H2      H       O       O2      OH      H2O     HO2     H2O2     AR      N2',
+        'H2      N2      H       O       O2      OH      H2O     HO2     H2O2     AR')
+    p = tmp_path / 'perm.inp'
+    p.write_text(src)
+    m = read_mech(str(p))
+    assert m.species_names() == ['H2', 'H', 'O', 'O2', 'OH', 'H2O', 'HO2', 'H2O2', 'AR', 'N2']
+    assert m.fwd_spec_map == [0, 2, 3, 4, 5, 6, 7, 8, 9, 1]
+    assert [m.back_spec_map[i] for i in m.fwd_spec_map] == list(range(10))
+
+
+def test_tables_roundtrip(tmp_path, tables):
+    t = tables('synth_alltypes')
+    f = tmp_path / 'm.pjtab'
+    t.save(str(f))
+    u = MechTables.load(str(f))
+    assert np.array_equal(t.I, u.I) and np.array_equal(t.D, u.D)
+
+
+def test_cabi_exports_every_declared_symbol():
+    from pyjac_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'pyjac_amd.h')).read()
+    declared = set(re.findall(r'\b(pj_[a-z_0-9]+)\s*\(', hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name)
+    assert b'gfx950' in L.pj_version()
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import pyjac_amd
+    ev = pyjac_amd.Evaluator(MECHS['h2o2_n2'])
+    assert (ev.nsp, ev.n_fwd, ev.n_rev, ev.n_pres_mod) == (10, 28, 28, 6)
+    with pytest.raises(pyjac_amd.PyjacError):
+        ev.init(64)
+    from pyjac_amd import pyjacob
+    pyjacob.use_mechanism(ev)
+    with pytest.raises(pyjac_amd.PyjacError):
+        pyjacob.py_dydt(0.0, 101325.0, np.ones(10), np.zeros(10))
+
+
+def test_product_package_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'pyjac_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cpp', '.h')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'(^|\n)\s*(from|import)\s+oracle', txt), f
+                for needle in ('libpyjac_oracle', 'libpyjac_ref', 'pjo_', 'oracle.oracle', '_ref/'):
+                    assert needle not in txt, (f, needle)
+
+
+# ---- kernel phases through the emulation harness ----
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _emu():
+    path = os.path.join(ROOT, 'tests', 'emu', '_build', 'libpj_emu.so')
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(path)
+
+
+def _run_emu(tab, pres, y_soa, TS, NT, aos):
+    n, nsp = pres.size, tab.nsp
+    out = dict(jac=np.zeros(nsp * nsp * n), conc=np.zeros(nsp * n), fwd=np.zeros(tab.nrxn * n),
+               rev=np.zeros(max(tab.nrev, 1) * n), pres_mod=np.zeros(max(tab.npres, 1) * n),
+               spec_rates=np.zeros(nsp * n), dydt=np.zeros(nsp * n))
+    I = np.ascontiguousarray(tab.I, dtype=np.int32)
+    D = np.ascontiguousarray(tab.D)
+    P = lambda a: a.ctypes.data_as(_dp)
+    rc = _emu().emu_run(I.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.c_long(I.size), P(D),
+                        ctypes.c_long(D.size), ctypes.c_long(n), P(pres), P(np.ascontiguousarray(y_soa)),
+                        P(out['jac']), int(aos), P(out['conc']), P(out['fwd']), P(out['rev']),
+                        P(out['pres_mod']), P(out['spec_rates']), P(out['dydt']), TS, NT, 0)
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize('name,TS,NT,aos', [('h2o2_n2', 64, 256, False), ('h2o2', 16, 256, False),
+                                            ('synth_alltypes', 4, 128, True),
+                                            ('synth_alltypes', 64, 64, False),
+                                            ('synth_alltypes', 1, 64, True)])
+def test_kernel_phases_match_oracle(name, TS, NT, aos, tables):
+    tab = tables(name)
+    o = Oracle(tab)
+    n = 97          # ragged: not a multiple of any tile size
+    pres, y = synth.dist_b(n, tab.nsp, seed=5, Tlo=400, Thi=2800)
+    pres = 101325 * 10 ** np.random.default_rng(2).uniform(-1.5, 1.5, n)
+    out = _run_emu(tab, pres, y, TS, NT, aos)
+    ref_j = o.batch_jacob(pres, np.ascontiguousarray(y.T))
+    got_j = out['jac'].reshape(n, -1) if aos else out['jac'].reshape(-1, n).T
+    mx, fro = thresholded_rel_err(got_j, ref_j)
+    assert mx < 1e-8 and fro < 1e-12, (mx, fro)
+    ref_d = o.batch_dydt(pres, np.ascontiguousarray(y.T))
+    mx, _ = thresholded_rel_err(out['dydt'].reshape(-1, n).T, ref_d)
+    assert mx < 1e-10
