@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: fp64 analytical Jacobians per second.
+
+A "step" is one pass of the hot path (the Jacobian kernel behind
+pj_eval_jacobian_dev) over one batch of synthetic states that is already
+resident in HBM.  One process per GPU; the batch shards trivially, so per-GPU
+work is fixed as N grows ("weak" scaling) and there is no collective in the
+timed region.  Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workloads (BASELINE.json configs):
+    h2   H2/O2+N2, 10 sp / 28 rxn, 1e6 states/GPU, Dist-A "PaSR-tiled"     (config 2)
+    gri  GRI-3.0-shaped synthetic, 53 sp / 325 rxn, 1e6 states/GPU, Dist-B (configs 3-4)
+    usc  USC-II-shaped synthetic, 111 sp / 784 rxn w/ PLOG, 2e5 states     (config 5)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md chip table (spec); 6290 measured copy
+
+WORKLOADS = {
+    'h2': dict(mech=os.path.join(ROOT, 'pyjac_amd', 'data', 'h2o2_n2.inp'), ref='h2o2_n2',
+               n=1_000_000, dist='A', label='H2/O2+N2 10sp/28rxn, 1e6 synthetic PaSR-tiled states per GPU'),
+    'gri': dict(mech=os.path.join(ROOT, 'pyjac_amd', 'data', 'gri30_shaped.inp'), ref='gri30_shaped',
+                n=1_000_000, dist='B', label='GRI-Mech-3.0-shaped synthetic 53sp/325rxn, 1e6 uniform states per GPU'),
+    'usc': dict(mech=os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'), ref='usc2_shaped',
+                n=200_000, dist='B', label='USC-Mech-II-shaped synthetic 111sp/784rxn PLOG, 2e5 uniform states per GPU'),
+}
+
+
+def make_states(w, nsp, n, seed):
+    from pyjac_amd import synth
+    if w['dist'] == 'A':
+        return synth.dist_a(n, nsp, seed=seed)
+    return synth.dist_b(n, nsp, seed=seed)
+
+
+def usable_cpus():
+    """Threads the host side may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(w, tables, target_seconds=12.0):
+    """Reference's generated C (oracle/_ref, kind "reference") when that library
+    travelled with the snapshot, else the table-driven port (kind "port"), timed
+    on this box's host cores on a bounded sample of the same workload with the
+    protocol of pyjac/performance_tester/tester.c.in:23-31."""
+    import numpy as np
+    from oracle.oracle import Oracle, Reference
+    cores = usable_cpus()
+    if Reference.available(w['ref']):
+        impl, kind = Reference(w['ref']), 'reference'
+    else:
+        impl, kind = Oracle(tables, native=True), 'port'
+    nsp = tables.nsp
+    pres, y = make_states(w, nsp, 200_000 if nsp <= 16 else 20_000, seed=99)
+    y_aos = np.ascontiguousarray(y.T)
+    n = pres.size
+    impl.batch_jacob(pres, y_aos, cores)            # warm-up pass (page faults, thread pool)
+    passes, dt = 0, 0.0
+    t0 = time.perf_counter()
+    while dt < target_seconds:
+        impl.batch_jacob(pres, y_aos, cores)
+        passes += 1
+        dt = time.perf_counter() - t0
+    return dict(value=passes * n / dt, unit='Jacobians/s', cores=cores, kind=kind,
+                sample='%d passes over %d states of the same synthetic distribution, OpenMP '
+                       'parallel-for over states (%d threads), %.1f s' % (passes, n, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default=os.environ.get('PJ_WORKLOAD', 'auto'))
+    ap.add_argument('--states', type=int, default=0, help='states per GPU (default: workload size)')
+    ap.add_argument('--layout', default='auto', choices=['auto', 'soa', 'aos'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--validate-states', type=int, default=4096,
+                    help='states per rank in the multi-GPU validation all-gather (outside the timed region)')
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import pyjac_amd
+    from pyjac_amd.dist import gather_shards, shard_checksums
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    assert world == a.gpus, 'launch with --nproc-per-node equal to --gpus'
+
+    wl = a.workload
+    if wl == 'auto':
+        wl = 'gri' if os.path.exists(WORKLOADS['gri']['mech']) else 'h2'
+    w = WORKLOADS[wl]
+    ev = pyjac_amd.Evaluator(w['mech'])
+    n = a.states or w['n']
+    # every rank owns n states (weak scaling); global batch = world * n
+    pres, y = make_states(w, ev.nsp, n, seed=20240901 + rank)
+    lay = a.layout
+    if lay == 'auto':
+        lay = 'soa' if ev.get_launch()['tile_states'] >= 16 else 'aos'
+    L = pyjac_amd.LAYOUT_SOA if lay == 'soa' else pyjac_amd.LAYOUT_AOS
+    d_p = torch.from_numpy(pres).cuda()
+    d_y = torch.from_numpy(y if L == pyjac_amd.LAYOUT_SOA else np.ascontiguousarray(y.T)).cuda()
+    shape = (ev.nsp * ev.nsp, n) if L == pyjac_amd.LAYOUT_SOA else (n, ev.nsp * ev.nsp)
+    jac = torch.empty(shape, dtype=torch.float64, device='cuda')
+
+    def step():
+        ev.jacobian(d_p, d_y, y_layout=L, out=jac, jac_layout=L)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-only duration, HIP events on the launch stream (roofline.achieved)
+    ms_kernel = ev.time_jacobian(d_p, d_y, jac, max(a.steps, 5), L, L)
+
+    finite = bool(torch.isfinite(jac[:, ::997] if L == pyjac_amd.LAYOUT_SOA else jac[::997]).all())
+    validation = None
+    if world > 1:
+        # the single RCCL all-gather of the path: reassemble a validation batch
+        nv = min(a.validate_states, n)
+        shard = (jac[:, :nv] if L == pyjac_amd.LAYOUT_SOA else jac[:nv].T).contiguous()
+        t0 = time.perf_counter()
+        g = gather_shards(shard)
+        torch.cuda.synchronize()
+        cs = shard_checksums(shard)
+        ok = bool(torch.equal(g[rank], shard)) and bool(torch.isfinite(g).all())
+        for r in range(world):
+            ok &= bool(torch.allclose(cs[r, 0], g[r].sum()))
+        validation = dict(states_per_rank=nv, gathered_bytes=int(g.numel() * 8), ok=ok,
+                          seconds=round(time.perf_counter() - t0, 4))
+
+    if rank == 0:
+        total = world * n * a.steps
+        value = total / elapsed
+        bj = ev.jacobian_bytes_per_state
+        achieved = n * bj / (ms_kernel * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % wl)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        line = {
+            'metric': 'fp64 analytical Jacobians/s', 'value': value, 'unit': 'Jacobians/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': w['label'], 'key': wl, 'states_per_gpu': n, 'nsp': ev.nsp,
+                       'n_rxn': ev.n_fwd, 'layout': lay, 'launch': ev.get_launch(),
+                       'parallelism': 'states sharded over %d GPU(s), no data-path collective' % world,
+                       'finite': finite},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'bytes_per_state': bj, 'kernel_ms': ms_kernel},
+        }
+        if validation:
+            line['validation_allgather'] = validation
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(w, ev.tables)
+            except Exception as ex:   # the baseline is reported, never required
+                line['cpu_baseline'] = {'error': repr(ex)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -355,7 +355,9 @@ int pj_mech_get_launch(const pj_mech* m, int* tile_states, int* threads, int* ld
 int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
                          double* d_jac, int jac_layout, void* stream)
 {
-    if (!m || !d_pres || !d_y || !d_jac || n < 0) return fail(PJ_EINVAL, "bad argument");
+    if (!m || n < 0) return fail(PJ_EINVAL, "bad argument");
+    if (n == 0) return PJ_OK;
+    if (!d_pres || !d_y || !d_jac) return fail(PJ_EINVAL, "null device pointer");
     Batch B;
     memset(&B, 0, sizeof(B));
     B.n = n; B.pres = d_pres; B.y = d_y; B.jac = d_jac; B.o_ld = n;
@@ -368,7 +370,9 @@ int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_
                       double* d_conc, double* d_fwd, double* d_rev, double* d_pres_mod,
                       double* d_spec_rates, double* d_dy, void* stream)
 {
-    if (!m || !d_pres || !d_y || n < 0) return fail(PJ_EINVAL, "bad argument");
+    if (!m || n < 0) return fail(PJ_EINVAL, "bad argument");
+    if (n == 0) return PJ_OK;
+    if (!d_pres || !d_y) return fail(PJ_EINVAL, "null device pointer");
     Batch B;
     memset(&B, 0, sizeof(B));
     B.n = n; B.pres = d_pres; B.y = d_y; B.o_ld = n;

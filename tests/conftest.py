@@ -13,6 +13,8 @@ MECHS = {
     'h2o2_n2': os.path.join(ROOT, 'pyjac_amd', 'data', 'h2o2_n2.inp'),
     'h2o2': os.path.join(GOLDEN, 'h2o2.inp'),
     'synth_alltypes': os.path.join(GOLDEN, 'synth_alltypes.inp'),
+    'gri30_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'gri30_shaped.inp'),
+    'usc2_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'),
 }
 
 
@@ -52,3 +54,44 @@ def tables():
             cache[name] = build_tables(read_mech(MECHS[name]))
         return cache[name]
     return get
+
+
+def rate_scales(tab, pres, y, conc, fwd, rev, pres_mod):
+    """Cancellation scales for net rates.  Near equilibrium the species rates are
+    differences of forward/reverse rates that agree to ~16 digits, so a pure
+    relative error is meaningless (SURVEY.md 7.4 'Tolerance definition'); errors
+    in omega_k / dY_k/dt / dT/dt are judged against the gross rate
+    max_i |q_f,i|, |q_r,i| (times pres_mod) of the state, propagated to each row.
+    Returns (gross[n], scale_dydt[n, NSP])."""
+    from pyjac_amd import tables as T
+    I, D = tab.I, tab.D
+    ia = lambda j, cnt: I[I[16 + j]:I[16 + j] + cnt]
+    da = lambda j, cnt: D[I[48 + j]:I[48 + j] + cnt]
+    nsp, nrxn = tab.nsp, tab.nrxn
+    rev_idx, pres_idx = ia(T.IA_REV_IDX, nrxn), ia(T.IA_PRES_IDX, nrxn)
+    mw, tmid = da(T.DA_MW, nsp), da(T.DA_TMID, nsp)
+    lo, hi = da(T.DA_LO, 7 * nsp).reshape(nsp, 7), da(T.DA_HI, 7 * nsp).reshape(nsp, 7)
+    n = pres.size
+    gross = np.zeros(n)
+    for i in range(nrxn):
+        c = pres_mod[:, pres_idx[i]] if pres_idx[i] >= 0 else 1.0
+        gross = np.maximum(gross, np.abs(fwd[:, i] * c))
+        if rev_idx[i] >= 0:
+            gross = np.maximum(gross, np.abs(rev[:, rev_idx[i]] * c))
+    rho = conc @ mw
+    Tt = y[:, 0][:, None]
+    a = np.where((Tt <= tmid[None, :])[:, :, None], lo[None], hi[None])
+    RU = 8314.4621
+    h = RU / mw * (a[..., 5] + Tt * (a[..., 0] + Tt * (a[..., 1] / 2 + Tt * (a[..., 2] / 3 + Tt * (a[..., 3] / 4 + a[..., 4] / 5 * Tt)))))
+    cp = RU / mw * (a[..., 0] + Tt * (a[..., 1] + Tt * (a[..., 2] + Tt * (a[..., 3] + a[..., 4] * Tt))))
+    Y = conc * mw / rho[:, None]
+    cpavg = (Y * cp).sum(axis=1)
+    sc = np.empty((n, nsp))
+    sc[:, 1:] = gross[:, None] * mw[None, :-1] / rho[:, None]
+    sc[:, 0] = gross * (np.abs(h) * mw).sum(axis=1) / (rho * cpavg)
+    return gross, sc
+
+
+def mixed_err(test, ref, scale, rtol=1e-6, ctol=1e-10):
+    """max |test - ref| / (rtol |ref| + ctol scale): <= 1 passes."""
+    return float((np.abs(test - ref) / (rtol * np.abs(ref) + ctol * scale + 1e-300)).max())
