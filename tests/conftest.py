@@ -95,3 +95,20 @@ def rate_scales(tab, pres, y, conc, fwd, rev, pres_mod):
 def mixed_err(test, ref, scale, rtol=1e-6, ctol=1e-10):
     """max |test - ref| / (rtol |ref| + ctol scale): <= 1 passes."""
     return float((np.abs(test - ref) / (rtol * np.abs(ref) + ctol * scale + 1e-300)).max())
+
+
+def jac_scaled_err(test, ref, nsp, rtol=1e-6, ctol=1e-12):
+    """Entry-wise Jacobian check that is meaningful for cancellation-dominated
+    entries: |d_kj| <= rtol |J_kj| + ctol max(max_j |J_k.|, max_k |J_.j|).
+    Entries that are 1e-12 of their row/column scale are differences of terms
+    ~1e12 times larger, so their relative error is bounded by the conditioning,
+    not by the implementation (the reference's own builds differ
+    by up to 6e-9 there).  test/ref: (n, nsp*nsp) column-major blocks.
+    Returns max over all entries of |d| / tolerance (<= 1 passes)."""
+    t = np.asarray(test).reshape(-1, nsp, nsp)
+    r = np.asarray(ref).reshape(-1, nsp, nsp)
+    a = np.abs(r)
+    colmax = a.max(axis=2, keepdims=True)      # blocks are [col][row]
+    rowmax = a.max(axis=1, keepdims=True)
+    tol = rtol * a + ctol * np.maximum(rowmax, colmax) + 1e-300
+    return float((np.abs(t - r) / tol).max())
