@@ -33,6 +33,8 @@ int fail(int code, const std::string& msg)
     } while (0)
 
 constexpr int MODE_JAC = 1, MODE_CONC_IN = 2;
+// timing ablations (wrong results; tools/gpu_probe.py --ablate): skip a phase
+constexpr int ABL_P2 = 16, ABL_P3 = 32, ABL_P4 = 64, ABL_P0 = 128;
 
 // conc-input variant of phase 0: the caller supplies concentrations
 // (eval_rxn_rates / get_rxn_pres_mod prototypes, pyjacob_wrapper.pyx:10-13)
@@ -48,6 +50,7 @@ PJ_DEV void phase0c(const DevMech& M, const Batch& B, const double* cin, const d
     const double T = Tin[gs], p = B.pres[gs];
     L.T = T; L.p = p; L.logT = log(T); L.invT = 1.0 / T; L.logp = log(p);
     L.Wbar = 1.0; L.rho = 1.0; L.invrho = 1.0; L.m = p / (RU_ * T); L.yN = 0.0;
+    L.cpavg = 1.0; L.dcp = 0.0; L.H = 0.0; L.scp = 0.0;
     for (int k = u; k < M.nsp; k += NU) {
         V[(M.v.C + k) * TS + s] = cin[k * B.o_ld + gs];
         V[(M.v.HW + k) * TS + s] = 0.0;
@@ -65,12 +68,17 @@ k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, doubl
     extern __shared__ __attribute__((aligned(16))) double V[];
     const int tid = threadIdx.x, NT = blockDim.x;
     const long ntiles = (B.n + TS - 1) / TS;
+    stage_prog<TS>(M, V, tid, NT);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         Lane L;
         if (mode & MODE_CONC_IN) {
             phase0c<TS>(M, B, cin, Tin, V, tid, NT, tile, L);
         } else {
-            phase0<TS>(M, B, V, tid, NT, tile, L);
+            phase0a<TS>(M, B, V, tid, NT, tile, L);
+            __syncthreads();
+            phase0b<TS>(M, B, V, tid, NT, L);
+            __syncthreads();
+            phase0c_scale<TS>(M, B, V, tid, NT, L);
             if (aux && tid / TS == 0 && L.valid) {
                 // y_N, mw_avg, rho of eval_conc (rate_subs.py:1595-1597)
                 aux[0 * B.o_ld + L.gs] = L.yN;
@@ -79,15 +87,21 @@ k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, doubl
             }
         }
         __syncthreads();
-        phase2<TS>(M, B, V, tid, NT, L);
+        if (!(mode & ABL_P2)) phase2<TS>(M, B, V, tid, NT, L);
         __syncthreads();
         if (!(mode & MODE_CONC_IN)) {
-            phase3<TS>(M, B, V, tid, NT, L);
+            if (!(mode & ABL_P3)) phase3<TS>(M, B, V, tid, NT, L);
             __syncthreads();
-            phase3b<TS>(M, B, V, tid, NT, L);
-            __syncthreads();
-            phase_dy0<TS>(M, B, V, tid, NT, L);
-            if (mode & MODE_JAC) phase4<TS>(M, B, V, tid, NT, L);
+            phase3c<TS>(M, B, V, tid, NT, L);
+            if ((mode & MODE_JAC) && !(mode & ABL_P4)) {
+                const int nr = phase4_rounds<TS>(M, NT);
+                for (int r = 0; r < nr; ++r) {
+                    phase4a<TS>(M, B, V, tid, NT, L, r);
+                    PJ_WAVE_SYNC();
+                    phase4b<TS>(M, B, V, tid, NT, L, r);
+                    PJ_WAVE_SYNC();
+                }
+            }
         }
         __syncthreads();
     }
@@ -146,8 +160,9 @@ struct pj_mech {
     DevMech M;
     bool on_device = false;
     int device = -1;
-    DevBuf<double> sp, rd, eff_am1, kcg, plog, net_nu, sp_nu, ct_c;
-    DevBuf<int32_t> ri, eff_sp, net_sp, sp_ptr, sp_rxn, en_ptr, ct_a, ct_b;
+    DevBuf<double> sp, rd, eff_am1, kcg, plog, net_nu, sp_nu;
+    DevBuf<int32_t> ri, eff_sp, net_sp, sp_ptr, sp_rxn;
+    DevBuf<uint32_t> prog;
     int ts = 0, nt = 0;       // 0 = auto
     int num_cu = 256;
     Workspace ws, ws1;
@@ -179,13 +194,13 @@ int ensure_device(pj_mech* m)
     HIPCHK(m->kcg.upload(P.kcg)); HIPCHK(m->plog.upload(P.plog));
     HIPCHK(m->net_sp.upload(P.net_sp)); HIPCHK(m->net_nu.upload(P.net_nu));
     HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
-    HIPCHK(m->en_ptr.upload(P.en_ptr)); HIPCHK(m->ct_a.upload(P.ct_a)); HIPCHK(m->ct_b.upload(P.ct_b));
-    HIPCHK(m->ct_c.upload(P.ct_c));
+    HIPCHK(m->prog.upload(P.prog));
     DevMech& M = m->M;
     M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
     M.kcg = m->kcg.p; M.plog = m->plog.p; M.net_sp = m->net_sp.p; M.net_nu = m->net_nu.p;
     M.sp_ptr = m->sp_ptr.p; M.sp_rxn = m->sp_rxn.p; M.sp_nu = m->sp_nu.p;
-    M.en_ptr = m->en_ptr.p; M.ct_a = m->ct_a.p; M.ct_b = m->ct_b.p; M.ct_c = m->ct_c.p;
+    M.prog = m->prog.p; M.prog_words = (int)P.prog.size();
+    M.p4en = P.p4en; M.p4c = P.p4c; M.p3en = P.p3en; M.p3c = P.p3c;
     m->on_device = true;
     return PJ_OK;
 }
@@ -193,16 +208,17 @@ int ensure_device(pj_mech* m)
 void pick_launch(const pj_mech* m, int* ts, int* nt, size_t* lds)
 {
     const size_t per_state = (size_t)m->P.vm.NV * 8;
+    const size_t prog_bytes = m->M.prog_in_lds ? m->P.prog.size() * 4 : 0;
     int t = m->ts;
     if (t <= 0) {
         // largest tile whose working set leaves room for two workgroups per CU
         size_t budget = 80 * 1024;
         if (const char* e = getenv("PJ_LDS_BUDGET")) budget = (size_t)atol(e);
         t = 64;
-        while (t > 1 && per_state * t > budget) t >>= 1;
+        while (t > 1 && per_state * t + 2048 + prog_bytes > budget) t >>= 1;
     }
     int n = m->nt > 0 ? m->nt : 256;
-    *ts = t; *nt = n; *lds = per_state * t;
+    *ts = t; *nt = n; *lds = per_state * t + (size_t)n * 8 + prog_bytes;
 }
 
 template <int TS>
@@ -292,6 +308,9 @@ int pj_mech_create(const int32_t* I, long nI, const double* D, long nD, pj_mech*
     memset(&M, 0, sizeof(M));
     M.nsp = m->P.nsp; M.nrxn = m->P.nrxn; M.ng = m->P.ng; M.ne = m->P.ne; M.nv = m->P.vm.NV;
     M.lastq_rxn = m->P.lastq_rxn; M.sum_last = 0; M.v = m->P.vm;
+    M.prog_words = (int)m->P.prog.size();
+    M.prog_in_lds = m->P.prog.size() * 4 <= 8192;
+    if (const char* e = getenv("PJ_PROG_LDS")) M.prog_in_lds = atoi(e);
     if (const char* e = getenv("PJ_TS")) m->ts = atoi(e);
     if (const char* e = getenv("PJ_NT")) m->nt = atoi(e);
     *out = m;
@@ -317,9 +336,8 @@ void pj_mech_destroy(pj_mech* m)
     if (!m) return;
     if (m->on_device) {
         m->sp.release(); m->rd.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release();
-        m->net_nu.release(); m->sp_nu.release(); m->ct_c.release(); m->ri.release(); m->eff_sp.release();
-        m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release(); m->en_ptr.release();
-        m->ct_a.release(); m->ct_b.release();
+        m->net_nu.release(); m->sp_nu.release(); m->prog.release(); m->ri.release(); m->eff_sp.release();
+        m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release();
         m->ws.release(); m->ws1.release();
     }
     delete m;
@@ -363,7 +381,8 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
     B.n = n; B.pres = d_pres; B.y = d_y; B.jac = d_jac; B.o_ld = n;
     set_layout(n, m->P.nsp, y_layout, &B.y_si, &B.y_ss);
     set_layout(n, m->P.nsp * m->P.nsp, jac_layout, &B.j_si, &B.j_ss);
-    return launch(m, B, MODE_JAC, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    static const int abl = getenv("PJ_ABLATE") ? atoi(getenv("PJ_ABLATE")) : 0;
+    return launch(m, B, MODE_JAC | abl, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,

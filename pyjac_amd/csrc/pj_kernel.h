@@ -49,11 +49,26 @@ struct DevMech {
     const int32_t* sp_ptr;
     const int32_t* sp_rxn;
     const double* sp_nu;
-    const int32_t* en_ptr;
-    const int32_t* ct_a;
-    const int32_t* ct_b;
-    const double* ct_c;
+    const uint32_t* prog;      // gather programs (global copy)
+    int prog_words, p4en, p4c, p3en, p3c;
+    int prog_in_lds;           // small programs are staged into LDS once per workgroup
 };
+
+// LDS layout of a workgroup (doubles): V[nv][TS] | RED[NT] | program (32-bit words)
+template <int TS>
+PJ_DEV const uint32_t* lds_prog(const DevMech& M, const double* V, int NT)
+{
+    return M.prog_in_lds ? reinterpret_cast<const uint32_t*>(V + (size_t)M.nv * TS + NT) : M.prog;
+}
+
+// copy the gather programs into LDS (once per workgroup)
+template <int TS>
+PJ_DEV void stage_prog(const DevMech& M, double* V, int tid, int NT)
+{
+    if (!M.prog_in_lds) return;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(V + (size_t)M.nv * TS + NT);
+    for (int w = tid; w < M.prog_words; w += NT) dst[w] = M.prog[w];
+}
 
 // One launch's arguments.  Element (i, s) of a 2-D quantity lives at
 // base[i * si + s * ss]; SoA (pyJac's batch layout, pyjacob.cu:139-187) is
@@ -69,14 +84,25 @@ struct Batch {
 
 struct Lane {
     double T, logT, invT, p, logp, rho, invrho, Wbar, m, yN;
+    double cpavg, dcp, H, scp;     // per-state sums (phase 0b / 3c)
     long gs;
     int valid;
 };
 
+#ifndef PJ_WAVE_SYNC
+// LDS hand-off between the lanes of ONE wavefront: LDS operations of a wave
+// execute in program order, so only the compiler has to be kept from
+// reordering the write and the dependent read.
+#define PJ_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#endif
+
 // ---------------------------------------------------------------- phase 0
-// eval_conc (rate_subs.py:1625-1710) + eval_h / eval_cp (rate_subs.py:1806-2086)
+// eval_conc (rate_subs.py:1625-1710) + eval_h / eval_cp (rate_subs.py:1806-2086).
+// 0a: each species item stores Y_k and
+// its NASA properties; 0b: every lane forms the per-state sums from LDS
+// (Y_N, Wbar, rho, cp_avg, dcp_avg/dT); 0c: the item lanes turn Y_k into C_k = rho Y_k / W_k.
 template <int TS>
-PJ_DEV void phase0(const DevMech& M, const Batch& B, double* V, int tid, int NT, long tile, Lane& L)
+PJ_DEV void phase0a(const DevMech& M, const Batch& B, double* V, int tid, int NT, long tile, Lane& L)
 {
     const int s = tid % TS, u = tid / TS, NU = NT / TS;
     const int nsp = M.nsp;
@@ -87,38 +113,66 @@ PJ_DEV void phase0(const DevMech& M, const Batch& B, double* V, int tid, int NT,
     const double* y = B.y + gs * B.y_ss;
     const double T = y[0];
     const double p = B.pres[gs];
-    double sumY = 0.0, sumYW = 0.0;
-    for (int k = 0; k < nsp - 1; ++k) {
-        const double Yk = y[(k + 1) * B.y_si];
-        sumY += Yk;
-        sumYW += Yk * M.sp[k * SPW + 0];
-    }
-    const double yN = 1.0 - sumY;
-    sumYW += yN * M.sp[(nsp - 1) * SPW + 0];
-    L.T = T; L.p = p; L.yN = yN;
+    L.T = T; L.p = p;
     L.logT = log(T); L.invT = 1.0 / T; L.logp = log(p);
-    L.Wbar = 1.0 / sumYW;
-    L.rho = p * L.Wbar / (RU_ * T);
-    L.invrho = 1.0 / L.rho;
     L.m = p / (RU_ * T);
     for (int k = u; k < nsp; k += NU) {
         const double* sp = M.sp + k * SPW;
-        const double Yk = (k == nsp - 1) ? yN : y[(k + 1) * B.y_si];
-        const double Ck = L.rho * Yk * sp[0];
         const double* a = (T <= sp[2]) ? sp + 4 : sp + 11;
         const double hW = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
                                  T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
         const double RW = RU_ * sp[0];
         const double cp = RW * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
         const double dcp = RW * (a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T)));
-        V[(M.v.C + k) * TS + s] = Ck;
+        // the last species' mass fraction is known only after the sum (phase 0b):
+        // its slots carry the unweighted values
+        const double Yk = (k == nsp - 1) ? 1.0 : y[(k + 1) * B.y_si];
+        V[(M.v.C + k) * TS + s] = Yk;
         V[(M.v.HW + k) * TS + s] = hW;
         V[(M.v.CP + k) * TS + s] = cp;
         V[(M.v.YC + k) * TS + s] = Yk * cp;
         V[(M.v.YD + k) * TS + s] = Yk * dcp;
-        if (B.conc && L.valid) B.conc[k * B.o_ld + gs] = Ck;
     }
     if (u == 0) V[M.v.ONE * TS + s] = 1.0;
+}
+
+template <int TS>
+PJ_DEV void phase0b(const DevMech& M, const Batch& B, double* V, int tid, int NT, Lane& L)
+{
+    const int s = tid % TS, u = tid / TS, NU = NT / TS;
+    const int nsp = M.nsp, last = nsp - 1;
+    double sumY = 0.0, sumYW = 0.0, cpa = 0.0, dcp = 0.0;
+    for (int k = 0; k < last; ++k) {
+        const double Yk = V[(M.v.C + k) * TS + s];
+        sumY += Yk;
+        sumYW += Yk * M.sp[k * SPW + 0];
+        cpa += V[(M.v.YC + k) * TS + s];
+        dcp += V[(M.v.YD + k) * TS + s];
+    }
+    const double yN = 1.0 - sumY;
+    sumYW += yN * M.sp[last * SPW + 0];
+    cpa += yN * V[(M.v.YC + last) * TS + s];
+    dcp += yN * V[(M.v.YD + last) * TS + s];
+    L.yN = yN;
+    L.Wbar = 1.0 / sumYW;
+    L.rho = L.p * L.Wbar / (RU_ * L.T);
+    L.invrho = 1.0 / L.rho;
+    L.cpavg = cpa;
+    L.dcp = dcp;
+}
+
+// second half of 0b, after every lane has read the unscaled slots
+template <int TS>
+PJ_DEV void phase0c_scale(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
+{
+    const int s = tid % TS, u = tid / TS, NU = NT / TS;
+    const int nsp = M.nsp, last = nsp - 1;
+    for (int k = u; k < nsp; k += NU) {
+        const double Yk = (k == last) ? L.yN : V[(M.v.C + k) * TS + s];
+        const double Ck = L.rho * Yk * M.sp[k * SPW + 0];
+        V[(M.v.C + k) * TS + s] = Ck;
+        if (B.conc && L.valid) B.conc[k * B.o_ld + L.gs] = Ck;
+    }
 }
 
 // ---------------------------------------------------------------- phase 2
@@ -249,7 +303,7 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         const double theta = (fl & F_NO_DT) ? 0.0 : (lead + c * invT * el) * L.invrho;
 
         // ---- dense-in-j scalars (create_jacobian.py:127-269) ----
-        double a = c * (nr * Rf - ((fl & F_REV) ? np_ * Rr : 0.0)) + a_extra;
+        const double a = c * (nr * Rf - ((fl & F_REV) ? np_ * Rr : 0.0)) + a_extra;
 
         // ---- sparse column values g (one per molecule slot) ----
         const double ckf = c * kf, ckr = c * kr;
@@ -271,17 +325,18 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         }
         if (fl & F_COLLIDER) { PJ_GSLOT(ri[RI_COLLIDER], bcol) }
         #undef PJ_GSLOT
+        if (fl & F_EFFTYPE)      // (alpha_ij - 1) b_i for the enhanced-collider columns
+            for (int e = 0; e < ri[RI_EFF_CNT]; ++e) {
+                const int es = M.eff_sp[ri[RI_EFF_PTR] + e];
+                if (es != last) { V[g * TS + s] = M.eff_am1[ri[RI_EFF_PTR] + e] * bM; ++g; }
+            }
 
-        double hn = 0.0;
-        for (int q = 0; q < ri[RI_NET_CNT]; ++q)
-            hn += M.net_nu[ri[RI_NET_PTR] + q] * V[(M.v.HW + M.net_sp[ri[RI_NET_PTR] + q]) * TS + s];
-
-        V[(M.v.RQ + i) * TS + s] = c * R;
+        const double q = c * R;
+        const double rp = (L.Wbar * L.invrho) * (q - a) + bM;
+        V[(M.v.RQ + i) * TS + s] = q;
         V[(M.v.RTH + i) * TS + s] = theta;
-        V[(M.v.RA + i) * TS + s] = a;
-        V[(M.v.RB + i) * TS + s] = bM;
-        V[(M.v.RGN + i) * TS + s] = gN;
-        V[(M.v.RHN + i) * TS + s] = hn;
+        V[(M.v.RP + i) * TS + s] = rp;
+        V[(M.v.RQQ + i) * TS + s] = rp + gN;
 
         if (L.valid) {
             if (B.fwd) B.fwd[ri[RI_ORIG] * B.o_ld + L.gs] = Rf;
@@ -292,43 +347,43 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
 }
 
 // ---------------------------------------------------------------- phase 3
-// eval_spec_rates (rate_subs.py:1297-1542) and the per-species dense vectors.
+// eval_spec_rates (rate_subs.py:1297-1542) and the per-species dense vectors
+//   P_k = sum_i nu_ki [(Wbar/rho)(q_i - a_i) + bM_i],  Q_k = P_k + sum_i nu_ki gN_i.
 template <int TS>
 PJ_DEV void phase3(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
 {
     const int s = tid % TS, u = tid / TS, NU = NT / TS;
     const int last = M.nsp - 1;
     for (int k = u; k < M.nsp; k += NU) {
-        double om = 0.0, jt = 0.0, A = 0.0, Bs = 0.0, qn = 0.0, jtq = 0.0;
-        for (int q = M.sp_ptr[k]; q < M.sp_ptr[k + 1]; ++q) {
-            const int i = M.sp_rxn[q];
-            const double nu = M.sp_nu[q];
-            const double th = V[(M.v.RTH + i) * TS + s];
-            om += nu * V[(M.v.RQ + i) * TS + s];
-            jt += nu * th;
-            A += nu * V[(M.v.RA + i) * TS + s];
-            Bs += nu * V[(M.v.RB + i) * TS + s];
-            qn += nu * V[(M.v.RGN + i) * TS + s];
-            if (i == M.lastq_rxn) jtq = nu * th;
+        double om = 0.0, jt = 0.0, P = 0.0, Q = 0.0, jtq = 0.0;
+        const uint32_t* PG = lds_prog<TS>(M, V, NT);
+        const uint32_t en = PG[M.p3en + k];
+        const uint2* cb = reinterpret_cast<const uint2*>(PG + M.p3c) + (en >> 8);
+        for (int b = 0; b < (int)(en & 255u); ++b) {
+            const uint2 cw = cb[b];
+            const uint32_t c4[4] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16};
+            #pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int i = (int)(c4[x] >> 3);
+                const int inu = (int)(c4[x] & 7u) - 4;
+                if (inu == 0) continue;          // padding
+                const double nu = (double)inu;
+                const double th = V[(M.v.RTH + i) * TS + s];
+                om += nu * V[(M.v.RQ + i) * TS + s];
+                jt += nu * th;
+                P += nu * V[(M.v.RP + i) * TS + s];
+                Q += nu * V[(M.v.RQQ + i) * TS + s];
+                if (i == M.lastq_rxn) jtq = nu * th;
+            }
         }
         // Reference quirk kept for parity (create_jacobian.py:2786-2818): only the
         // last reaction's d/dT of the LAST species reaches jac[0].
-        const double jt_e = (k == last && !M.sum_last) ? jtq : jt;
-        const double uu = (L.Wbar * L.invrho) * (om - A);
-        const double P = uu + Bs;
-        const double Q = P + qn;
-        const double hW = V[(M.v.HW + k) * TS + s];
-        const double cp = V[(M.v.CP + k) * TS + s];
+        if (k == last && !M.sum_last) jt = jtq;
         const double Wk = M.sp[k * SPW + 1];
         V[(M.v.AP + k) * TS + s] = P;
         V[(M.v.AQ + k) * TS + s] = Q;
         V[(M.v.AJT + k) * TS + s] = jt;
         V[(M.v.AOM + k) * TS + s] = om;
-        V[(M.v.X + 0 * M.nsp + k) * TS + s] = hW * om;
-        V[(M.v.X + 1 * M.nsp + k) * TS + s] = hW * P;
-        V[(M.v.X + 2 * M.nsp + k) * TS + s] = hW * Q;
-        V[(M.v.X + 3 * M.nsp + k) * TS + s] = om * Wk * cp;
-        V[(M.v.X + 4 * M.nsp + k) * TS + s] = hW * jt_e;
         if (L.valid) {
             if (B.spec_rates) B.spec_rates[k * B.o_ld + L.gs] = om;
             if (B.dy && k < last) B.dy[(k + 1) * B.o_ld + L.gs] = om * Wk * L.invrho;
@@ -336,68 +391,100 @@ PJ_DEV void phase3(const DevMech& M, const Batch& B, double* V, int tid, int NT,
     }
 }
 
-// per-state scalar sums
+// per-state sums H = sum_k h_k W_k omega_k and SCP = sum_k omega_k W_k cp_k, needed by
+// the lanes that finish the energy row (il == 0) and by dT/dt of dydt
+// (rate_subs.py:2171-2335)
 template <int TS>
-PJ_DEV void phase3b(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
+PJ_DEV void phase3c(const DevMech& M, const Batch& B, double* V, int tid, int NT, Lane& L)
 {
-    const int s = tid % TS, u = tid / TS, NU = NT / TS;
-    for (int r = u; r < S_COUNT; r += NU) {
-        const int base = (r < 5) ? M.v.X + r * M.nsp : (r == S_CPAVG ? M.v.YC : M.v.YD);
-        double acc = 0.0;
-        for (int k = 0; k < M.nsp; ++k) acc += V[(base + k) * TS + s];
-        V[(M.v.S + r) * TS + s] = acc;
+    const int s = tid % TS, il = (tid % 64) / TS, u = tid / TS;
+    if (il != 0) return;
+    double H = 0.0, scp = 0.0;
+    for (int k = 0; k < M.nsp; ++k) {
+        const double om = V[(M.v.AOM + k) * TS + s];
+        H += V[(M.v.HW + k) * TS + s] * om;
+        scp += om * M.sp[k * SPW + 1] * V[(M.v.CP + k) * TS + s];
     }
-}
-
-// dT/dt of dydt (rate_subs.py:2171-2335); needs phase3b's sums
-template <int TS>
-PJ_DEV void phase_dy0(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
-{
-    const int s = tid % TS, u = tid / TS;
-    if (u == 0 && B.dy && L.valid)
-        B.dy[L.gs] = -V[(M.v.S + S_H) * TS + s] / (L.rho * V[(M.v.S + S_CPAVG) * TS + s]);
+    L.H = H; L.scp = scp;
+    if (u == 0 && B.dy && L.valid) B.dy[L.gs] = -H / (L.rho * L.cpavg);
 }
 
 // ---------------------------------------------------------------- phase 4
-// Jacobian entries (create_jacobian.py:2850-2938 species block, 3095-3234
-// energy row, 1853-1905 jac[0]); every entry of the NSP x NSP block is written.
+// Jacobian, one column per wavefront per round (create_jacobian.py:2850-2938
+// species block, 3095-3234 energy row, 1853-1905 jac[0]).  Within a wavefront
+// the IL = 64/TS item lanes of a state walk the NSP+1 "rows" of the column in
+// chunks: row 0 is the energy entry, rows 1..NSP-1 the species rows, row NSP
+// the eliminated last species (it enters the energy row only).  Each lane
+// keeps its part of  sum_k h_k W_k M_kj  (phase4a) and the row-0 lane adds the
+// IL parts up through the RED exchange area (phase4b).  Every entry of the
+// NSP x NSP block is written.
 template <int TS>
-PJ_DEV void phase4(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
+PJ_DEV int phase4_rounds(const DevMech& M, int NT) { return (M.nsp + NT / 64 - 1) / (NT / 64); }
+
+template <int TS>
+PJ_DEV void phase4a(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L, int round)
 {
-    const int s = tid % TS, u = tid / TS, NU = NT / TS;
+    constexpr int IL = 64 / TS;
+    const int s = tid % TS, lane = tid % 64, il = lane / TS, w = tid / 64, NW = NT / 64;
     const int nsp = M.nsp, last = nsp - 1;
-    for (int e = u; e < M.ne; e += NU) {
-        const int col = e / nsp, row = e - col * nsp;
-        double sum = 0.0;
-        for (int q = M.en_ptr[e]; q < M.en_ptr[e + 1]; ++q)
-            sum += M.ct_c[q] * V[M.ct_a[q] * TS + s] * V[M.ct_b[q] * TS + s];
-        double val;
-        if (col > 0) {
-            const int j = col - 1;
-            const double* spj = M.sp + j * SPW;
-            if (row > 0) {
-                const int k = row - 1;
-                val = (M.sp[k * SPW + 1] * spj[0]) *
-                      (V[(M.v.AP + k) * TS + s] - spj[3] * V[(M.v.AQ + k) * TS + s] + sum);
-            } else {
-                const double cpavg = V[(M.v.S + S_CPAVG) * TS + s];
-                const double icp = 1.0 / cpavg;
-                const double HP = V[(M.v.S + S_HP) * TS + s], HQ = V[(M.v.S + S_HQ) * TS + s];
-                const double H = V[(M.v.S + S_H) * TS + s];
-                val = -(HP - spj[3] * HQ + sum) * spj[0] * icp +
-                      (V[(M.v.CP + j) * TS + s] - V[(M.v.CP + last) * TS + s]) * H * L.invrho * icp * icp;
-            }
-        } else if (row > 0) {
-            const int k = row - 1;
-            val = M.sp[k * SPW + 1] * V[(M.v.AJT + k) * TS + s];
-        } else {
-            const double cpavg = V[(M.v.S + S_CPAVG) * TS + s];
-            const double H = V[(M.v.S + S_H) * TS + s];
-            val = -(V[(M.v.S + S_SCP) * TS + s] - (V[(M.v.S + S_DCP) * TS + s] / cpavg) * H +
-                    L.rho * V[(M.v.S + S_SJT) * TS + s]) / (L.rho * cpavg);
+    const int col = round * NW + w;
+    double part = 0.0;
+    if (col == 0) {
+        // d/dT column (create_jacobian.py:2728-2845): rows W_k * sum_i nu_ki theta_i
+        for (int r = (il == 0 ? IL : il); r <= nsp; r += IL) {
+            const int k = r - 1;
+            const double jt = V[(M.v.AJT + k) * TS + s];
+            part += V[(M.v.HW + k) * TS + s] * jt;
+            if (k < last && L.valid) B.jac[r * B.j_si + L.gs * B.j_ss] = M.sp[k * SPW + 1] * jt;
         }
-        if (L.valid) B.jac[e * B.j_si + L.gs * B.j_ss] = val;
+    } else if (col < nsp) {
+        const int j = col - 1;
+        const double wj = M.sp[j * SPW + 3];
+        const double iWj = M.sp[j * SPW + 0];
+        const uint32_t* PG = lds_prog<TS>(M, V, NT);
+        const uint32_t* ep = PG + M.p4en + nsp * j;
+        const uint2* cb = reinterpret_cast<const uint2*>(PG + M.p4c);
+        for (int r = (il == 0 ? IL : il); r <= nsp; r += IL) {
+            const int k = r - 1;
+            const uint32_t en = ep[k];
+            double sum = V[(M.v.AP + k) * TS + s] - wj * V[(M.v.AQ + k) * TS + s];
+            const uint2* c = cb + (en >> 8);
+            for (int b = 0; b < (int)(en & 255u); ++b) {
+                const uint2 cw = c[b];
+                const uint32_t c0 = cw.x & 0xffffu, c1 = cw.x >> 16, c2 = cw.y & 0xffffu, c3 = cw.y >> 16;
+                sum += (double)((int)(c0 & 7u) - 4) * V[(c0 >> 3) * TS + s] +
+                       (double)((int)(c1 & 7u) - 4) * V[(c1 >> 3) * TS + s] +
+                       (double)((int)(c2 & 7u) - 4) * V[(c2 >> 3) * TS + s] +
+                       (double)((int)(c3 & 7u) - 4) * V[(c3 >> 3) * TS + s];
+            }
+            part += V[(M.v.HW + k) * TS + s] * sum;
+            if (k < last && L.valid)
+                B.jac[(r + nsp * col) * B.j_si + L.gs * B.j_ss] = (M.sp[k * SPW + 1] * iWj) * sum;
+        }
     }
+    V[M.v.RED * TS + tid] = part;
+}
+
+template <int TS>
+PJ_DEV void phase4b(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L, int round)
+{
+    constexpr int IL = 64 / TS;
+    const int s = tid % TS, lane = tid % 64, il = lane / TS, w = tid / 64, NW = NT / 64;
+    const int nsp = M.nsp, last = nsp - 1;
+    const int col = round * NW + w;
+    if (col >= nsp || il != 0) return;
+    double tot = 0.0;
+    for (int x = 0; x < IL; ++x) tot += V[M.v.RED * TS + w * 64 + x * TS + s];
+    double val;
+    if (col == 0) {
+        val = -(L.scp - (L.dcp / L.cpavg) * L.H + L.rho * tot) / (L.rho * L.cpavg);
+    } else {
+        const int j = col - 1;
+        const double icp = 1.0 / L.cpavg;
+        val = -tot * M.sp[j * SPW + 0] * icp +
+              (V[(M.v.CP + j) * TS + s] - V[(M.v.CP + last) * TS + s]) * L.H * L.invrho * icp * icp;
+    }
+    if (L.valid) B.jac[(nsp * col) * B.j_si + L.gs * B.j_ss] = val;
 }
 
 }  // namespace pj

@@ -197,6 +197,11 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         for (int r = 0; r < nrs; ++r) gslot_sp[d].push_back(rs[r]);
         if (fl & F_REV) for (int r = 0; r < nps; ++r) gslot_sp[d].push_back(ps[r]);
         if (fl & F_COLLIDER) gslot_sp[d].push_back(col);
+        // enhanced colliders of an [M] with efficiencies: one slot each holding
+        // (alpha_ij - 1) b_i, in eff-list order (the last species goes to gN instead)
+        if (fl & F_EFFTYPE)
+            for (auto& e : effs[d])
+                if (e.first != last) gslot_sp[d].push_back(e.first);
         ng += (int)gslot_sp[d].size();
 
         ri[RI_NET_PTR] = (int)p.net_sp.size();
@@ -217,12 +222,10 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
     int o = 0;
     v.C = o; o += nsp; v.ONE = o; o += 1;
     v.HW = o; o += nsp; v.CP = o; o += nsp; v.YC = o; o += nsp; v.YD = o; o += nsp;
-    v.RQ = o; o += nrxn; v.RTH = o; o += nrxn; v.RA = o; o += nrxn; v.RB = o; o += nrxn;
-    v.RGN = o; o += nrxn; v.RHN = o; o += nrxn;
+    v.RQ = o; o += nrxn; v.RTH = o; o += nrxn; v.RP = o; o += nrxn; v.RQQ = o; o += nrxn;
     v.G = o; o += ng;
     v.AP = o; o += nsp; v.AQ = o; o += nsp; v.AJT = o; o += nsp; v.AOM = o; o += nsp;
-    v.X = o; o += 5 * nsp;
-    v.S = o; o += S_COUNT;
+    v.RED = o;                       // partial-sum exchange area: NT doubles, NOT scaled by TS
     v.NV = o;
 
     // ---- P3: per species gather (device reaction order) ----
@@ -240,43 +243,50 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         }
     }
 
-    // ---- P4: per entry gather ----
-    const int ne = nsp * nsp;
+    if (v.NV >= 8192 || nrxn >= 8192) { p.error = "mechanism too large for the 13-bit program encoding"; return false; }
+
+    // ---- P4: per species-block entry gather, packed for LDS ----
+    const int ne = nsp * (nsp - 1);
     p.ne = ne;
-    std::vector<std::vector<int32_t>> ea(ne), eb(ne);
-    std::vector<std::vector<double>> ec(ne);
+    std::vector<std::vector<uint16_t>> codes(ne);
     for (int d = 0; d < nrxn; ++d) {
         const int32_t* ri = &p.ri[(size_t)d * RIW];
-        const int fl = ri[RI_FLAGS];
         const int gb = ri[RI_GBASE];
-        // column contributions of this reaction: (column j, V index, coef)
-        struct Col { int j; int a; double c; };
-        std::vector<Col> cols;
-        for (size_t t = 0; t < gslot_sp[d].size(); ++t)
-            if (gslot_sp[d][t] < last) cols.push_back({gslot_sp[d][t], v.G + gb + (int)t, 1.0});
-        if (fl & F_EFFTYPE)
-            for (auto& e : effs[d])
-                if (e.first < last) cols.push_back({e.first, v.RB + d, e.second});
-        for (auto& c : cols) {
+        for (size_t t = 0; t < gslot_sp[d].size(); ++t) {
+            const int j = gslot_sp[d][t];
+            if (j >= last) continue;
             for (int q = 0; q < ri[RI_NET_CNT]; ++q) {
                 const int k = p.net_sp[ri[RI_NET_PTR] + q];
-                if (k == last) continue;
-                const int e = (k + 1) + nsp * (c.j + 1);
-                ea[e].push_back(c.a); eb[e].push_back(v.ONE);
-                ec[e].push_back(c.c * p.net_nu[ri[RI_NET_PTR] + q]);
-            }
-            if (ri[RI_NET_CNT] > 0) {
-                const int e = nsp * (c.j + 1);   // energy row
-                ea[e].push_back(v.RHN + d); eb[e].push_back(c.a); ec[e].push_back(c.c);
+                const int nu = (int)p.net_nu[ri[RI_NET_PTR] + q];
+                if (nu < -4 || nu > 3) { p.error = "net stoichiometric coefficient out of range"; return false; }
+                codes[k + nsp * j].push_back((uint16_t)(((v.G + gb + (int)t) << 3) | (nu + 4)));
             }
         }
     }
-    p.en_ptr.assign(ne + 1, 0);
-    for (int e = 0; e < ne; ++e) {
-        p.ct_a.insert(p.ct_a.end(), ea[e].begin(), ea[e].end());
-        p.ct_b.insert(p.ct_b.end(), eb[e].begin(), eb[e].end());
-        p.ct_c.insert(p.ct_c.end(), ec[e].begin(), ec[e].end());
-        p.en_ptr[e + 1] = (int)p.ct_a.size();
+    auto pack = [&](const std::vector<std::vector<uint16_t>>& lists, uint16_t pad, int* en_off, int* c_off) -> bool {
+        *en_off = (int)p.prog.size();
+        p.prog.resize(p.prog.size() + lists.size());
+        if (p.prog.size() & 1) p.prog.push_back(0);          // keep the code area 8-byte aligned
+        *c_off = (int)p.prog.size();
+        int batch = 0;
+        for (size_t e = 0; e < lists.size(); ++e) {
+            std::vector<uint16_t> l = lists[e];
+            while (l.size() % 4) l.push_back(pad);
+            const int nb = (int)l.size() / 4;
+            if (nb > 255 || batch >= (1 << 24)) return false;
+            p.prog[*en_off + e] = ((uint32_t)batch << 8) | (uint32_t)nb;
+            for (size_t x = 0; x < l.size(); x += 2) p.prog.push_back((uint32_t)l[x] | ((uint32_t)l[x + 1] << 16));
+            batch += nb;
+        }
+        return true;
+    };
+    if (!pack(codes, (uint16_t)((v.ONE << 3) | 4), &p.p4en, &p.p4c)) { p.error = "P4 program overflow"; return false; }
+    {
+        std::vector<std::vector<uint16_t>> l3(nsp);
+        for (int k = 0; k < nsp; ++k)
+            for (int q = p.sp_ptr[k]; q < p.sp_ptr[k + 1]; ++q)
+                l3[k].push_back((uint16_t)((p.sp_rxn[q] << 3) | ((int)p.sp_nu[q] + 4)));
+        if (!pack(l3, (uint16_t)4, &p.p3en, &p.p3c)) { p.error = "P3 program overflow"; return false; }
     }
     return true;
 }

@@ -45,14 +45,12 @@ constexpr int KCW = 15;   // kc group: tmid, lo[7], hi[7]
 struct VMap {
     int nsp = 0, nrxn = 0, ng = 0;
     int C = 0, ONE = 0, HW = 0, CP = 0, YC = 0, YD = 0;
-    int RQ = 0, RTH = 0, RA = 0, RB = 0, RGN = 0, RHN = 0;   // [nrxn] each
+    int RQ = 0, RTH = 0, RP = 0, RQQ = 0;                    // [nrxn] each
     int G = 0;                                               // [ng]
     int AP = 0, AQ = 0, AJT = 0, AOM = 0;                    // [nsp] each
-    int X = 0;                                               // [5][nsp]
-    int S = 0;                                               // 7 scalars
+    int RED = 0;                                             // start of the NT-double exchange area (not x TS)
     int NV = 0;
 };
-enum { S_H, S_HP, S_HQ, S_SCP, S_SJT, S_CPAVG, S_DCP, S_COUNT };
 
 struct Programs {
     int nsp = 0, nrxn = 0, nrev = 0, npres = 0, ng = 0, ne = 0;
@@ -66,12 +64,16 @@ struct Programs {
     std::vector<double> plog;      // [n*PLW]
     std::vector<int32_t> net_sp;   // per-reaction net list
     std::vector<double> net_nu;
-    // P3: per species gather over reactions
+    // P3: per species gather over reactions (global copy: k_spec_rates)
     std::vector<int32_t> sp_ptr, sp_rxn;
     std::vector<double> sp_nu;
-    // P4: per Jacobian entry (row + nsp*col) gather list
-    std::vector<int32_t> en_ptr, ct_a, ct_b;
-    std::vector<double> ct_c;
+    // LDS-resident program (staged once per workgroup), 32-bit words:
+    //   p4en[nsp*(nsp-1)]  entry (k + nsp*j, k < nsp incl. last species): (first_batch << 8) | n_batches
+    //   p4c [2*batches]    4 codes per batch, code = (V slot << 3) | (nu + 4), pad = (ONE << 3) | 4
+    //   p3en[nsp]          species: (first_batch << 8) | n_batches
+    //   p3c [2*batches]    code = (reaction << 3) | (nu + 4), pad = reaction 0, nu 0
+    std::vector<uint32_t> prog;
+    int p4en = 0, p4c = 0, p3en = 0, p3c = 0;
     int lastq_rxn = -1;            // device index of the F_LASTQ reaction
     std::string error;
 };

@@ -7,8 +7,10 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+struct uint2 { unsigned x, y; };
 using std::exp; using std::log; using std::fmax;
 #define PJ_DEV static inline
+#define PJ_WAVE_SYNC() ((void)0)
 #include "../../pyjac_amd/csrc/pj_kernel.h"
 #include "../../pyjac_amd/csrc/pj_tables.cpp"
 
@@ -17,17 +19,24 @@ using namespace pj;
 template <int TS>
 static void run_tiles(const DevMech& M, const Batch& B, int NT, int want_jac)
 {
-    std::vector<double> V((size_t)M.nv * TS);
+    std::vector<double> V((size_t)M.nv * TS + NT + (M.prog_words + 1) / 2 + 1);
+    for (int tid = 0; tid < NT; ++tid) stage_prog<TS>(M, V.data(), tid, NT);
     std::vector<Lane> L(NT);
     const long ntiles = (B.n + TS - 1) / TS;
     for (long t = 0; t < ntiles; ++t) {
-        for (int tid = 0; tid < NT; ++tid) phase0<TS>(M, B, V.data(), tid, NT, t, L[tid]);
+        for (int tid = 0; tid < NT; ++tid) phase0a<TS>(M, B, V.data(), tid, NT, t, L[tid]);
+        for (int tid = 0; tid < NT; ++tid) phase0b<TS>(M, B, V.data(), tid, NT, L[tid]);
+        for (int tid = 0; tid < NT; ++tid) phase0c_scale<TS>(M, B, V.data(), tid, NT, L[tid]);
         for (int tid = 0; tid < NT; ++tid) phase2<TS>(M, B, V.data(), tid, NT, L[tid]);
         for (int tid = 0; tid < NT; ++tid) phase3<TS>(M, B, V.data(), tid, NT, L[tid]);
-        for (int tid = 0; tid < NT; ++tid) phase3b<TS>(M, B, V.data(), tid, NT, L[tid]);
-        for (int tid = 0; tid < NT; ++tid) phase_dy0<TS>(M, B, V.data(), tid, NT, L[tid]);
-        if (want_jac)
-            for (int tid = 0; tid < NT; ++tid) phase4<TS>(M, B, V.data(), tid, NT, L[tid]);
+        for (int tid = 0; tid < NT; ++tid) phase3c<TS>(M, B, V.data(), tid, NT, L[tid]);
+        if (want_jac) {
+            const int nr = phase4_rounds<TS>(M, NT);
+            for (int r = 0; r < nr; ++r) {
+                for (int tid = 0; tid < NT; ++tid) phase4a<TS>(M, B, V.data(), tid, NT, L[tid], r);
+                for (int tid = 0; tid < NT; ++tid) phase4b<TS>(M, B, V.data(), tid, NT, L[tid], r);
+            }
+        }
     }
 }
 
@@ -45,7 +54,8 @@ extern "C" int emu_run(const int32_t* I, long nI, const double* D, long nD, long
     M.eff_sp = P.eff_sp.data(); M.eff_am1 = P.eff_am1.data(); M.kcg = P.kcg.data();
     M.plog = P.plog.data(); M.net_sp = P.net_sp.data(); M.net_nu = P.net_nu.data();
     M.sp_ptr = P.sp_ptr.data(); M.sp_rxn = P.sp_rxn.data(); M.sp_nu = P.sp_nu.data();
-    M.en_ptr = P.en_ptr.data(); M.ct_a = P.ct_a.data(); M.ct_b = P.ct_b.data(); M.ct_c = P.ct_c.data();
+    M.prog = P.prog.data(); M.prog_words = (int)P.prog.size();
+    M.p4en = P.p4en; M.p4c = P.p4c; M.p3en = P.p3en; M.p3c = P.p3c; M.prog_in_lds = (TS % 2 == 0);
     Batch B;
     B.n = n; B.pres = pres; B.y = y_soa; B.y_si = n; B.y_ss = 1;
     B.jac = jac;
