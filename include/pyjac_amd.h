@@ -67,6 +67,22 @@ int pj_mech_set_sum_last_species(pj_mech* m, int on);
 int pj_mech_set_launch(pj_mech* m, int tile_states, int threads);
 int pj_mech_get_launch(const pj_mech* m, int* tile_states, int* threads, int* lds_bytes);
 
+/* ---- register-resident specialisation for small mechanisms (pj_lane.hip) ----
+ * pyJac compiles every mechanism (python -m pyjac + libgen); here compilation is
+ * optional: the table-driven kernel serves any mechanism, and a mechanism-
+ * specific build of ONE hand-written kernel (constexpr tables, everything in
+ * registers) can be attached for speed.  The two paths agree to rounding. */
+unsigned long long pj_mech_spec_hash(const pj_mech* m);
+/* write the constexpr header consumed by pj_lane.hip (-DPJS_HEADER='"path"') */
+int pj_mech_emit_spec(const pj_mech* m, const char* header_path);
+/* dlopen a library built from pj_lane.hip for this mechanism (hash-checked) and
+ * route pj_eval_jacobian_dev / pj_run / pj_eval_jacob through it */
+int pj_mech_attach_spec(pj_mech* m, const char* library_path);
+/* 1 if a specialised kernel is attached */
+int pj_mech_has_spec(const pj_mech* m);
+/* 0: table-driven kernel even if a specialisation is attached; 1 (default): use it */
+int pj_mech_use_spec(pj_mech* m, int on);
+
 /* ---- device-resident batch evaluation (pointers are device pointers on the
  *      current HIP device; stream is a hipStream_t or NULL) ---- */
 int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y,

@@ -34,6 +34,11 @@ SIGNATURES = {
     'pj_mech_set_launch': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     'pj_mech_get_launch': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int),
                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    'pj_mech_spec_hash': (ctypes.c_ulonglong, [_vp]),
+    'pj_mech_emit_spec': (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    'pj_mech_attach_spec': (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    'pj_mech_has_spec': (ctypes.c_int, [_vp]),
+    'pj_mech_use_spec': (ctypes.c_int, [_vp, ctypes.c_int]),
     'pj_eval_jacobian_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_int, _vp,
                                             ctypes.c_int, _vp]),
     'pj_eval_rates_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_int,

@@ -1,6 +1,8 @@
 // pj_api.hip -- HIP kernels + C ABI (include/pyjac_amd.h) for gfx950.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -166,6 +168,10 @@ struct pj_mech {
     int ts = 0, nt = 0;       // 0 = auto
     int num_cu = 256;
     Workspace ws, ws1;
+    // attached register-resident specialisation (pj_lane.hip)
+    void* spec_lib = nullptr;
+    int (*spec_jac)(long, const double*, const double*, long, long, double*, long, long, int, void*) = nullptr;
+    bool use_spec = true;
 };
 
 namespace {
@@ -340,6 +346,7 @@ void pj_mech_destroy(pj_mech* m)
         m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release();
         m->ws.release(); m->ws1.release();
     }
+    if (m->spec_lib) dlclose(m->spec_lib);
     delete m;
 }
 
@@ -349,6 +356,38 @@ int pj_mech_rev_rates(const pj_mech* m) { return m->P.nrev; }
 int pj_mech_pres_mod_rates(const pj_mech* m) { return m->P.npres; }
 
 int pj_mech_set_sum_last_species(pj_mech* m, int on) { m->M.sum_last = on ? 1 : 0; return PJ_OK; }
+
+unsigned long long pj_mech_spec_hash(const pj_mech* m) { return programs_hash(m->P); }
+
+int pj_mech_emit_spec(const pj_mech* m, const char* header_path)
+{
+    FILE* f = fopen(header_path, "w");
+    if (!f) return fail(PJ_EIO, std::string("cannot write ") + header_path);
+    const std::string h = emit_spec_header(m->P);
+    const bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
+    fclose(f);
+    return ok ? PJ_OK : fail(PJ_EIO, "short write");
+}
+
+int pj_mech_attach_spec(pj_mech* m, const char* library_path)
+{
+    void* lib = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(PJ_EIO, std::string("dlopen: ") + dlerror());
+    auto hash = (unsigned long long (*)(void))dlsym(lib, "pj_spec_hash");
+    auto jac = (decltype(m->spec_jac))dlsym(lib, "pj_spec_jacobian");
+    if (!hash || !jac) { dlclose(lib); return fail(PJ_EINVAL, "not a pj_lane specialisation library"); }
+    if (hash() != programs_hash(m->P)) {
+        dlclose(lib);
+        return fail(PJ_EINVAL, "specialisation was built for a different mechanism (hash mismatch)");
+    }
+    if (m->spec_lib) dlclose(m->spec_lib);
+    m->spec_lib = lib;
+    m->spec_jac = jac;
+    return PJ_OK;
+}
+
+int pj_mech_has_spec(const pj_mech* m) { return m->spec_jac != nullptr; }
+int pj_mech_use_spec(pj_mech* m, int on) { m->use_spec = on != 0; return PJ_OK; }
 
 int pj_mech_set_launch(pj_mech* m, int tile_states, int threads)
 {
@@ -381,6 +420,13 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
     B.n = n; B.pres = d_pres; B.y = d_y; B.jac = d_jac; B.o_ld = n;
     set_layout(n, m->P.nsp, y_layout, &B.y_si, &B.y_ss);
     set_layout(n, m->P.nsp * m->P.nsp, jac_layout, &B.j_si, &B.j_ss);
+    if (m->spec_jac && m->use_spec) {
+        int rc = ensure_device(m);
+        if (rc) return rc;
+        if (m->spec_jac(n, d_pres, d_y, B.y_si, B.y_ss, d_jac, B.j_si, B.j_ss, m->M.sum_last, stream))
+            return fail(PJ_EHIP, "specialised kernel launch failed");
+        return PJ_OK;
+    }
     static const int abl = getenv("PJ_ABLATE") ? atoi(getenv("PJ_ABLATE")) : 0;
     return launch(m, B, MODE_JAC | abl, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
@@ -456,8 +502,11 @@ static int run_ws(pj_mech* m, Workspace& w, int num, const double* pres, const d
     B.n = num; B.pres = w.pres; B.y = w.y; B.y_si = num; B.y_ss = 1; B.o_ld = num;
     B.jac = w.jac; B.j_si = num; B.j_ss = 1;
     B.conc = w.conc; B.fwd = w.fwd; B.rev = w.rev; B.pres_mod = w.pm; B.spec_rates = w.sr; B.dy = w.dy;
-    int rc = launch(m, B, jac ? MODE_JAC : 0, nullptr, nullptr, aux ? w.aux : nullptr, 0);
+    const bool spec = jac && m->spec_jac && m->use_spec;
+    int rc = launch(m, B, (jac && !spec) ? MODE_JAC : 0, nullptr, nullptr, aux ? w.aux : nullptr, 0);
     if (rc) return rc;
+    if (spec && m->spec_jac(num, w.pres, w.y, B.y_si, B.y_ss, w.jac, B.j_si, B.j_ss, m->M.sum_last, nullptr))
+        return fail(PJ_EHIP, "specialised kernel launch failed");
     HIPCHK(hipDeviceSynchronize());
     if (conc) HIPCHK(hipMemcpy(conc, w.conc, 8 * n * nsp, hipMemcpyDeviceToHost));
     if (fwd) HIPCHK(hipMemcpy(fwd, w.fwd, 8 * n * m->P.nrxn, hipMemcpyDeviceToHost));

@@ -1,0 +1,327 @@
+// pj_lane.hip -- register-resident Jacobian kernel for SMALL mechanisms.
+//
+// One thermochemical state per lane; the mechanism is injected as constexpr
+// tables (pj::emit_spec_header -> PJS_HEADER), every loop over species,
+// reactions, molecule slots and Jacobian entries is fully unrolled, so all
+// per-state arrays (C_k, omega_k, P_k, Q_k, the sparse S entries ...) have
+// compile-time indices and live in VGPRs: no LDS, no table loads, no
+// divergence except the NASA / PLOG range selects.  State loads and Jacobian
+// stores are lane-contiguous (SoA) = fully coalesced.
+//
+// Same formulation as pj_kernel.h (which stays the path for mechanisms whose
+// unrolled code or register footprint would be too large); reference
+// emitters: pyjac/core/rate_subs.py:254-2335, pyjac/core/create_jacobian.py:2189-3298.
+//
+// Built per mechanism:  hipcc --offload-arch=gfx950 -O3 -DPJS_HEADER='"<hdr>"' -shared -fPIC pj_lane.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <type_traits>
+
+#include "pj_tables.h"
+#include PJS_HEADER
+
+using namespace pj;
+
+namespace {
+
+constexpr double RU_ = 8314.4621;
+constexpr double INV_LN10 = 0.434294481903251828;
+constexpr int NSP = pjs::NSP, NRXN = pjs::NRXN, LAST = pjs::NSP - 1, ONE = pjs::NSP;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1, so every
+// table index inside is a constant expression (guaranteed, not left to the unroller)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_impl<I + 1, N>(f);
+    }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
+
+struct Args {
+    long n;
+    const double* pres;
+    const double* y; long y_si, y_ss;
+    double* jac; long j_si, j_ss;
+    int sum_last;
+};
+
+__global__ void __launch_bounds__(64) k_lane(Args A)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n) return;
+    const double* y = A.y + s * A.y_ss;
+    const double T = y[0];
+    const double p = A.pres[s];
+    const double logT = log(T), invT = 1.0 / T, logp = log(p);
+
+    // ---- eval_conc + NASA properties ----
+    double C[NSP + 1], hW[NSP], cpk[NSP];
+    double sumY = 0.0, sumYW = 0.0;
+#pragma unroll
+    for (int k = 0; k < LAST; ++k) {
+        C[k] = y[(k + 1) * A.y_si];
+        sumY += C[k];
+        sumYW += C[k] * pjs::SP[k][0];
+    }
+    const double yN = 1.0 - sumY;
+    C[LAST] = yN;
+    sumYW += yN * pjs::SP[LAST][0];
+    const double Wbar = 1.0 / sumYW;
+    const double rho = p * Wbar / (RU_ * T), invrho = 1.0 / rho;
+    const double mconc = p / (RU_ * T);
+    double cpavg = 0.0, dcpavg = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSP; ++k) {
+        const bool lo = T <= pjs::SP[k][2];
+        double a[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+        hW[k] = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                       T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+        const double RW = RU_ * pjs::SP[k][0];
+        cpk[k] = RW * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+        const double dcp = RW * (a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T)));
+        cpavg += C[k] * cpk[k];
+        dcpavg += C[k] * dcp;
+        C[k] = rho * C[k] * pjs::SP[k][0];
+    }
+    C[ONE] = 1.0;
+
+    double om[NSP], jt[NSP], P[NSP], Q[NSP], S[pjs::NNZ];
+    double jtq = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSP; ++k) { om[k] = 0.0; jt[k] = 0.0; P[k] = 0.0; Q[k] = 0.0; }
+#pragma unroll
+    for (int e = 0; e < pjs::NNZ; ++e) S[e] = 0.0;
+
+    // ---- reactions: compile-time loop, every table read is a constant expression ----
+#define PJL_INL __attribute__((always_inline))
+    static_for<NRXN>([&](auto ic) PJL_INL {
+        constexpr int i = decltype(ic)::value;
+        constexpr int fl = pjs::RI[i][RI_FLAGS];
+        double lnk, dlnk;
+        if constexpr ((fl & F_PLOG) != 0) {
+            constexpr int pp = pjs::RI[i][RI_PLOG_PTR], np = pjs::RI[i][RI_PLOG_CNT];
+            // interval select chain over the breakpoints (rate_subs.py:598-632)
+            lnk = pjs::PLOG[pp][2] + pjs::PLOG[pp][3] * logT - pjs::PLOG[pp][4] * invT;
+            dlnk = pjs::PLOG[pp][3] + pjs::PLOG[pp][4] * invT;
+            static_for<np - 1>([&](auto qc) PJL_INL {
+                constexpr int q = decltype(qc)::value + 1;
+                constexpr double P1 = pjs::PLOG[pp + q - 1][0], L1 = pjs::PLOG[pp + q - 1][1],
+                                 A1 = pjs::PLOG[pp + q - 1][2], B1 = pjs::PLOG[pp + q - 1][3],
+                                 E1 = pjs::PLOG[pp + q - 1][4];
+                constexpr double P2 = pjs::PLOG[pp + q][0], L2 = pjs::PLOG[pp + q][1], A2 = pjs::PLOG[pp + q][2],
+                                 B2 = pjs::PLOG[pp + q][3], E2 = pjs::PLOG[pp + q][4];
+                const double k1 = A1 + B1 * logT - E1 * invT;
+                const double k2 = A2 + B2 * logT - E2 * invT;
+                const double f = (logp - L1) / (L2 - L1);
+                const bool in = p > P1 && p <= P2;
+                lnk = in ? k1 + (k2 - k1) * f : lnk;
+                dlnk = in ? B1 + E1 * invT + ((B2 - B1) + (E2 - E1) * invT) * f : dlnk;
+            });
+            {
+                constexpr double Pn = pjs::PLOG[pp + np - 1][0], An = pjs::PLOG[pp + np - 1][2],
+                                 Bn = pjs::PLOG[pp + np - 1][3], En = pjs::PLOG[pp + np - 1][4];
+                const bool hi = p > Pn;
+                lnk = hi ? An + Bn * logT - En * invT : lnk;
+                dlnk = hi ? Bn + En * invT : dlnk;
+            }
+        } else {
+            lnk = pjs::RD[i][RD_LNA] + pjs::RD[i][RD_B] * logT - pjs::RD[i][RD_TA] * invT;
+            dlnk = pjs::RD[i][RD_B] + pjs::RD[i][RD_TA] * invT;
+        }
+        const double kf = pjs::RD[i][RD_SGN] * exp(lnk);
+
+        double kr = 0.0, TdlnKc = 0.0;
+        if constexpr ((fl & F_REV) != 0) {
+            double lnKc = pjs::RD[i][RD_LNPREF];
+            static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJL_INL {
+                constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
+                const bool lo = T <= pjs::KCG[g][0];
+                double a[7];
+                static_for<7>([&](auto xc) PJL_INL {
+                    constexpr int x = decltype(xc)::value;
+                    a[x] = lo ? pjs::KCG[g][1 + x] : pjs::KCG[g][8 + x];
+                });
+                lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
+                TdlnKc += a[1] + T * (a[2] + T * (2.0 * a[3] + T * (3.0 * a[4] + 4.0 * a[5] * T))) + a[6] * invT;
+            });
+            kr = kf * exp(-lnKc);
+        }
+
+        const double cr0 = C[pjs::RI[i][RI_R0]], cr1 = C[pjs::RI[i][RI_R1]], cr2 = C[pjs::RI[i][RI_R2]];
+        const double cp0 = C[pjs::RI[i][RI_P0]], cp1 = C[pjs::RI[i][RI_P1]], cp2 = C[pjs::RI[i][RI_P2]];
+        const double Rf = kf * (cr0 * cr1 * cr2);
+        const double Rr = kr * (cp0 * cp1 * cp2);
+        const double R = Rf - Rr;
+
+        double c = 1.0, lead = 0.0, a_extra = 0.0, bM = 0.0, bcol = 0.0;
+        if constexpr ((fl & (F_THD | F_PDEP)) != 0) {
+            double Mc = mconc;
+            static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJL_INL {
+                constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                Mc += pjs::EFF_AM1[e][0] * C[pjs::EFF_SP[e][0]];
+            });
+            if constexpr ((fl & F_THD) != 0) {
+                c = Mc;
+                lead = -c * R * invT;
+                if constexpr ((fl & F_EFFTYPE) != 0) { bM = R; a_extra = c * R; }
+            } else {
+                constexpr int col = pjs::RI[i][RI_COLLIDER];
+                double conc_temp = Mc;
+                if constexpr (col >= 0) conc_temp = C[col >= 0 ? col : 0];
+                const double e0T = pjs::RD[i][RD_E0] * invT;
+                const double k0kinf = exp(pjs::RD[i][RD_LNAR] + pjs::RD[i][RD_B0] * logT - e0T);
+                const double Pr = conc_temp * k0kinf;
+                const double i1Pr = 1.0 / (1.0 + Pr);
+                double F = 1.0, extra = 0.0, Xtroe = 0.0;
+                if constexpr ((fl & F_TROE) != 0) {
+                    constexpr double ta = pjs::RD[i][RD_TRA], T3 = pjs::RD[i][RD_T3], T1 = pjs::RD[i][RD_T1],
+                                     T2 = pjs::RD[i][RD_T2];
+                    const double e3 = exp(-T / T3), e1 = exp(-T / T1);
+                    double Fcent = (1.0 - ta) * e3 + ta * e1;
+                    double dF = -((1.0 - ta) / T3) * e3 - (ta / T1) * e1;
+                    if constexpr ((fl & F_TROE4) != 0) {
+                        const double e2 = exp(-T2 * invT);
+                        Fcent += e2;
+                        dF += T2 * invT * invT * e2;
+                    }
+                    const double lF = log(fmax(Fcent, 1.0e-300));
+                    const double lgF = lF * INV_LN10;
+                    const double lgPr = log(fmax(Pr, 1.0e-300)) * INV_LN10;
+                    const double At = lgPr - 0.67 * lgF - 0.4;
+                    const double Bt = 0.806 - 1.1762 * lgF - 0.14 * lgPr;
+                    const double iB = 1.0 / Bt;
+                    const double iden = 1.0 / (1.0 + At * At * iB * iB);
+                    F = exp(lF * iden);
+                    const double lnF_AB = 2.0 * lF * At * iB * iB * iB * iden * iden;
+                    const double iFc = 1.0 / Fcent;
+                    Xtroe = lnF_AB * (INV_LN10 * Bt + (0.14 * INV_LN10) * At);
+                    extra = (iFc * iden - lnF_AB * (-(0.67 * INV_LN10) * Bt + (1.1762 * INV_LN10) * At) * iFc) * dF -
+                            Xtroe * (pjs::RD[i][RD_B0] + e0T - 1.0) * invT;
+                }
+                double dpr = (pjs::RD[i][RD_B04] + e0T - 1.0) * invT * i1Pr;
+                double X;
+                if constexpr ((fl & F_LOW) != 0) { c = F * Pr * i1Pr; X = i1Pr - Xtroe; }
+                else { c = F * i1Pr; X = -Pr * i1Pr - Xtroe; dpr = -Pr * dpr; }
+                lead = c * (dpr + extra) * R;
+                if constexpr ((fl & (F_EFFTYPE | F_COLLIDER)) != 0) {
+                    const double pmt = X * R;
+                    a_extra = c * pmt;
+                    const double bb = pmt * k0kinf * F * i1Pr;
+                    if constexpr ((fl & F_COLLIDER) != 0) bcol = bb; else bM = bb;
+                }
+            }
+        }
+
+        constexpr double nr = pjs::RD[i][RD_NR], np_ = pjs::RD[i][RD_NP];
+        double el = R * dlnk + Rf * (1.0 - nr);
+        if constexpr ((fl & F_REV) != 0) el -= Rr * ((1.0 - np_) - TdlnKc);
+        const double theta = (fl & F_NO_DT) ? 0.0 : (lead + c * invT * el) * invrho;
+        const double a = c * (nr * Rf - ((fl & F_REV) ? np_ * Rr : 0.0)) + a_extra;
+        const double ckf = c * kf, ckr = c * kr;
+
+        // sparse values per molecule slot, accumulated straight into S (compile-time indices)
+        double gN = bM * pjs::RD[i][RD_ANM1];
+        constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
+        auto slot = [&](auto spc, const double gv) PJL_INL {
+            constexpr int sp = decltype(spc)::value;
+            if constexpr (sp == LAST) gN += gv;
+            else if constexpr (sp != ONE) {
+                static_for<ncnt>([&](auto qc) PJL_INL {
+                    constexpr int q = np0 + decltype(qc)::value;
+                    constexpr int si = pjs::SIDX[pjs::NET_SP[q][0]][sp];
+                    static_assert(si >= 0, "sparse pattern and program disagree");
+                    S[si] += pjs::NET_NU[q][0] * gv;
+                });
+            }
+        };
+        slot(std::integral_constant<int, pjs::RI[i][RI_R0]>{}, ckf * (cr1 * cr2));
+        slot(std::integral_constant<int, pjs::RI[i][RI_R1]>{}, ckf * (cr0 * cr2));
+        slot(std::integral_constant<int, pjs::RI[i][RI_R2]>{}, ckf * (cr0 * cr1));
+        if constexpr ((fl & F_REV) != 0) {
+            slot(std::integral_constant<int, pjs::RI[i][RI_P0]>{}, -ckr * (cp1 * cp2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -ckr * (cp0 * cp2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -ckr * (cp0 * cp1));
+        }
+        if constexpr ((fl & F_COLLIDER) != 0)
+            slot(std::integral_constant<int, (pjs::RI[i][RI_COLLIDER] >= 0 ? pjs::RI[i][RI_COLLIDER] : ONE)>{}, bcol);
+        if constexpr ((fl & F_EFFTYPE) != 0) {
+            static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJL_INL {
+                constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                constexpr int es = pjs::EFF_SP[e][0];
+                // the last species' enhanced efficiency is already in gN (RD_ANM1)
+                if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, pjs::EFF_AM1[e][0] * bM);
+            });
+        }
+
+        const double q_ = c * R;
+        const double rp = (Wbar * invrho) * (q_ - a) + bM;
+        const double rq = rp + gN;
+        static_for<ncnt>([&](auto qc) PJL_INL {
+            constexpr int q = np0 + decltype(qc)::value;
+            constexpr int k = pjs::NET_SP[q][0];
+            constexpr double nu = pjs::NET_NU[q][0];
+            om[k] += nu * q_;
+            jt[k] += nu * theta;
+            P[k] += nu * rp;
+            Q[k] += nu * rq;
+            if constexpr (k == LAST && i == pjs::LASTQ) jtq = nu * theta;
+        });
+    });
+    // reference quirk (create_jacobian.py:2786-2818), see pj_kernel.h phase 3
+    if (!A.sum_last) jt[LAST] = jtq;
+
+    // ---- Jacobian block: every entry written ----
+    double H = 0.0, scp = 0.0, sjt = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSP; ++k) {
+        H += hW[k] * om[k];
+        scp += om[k] * pjs::SP[k][1] * cpk[k];
+        sjt += hW[k] * jt[k];
+    }
+    double* J = A.jac + s * A.j_ss;
+    const double icp = 1.0 / cpavg;
+    J[0] = -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg);
+#pragma unroll
+    for (int k = 0; k < LAST; ++k) J[(k + 1) * A.j_si] = pjs::SP[k][1] * jt[k];
+    static_for<LAST>([&](auto jc) PJL_INL {
+        constexpr int j = decltype(jc)::value;
+        constexpr double wj = pjs::SP[j][3], iWj = pjs::SP[j][0];
+        double tot = 0.0;
+        static_for<NSP>([&](auto kc) PJL_INL {
+            constexpr int k = decltype(kc)::value;
+            constexpr int si = pjs::SIDX[k][j];
+            double m = P[k] - wj * Q[k];
+            if constexpr (si >= 0) m += S[si];
+            tot += hW[k] * m;
+            if constexpr (k < LAST) J[(k + 1 + NSP * (j + 1)) * A.j_si] = (pjs::SP[k][1] * iWj) * m;
+        });
+        J[(NSP * (j + 1)) * A.j_si] = -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp;
+    });
+#undef PJL_INL
+}
+
+}  // namespace
+
+extern "C" {
+
+unsigned long long pj_spec_hash(void) { return PJS_HASH; }
+int pj_spec_nsp(void) { return NSP; }
+
+// layouts as in include/pyjac_amd.h: element (i, s) at base[i*si + s*ss]
+int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
+                     long j_si, long j_ss, int sum_last, void* stream)
+{
+    if (n <= 0) return 0;
+    Args A{n, pres, y, y_si, y_ss, jac, j_si, j_ss, sum_last};
+    const unsigned grid = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(k_lane, dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // extern "C"

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <cstdio>
+#include <cstring>
 
 namespace pj {
 
@@ -289,6 +291,76 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         if (!pack(l3, (uint16_t)4, &p.p3en, &p.p3c)) { p.error = "P3 program overflow"; return false; }
     }
     return true;
+}
+
+uint64_t programs_hash(const Programs& p)
+{
+    uint64_t h = 1469598103934665603ULL;
+    auto mix = [&](const void* d, size_t n) {
+        const unsigned char* b = (const unsigned char*)d;
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ULL; }
+    };
+    int hdr[4] = {p.nsp, p.nrxn, p.ng, p.lastq_rxn};
+    mix(hdr, sizeof(hdr));
+    mix(p.sp.data(), p.sp.size() * 8); mix(p.ri.data(), p.ri.size() * 4); mix(p.rd.data(), p.rd.size() * 8);
+    mix(p.eff_sp.data(), p.eff_sp.size() * 4); mix(p.eff_am1.data(), p.eff_am1.size() * 8);
+    mix(p.kcg.data(), p.kcg.size() * 8); mix(p.plog.data(), p.plog.size() * 8);
+    mix(p.net_sp.data(), p.net_sp.size() * 4); mix(p.net_nu.data(), p.net_nu.size() * 8);
+    mix(p.prog.data(), p.prog.size() * 4);
+    return h;
+}
+
+std::string emit_spec_header(const Programs& p)
+{
+    std::string o;
+    char buf[64];
+    auto d = [&](double x) { snprintf(buf, sizeof buf, "%a", x); o += buf; };
+    auto arr_d = [&](const char* name, const std::vector<double>& v, int width) {
+        const size_t rows = v.size() / width;
+        o += "constexpr double "; o += name; o += "[" + std::to_string(rows ? rows : 1) + "][" + std::to_string(width) + "] = {";
+        if (!rows) o += "{}";
+        for (size_t r = 0; r < rows; ++r) {
+            o += "{";
+            for (int c = 0; c < width; ++c) { d(v[r * width + c]); o += ","; }
+            o += "},\n";
+        }
+        o += "};\n";
+    };
+    auto arr_i = [&](const char* name, const std::vector<int32_t>& v, int width) {
+        const size_t rows = v.size() / width;
+        o += "constexpr int "; o += name; o += "[" + std::to_string(rows ? rows : 1) + "][" + std::to_string(width) + "] = {";
+        if (!rows) o += "{}";
+        for (size_t r = 0; r < rows; ++r) {
+            o += "{";
+            for (int c = 0; c < width; ++c) o += std::to_string(v[r * width + c]) + ",";
+            o += "},\n";
+        }
+        o += "};\n";
+    };
+    const int nsp = p.nsp;
+    snprintf(buf, sizeof buf, "0x%016llxULL", (unsigned long long)programs_hash(p));
+    o += "// generated by pj::emit_spec_header -- mechanism constants for pj_lane.hip\n#pragma once\n";
+    o += std::string("#define PJS_HASH ") + buf + "\nnamespace pjs {\n";
+    // sparse-entry index map: [k][j] -> slot or -1
+    std::vector<int32_t> sidx((size_t)nsp * nsp, -1);
+    int nnz = 0;
+    for (int j = 0; j < nsp - 1; ++j)
+        for (int k = 0; k < nsp; ++k)
+            if (p.prog[p.p4en + k + nsp * j] & 255u) sidx[(size_t)k * nsp + j] = nnz++;
+    o += "constexpr int NSP = " + std::to_string(nsp) + ", NRXN = " + std::to_string(p.nrxn) +
+         ", NNZ = " + std::to_string(nnz ? nnz : 1) + ", LASTQ = " + std::to_string(p.lastq_rxn) + ";\n";
+    arr_d("SP", p.sp, SPW);
+    arr_i("RI", p.ri, RIW);
+    arr_d("RD", p.rd, RDW);
+    arr_i("EFF_SP", p.eff_sp, 1);
+    arr_d("EFF_AM1", p.eff_am1, 1);
+    arr_d("KCG", p.kcg, KCW);
+    arr_d("PLOG", p.plog, PLW);
+    arr_i("NET_SP", p.net_sp, 1);
+    arr_d("NET_NU", p.net_nu, 1);
+    arr_i("SIDX", sidx, nsp);
+    o += "}  // namespace pjs\n";
+    return o;
 }
 
 }  // namespace pj

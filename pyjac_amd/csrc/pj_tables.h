@@ -78,6 +78,12 @@ struct Programs {
     std::string error;
 };
 
+// 64-bit FNV-1a of the device programs: identifies a mechanism for the
+// register-resident specialisation (pj_lane.hip).
+uint64_t programs_hash(const Programs& p);
+// Mechanism constants as a C++ header (constexpr arrays) for pj_lane.hip.
+std::string emit_spec_header(const Programs& p);
+
 // Returns false (and sets p.error) when the blob is malformed or uses a
 // feature outside the hot-path scope.
 bool build_programs(const int32_t* I, long nI, const double* D, long nD, Programs& p);

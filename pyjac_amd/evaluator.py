@@ -19,7 +19,10 @@ class Evaluator:
     (pyjac/pywrap/pywrap_gen.py:66-128): the mechanism is loaded as tables.
     """
 
-    def __init__(self, mech, therm: str = None, last_spec: str = None):
+    def __init__(self, mech, therm: str = None, last_spec: str = None, specialize: str = 'auto'):
+        """specialize: 'auto' attaches a prebuilt register-resident kernel for
+        this mechanism if pyjac_amd/spec/ holds one; 'build' also compiles it
+        when missing (hipcc, seconds; small mechanisms only); 'off' never."""
         if isinstance(mech, MechTables):
             self.tables = mech
             self.mechanism = None
@@ -40,6 +43,41 @@ class Evaluator:
         self.n_fwd = L.pj_mech_fwd_rates(h)
         self.n_rev = L.pj_mech_rev_rates(h)
         self.n_pres_mod = L.pj_mech_pres_mod_rates(h)
+        if specialize != 'off':
+            self.specialize(build=(specialize == 'build'))
+
+    # ---- register-resident specialisation (csrc/pj_lane.hip) ----
+    SPEC_MAX_NSP, SPEC_MAX_RXN = 16, 64
+
+    def spec_path(self) -> str:
+        h = _lib.lib().pj_mech_spec_hash(self._h)
+        return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'spec', 'libpj_spec_%016x.so' % h)
+
+    def specialize(self, build: bool = False) -> bool:
+        """Attach (and optionally build) the mechanism-specific lane kernel."""
+        L = _lib.lib()
+        so = self.spec_path()
+        if not os.path.exists(so):
+            if not build or self.nsp > self.SPEC_MAX_NSP or self.n_fwd > self.SPEC_MAX_RXN:
+                return False
+            import subprocess
+            here = os.path.dirname(os.path.abspath(__file__))
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            hdr = so[:-3] + '.h'
+            check(L.pj_mech_emit_spec(self._h, hdr.encode()))
+            hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+            subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+                                   '-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
+                                   '-o', so, os.path.join(here, 'csrc', 'pj_lane.hip')])
+        check(L.pj_mech_attach_spec(self._h, so.encode()))
+        return True
+
+    @property
+    def has_spec(self) -> bool:
+        return bool(_lib.lib().pj_mech_has_spec(self._h))
+
+    def use_spec(self, on: bool):
+        check(_lib.lib().pj_mech_use_spec(self._h, int(on)))
 
     def close(self):
         if getattr(self, '_h', None):

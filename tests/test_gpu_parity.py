@@ -68,6 +68,7 @@ def test_every_tile_mapping_and_layout(ts, layout, tables, torch_cuda):
     torch = torch_cuda
     name = 'synth_alltypes'
     ev = _ev(name)
+    ev.use_spec(False)          # this test is about the table-driven kernel's mappings
     ev.set_launch(ts, 256)
     if ev.get_launch()['lds_bytes'] > 160 * 1024:
         pytest.skip('tile of %d states needs %d B of LDS' % (ts, ev.get_launch()['lds_bytes']))
@@ -200,3 +201,34 @@ def test_large_mechanisms_vs_oracle(name, n, layout, tables, torch_cuda):
     # large mechanisms have entries 1e-13 of their row scale: judge those by the scaled metric
     sc = jac_scaled_err(jac, ref, ev.nsp)
     assert sc <= 1.0 and fro < 1e-9, (name, layout, sc, mx, fro)
+
+
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_specialised_lane_kernel(name, layout, tables, torch_cuda):
+    """The register-resident specialisation (csrc/pj_lane.hip) against the oracle
+    and against the table-driven kernel on the same inputs."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = pyjac_amd.Evaluator(MECHS[name], specialize='build')
+    assert ev.has_spec
+    n = 4099
+    pres, y = synth.dist_b(n, ev.nsp, seed=31, Tlo=400, Thi=2800)
+    pres = 101325 * 10 ** np.random.default_rng(8).uniform(-1.5, 1.5, n)
+    d_p = torch.from_numpy(pres).cuda()
+    if layout == 'soa':
+        d_y, L = torch.from_numpy(y).cuda(), pyjac_amd.LAYOUT_SOA
+    else:
+        d_y, L = torch.from_numpy(np.ascontiguousarray(y.T)).cuda(), pyjac_amd.LAYOUT_AOS
+    spec = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+    ev.use_spec(False)
+    gen = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+    if layout == 'soa':
+        spec, gen = spec.T, gen.T
+    ref = Oracle(tables(name)).batch_jacob(pres, np.ascontiguousarray(y.T))
+    mx, fro = thresholded_rel_err(spec, ref)
+    assert mx < RTOL and fro < 1e-9, (name, layout, mx, fro)
+    mx, fro = thresholded_rel_err(spec, gen)
+    assert mx < RTOL and fro < 1e-9, ('spec vs table-driven', mx, fro)

@@ -21,9 +21,10 @@ ap.add_argument('--ts', default='64,32,16,8')
 ap.add_argument('--nt', default='256')
 ap.add_argument('--layout', default='soa')
 ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--spec', default='off')
 a = ap.parse_args()
 
-ev = pyjac_amd.Evaluator(a.mech)
+ev = pyjac_amd.Evaluator(a.mech, specialize=a.spec)
 n = a.n
 if ev.nsp == 10 and 'h2o2' in a.mech:
     pres, y = synth.dist_a(n, ev.nsp)
@@ -40,7 +41,7 @@ for ts in [int(x) for x in a.ts.split(',')]:
             ev.time_jacobian(d_p, d_y, out, 2, lay, lay)
             ms = ev.time_jacobian(d_p, d_y, out, a.iters, lay, lay)
             gbs = n * ev.jacobian_bytes_per_state / ms / 1e6
-            print(json.dumps(dict(mech=os.path.basename(a.mech), n=n, ts=ts, nt=nt, layout=a.layout,
+            print(json.dumps(dict(spec=ev.has_spec, mech=os.path.basename(a.mech), n=n, ts=ts, nt=nt, layout=a.layout,
                                   lds=ev.get_launch()['lds_bytes'], ms=round(ms, 4),
                                   jac_per_s=round(n / ms * 1e3), GBps=round(gbs, 1),
                                   frac_hbm=round(gbs / 8000, 4))), flush=True)
