@@ -49,7 +49,11 @@ struct Args {
     int sum_last;
 };
 
-__global__ void __launch_bounds__(64) k_lane(Args A)
+#ifndef PJL_BLOCK
+#define PJL_BLOCK 64
+#endif
+
+__global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= A.n) return;
@@ -319,8 +323,8 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
 {
     if (n <= 0) return 0;
     Args A{n, pres, y, y_si, y_ss, jac, j_si, j_ss, sum_last};
-    const unsigned grid = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(k_lane, dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    const unsigned grid = (unsigned)((n + PJL_BLOCK - 1) / PJL_BLOCK);
+    hipLaunchKernelGGL(k_lane, dim3(grid), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
