@@ -53,10 +53,18 @@ struct Args {
 #define PJL_BLOCK 64
 #endif
 
+#ifndef PJL_PERSIST
+#define PJL_PERSIST 2      // resident workgroups per slot; states are walked grid-stride
+#endif
+
 __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 {
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n) return;
+    // NASA lo/hi coefficient rows live in LDS: one ds_read per coefficient pair at an
+    // address picked by the range test, instead of a v_cndmask per 32-bit half
+    __shared__ __attribute__((aligned(16))) double LT[pjs::LT_SIZE];
+    for (int w = threadIdx.x; w < pjs::LT_SIZE; w += PJL_BLOCK) LT[w] = pjs::LTAB[w];
+    __syncthreads();
+  for (long s = (long)blockIdx.x * PJL_BLOCK + threadIdx.x; s < A.n; s += (long)gridDim.x * PJL_BLOCK) {
     const double* y = A.y + s * A.y_ss;
     const double T = y[0];
     const double p = A.pres[s];
@@ -80,10 +88,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     double cpavg = 0.0, dcpavg = 0.0;
 #pragma unroll
     for (int k = 0; k < NSP; ++k) {
-        const bool lo = T <= pjs::SP[k][2];
-        double a[7];
-#pragma unroll
-        for (int c = 0; c < 7; ++c) a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+        const double* a = LT + pjs::LT_SP + k * 16 + ((T <= pjs::SP[k][2]) ? 0 : 8);
         hW[k] = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
                        T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
         const double RW = RU_ * pjs::SP[k][0];
@@ -145,12 +150,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             double lnKc = pjs::RD[i][RD_LNPREF];
             static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJL_INL {
                 constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
-                const bool lo = T <= pjs::KCG[g][0];
-                double a[7];
-                static_for<7>([&](auto xc) PJL_INL {
-                    constexpr int x = decltype(xc)::value;
-                    a[x] = lo ? pjs::KCG[g][1 + x] : pjs::KCG[g][8 + x];
-                });
+                const double* a = LT + pjs::LT_KC + g * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
                 lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
                 TdlnKc += a[1] + T * (a[2] + T * (2.0 * a[3] + T * (3.0 * a[4] + 4.0 * a[5] * T))) + a[6] * invT;
             });
@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         J[(NSP * (j + 1)) * A.j_si] = -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp;
     });
 #undef PJL_INL
+  }
 }
 
 }  // namespace
@@ -323,8 +324,17 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
 {
     if (n <= 0) return 0;
     Args A{n, pres, y, y_si, y_ss, jac, j_si, j_ss, sum_last};
-    const unsigned grid = (unsigned)((n + PJL_BLOCK - 1) / PJL_BLOCK);
-    hipLaunchKernelGGL(k_lane, dim3(grid), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+    long blocks = (n + PJL_BLOCK - 1) / PJL_BLOCK;
+    static long resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 256, per_cu = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane, PJL_BLOCK, 0);
+        resident = (long)cus * (per_cu > 0 ? per_cu : 1);
+    }
+    if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
+    hipLaunchKernelGGL(k_lane, dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

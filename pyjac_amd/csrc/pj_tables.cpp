@@ -359,6 +359,21 @@ std::string emit_spec_header(const Programs& p)
     arr_i("NET_SP", p.net_sp, 1);
     arr_d("NET_NU", p.net_nu, 1);
     arr_i("SIDX", sidx, nsp);
+    // NASA range tables for LDS: one 16-double row per K_c group, then per species:
+    // [lo0..lo6, 0, hi0..hi6, 0]; the kernel reads 7 doubles at row*16 + (T <= Tmid ? 0 : 8)
+    const size_t nkc = p.kcg.size() / KCW;
+    o += "constexpr int LT_KC = 0, LT_SP = " + std::to_string(nkc * 16) + ", LT_SIZE = " +
+         std::to_string((nkc + nsp) * 16) + ";\n";
+    o += "#ifdef __HIPCC__\n__device__ const double LTAB[LT_SIZE] = {\n";
+    auto row = [&](const double* lo, const double* hi) {
+        for (int c = 0; c < 7; ++c) { d(lo[c]); o += ","; }
+        o += "0,";
+        for (int c = 0; c < 7; ++c) { d(hi[c]); o += ","; }
+        o += "0,\n";
+    };
+    for (size_t g = 0; g < nkc; ++g) row(&p.kcg[g * KCW + 1], &p.kcg[g * KCW + 8]);
+    for (int k = 0; k < nsp; ++k) row(&p.sp[(size_t)k * SPW + 4], &p.sp[(size_t)k * SPW + 11]);
+    o += "};\n#endif\n";
     o += "}  // namespace pjs\n";
     return o;
 }
