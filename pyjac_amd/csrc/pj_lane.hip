@@ -4,8 +4,11 @@
 // tables (pj::emit_spec_header -> PJS_HEADER), every loop over species,
 // reactions, molecule slots and Jacobian entries is fully unrolled, so all
 // per-state arrays (C_k, omega_k, P_k, Q_k, the sparse S entries ...) have
-// compile-time indices and live in VGPRs: no LDS, no table loads, no
-// divergence except the NASA / PLOG range selects.  State loads and Jacobian
+// compile-time indices and live in VGPRs; stoichiometry, species indices and
+// reaction kinds are folded into the instruction stream.  The real-valued
+// coefficients (NASA rows, Arrhenius / falloff parameters, efficiencies) are
+// staged in LDS once per workgroup and read with uniform ds_reads.  No
+// divergence except the PLOG interval selects.  State loads and Jacobian
 // stores are lane-contiguous (SoA) = fully coalesced.
 //
 // Same formulation as pj_kernel.h (which stays the path for mechanisms whose
@@ -61,10 +64,22 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 {
     // NASA lo/hi coefficient rows live in LDS: one ds_read per coefficient pair at an
     // address picked by the range test, instead of a v_cndmask per 32-bit half
+    // plus the real-valued coefficient tables (Arrhenius / falloff / Troe parameters,
+    // efficiencies, molecular weights): uniform LDS reads where they are used, instead
+    // of ~1000 64-bit literals that the persistent loop would hoist and spill
     __shared__ __attribute__((aligned(16))) double LT[pjs::LT_SIZE];
+    __shared__ __attribute__((aligned(16))) double RDL[NRXN][RDW];
+    __shared__ __attribute__((aligned(16))) double EFL[sizeof(pjs::EFFT) / 8][1];
+    __shared__ __attribute__((aligned(16))) double SPL[NSP][4];
     for (int w = threadIdx.x; w < pjs::LT_SIZE; w += PJL_BLOCK) LT[w] = pjs::LTAB[w];
+    for (int w = threadIdx.x; w < NRXN * RDW; w += PJL_BLOCK) (&RDL[0][0])[w] = (&pjs::RDT[0][0])[w];
+    for (int w = threadIdx.x; w < (int)(sizeof(pjs::EFFT) / 8); w += PJL_BLOCK) EFL[w][0] = pjs::EFFT[w][0];
+    for (int w = threadIdx.x; w < NSP * 4; w += PJL_BLOCK) (&SPL[0][0])[w] = (&pjs::SPT[0][0])[w];
     __syncthreads();
   for (long s = (long)blockIdx.x * PJL_BLOCK + threadIdx.x; s < A.n; s += (long)gridDim.x * PJL_BLOCK) {
+    const double (*RDT)[RDW] = RDL;
+    const double (*EFFT)[1] = EFL;
+    const double (*SPT)[4] = SPL;
     const double* y = A.y + s * A.y_ss;
     const double T = y[0];
     const double p = A.pres[s];
@@ -77,26 +92,26 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     for (int k = 0; k < LAST; ++k) {
         C[k] = y[(k + 1) * A.y_si];
         sumY += C[k];
-        sumYW += C[k] * pjs::SP[k][0];
+        sumYW += C[k] * SPT[k][0];
     }
     const double yN = 1.0 - sumY;
     C[LAST] = yN;
-    sumYW += yN * pjs::SP[LAST][0];
+    sumYW += yN * SPT[LAST][0];
     const double Wbar = 1.0 / sumYW;
     const double rho = p * Wbar / (RU_ * T), invrho = 1.0 / rho;
     const double mconc = p / (RU_ * T);
     double cpavg = 0.0, dcpavg = 0.0;
 #pragma unroll
     for (int k = 0; k < NSP; ++k) {
-        const double* a = LT + pjs::LT_SP + k * 16 + ((T <= pjs::SP[k][2]) ? 0 : 8);
+        const double* a = LT + pjs::LT_SP + k * 16 + ((T <= SPT[k][2]) ? 0 : 8);
         hW[k] = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
                        T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
-        const double RW = RU_ * pjs::SP[k][0];
+        const double RW = RU_ * SPT[k][0];
         cpk[k] = RW * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
         const double dcp = RW * (a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T)));
         cpavg += C[k] * cpk[k];
         dcpavg += C[k] * dcp;
-        C[k] = rho * C[k] * pjs::SP[k][0];
+        C[k] = rho * C[k] * SPT[k][0];
     }
     C[ONE] = 1.0;
 
@@ -140,14 +155,14 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
                 dlnk = hi ? Bn + En * invT : dlnk;
             }
         } else {
-            lnk = pjs::RD[i][RD_LNA] + pjs::RD[i][RD_B] * logT - pjs::RD[i][RD_TA] * invT;
-            dlnk = pjs::RD[i][RD_B] + pjs::RD[i][RD_TA] * invT;
+            lnk = RDT[i][RD_LNA] + RDT[i][RD_B] * logT - RDT[i][RD_TA] * invT;
+            dlnk = RDT[i][RD_B] + RDT[i][RD_TA] * invT;
         }
-        const double kf = pjs::RD[i][RD_SGN] * exp(lnk);
+        const double kf = (pjs::RD[i][RD_SGN] < 0.0) ? -exp(lnk) : exp(lnk);
 
         double kr = 0.0, TdlnKc = 0.0;
         if constexpr ((fl & F_REV) != 0) {
-            double lnKc = pjs::RD[i][RD_LNPREF];
+            double lnKc = RDT[i][RD_LNPREF];
             static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJL_INL {
                 constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
                 const double* a = LT + pjs::LT_KC + g * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
@@ -168,7 +183,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             double Mc = mconc;
             static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJL_INL {
                 constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
-                Mc += pjs::EFF_AM1[e][0] * C[pjs::EFF_SP[e][0]];
+                Mc += EFFT[e][0] * C[pjs::EFF_SP[e][0]];
             });
             if constexpr ((fl & F_THD) != 0) {
                 c = Mc;
@@ -178,14 +193,14 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
                 constexpr int col = pjs::RI[i][RI_COLLIDER];
                 double conc_temp = Mc;
                 if constexpr (col >= 0) conc_temp = C[col >= 0 ? col : 0];
-                const double e0T = pjs::RD[i][RD_E0] * invT;
-                const double k0kinf = exp(pjs::RD[i][RD_LNAR] + pjs::RD[i][RD_B0] * logT - e0T);
+                const double e0T = RDT[i][RD_E0] * invT;
+                const double k0kinf = exp(RDT[i][RD_LNAR] + RDT[i][RD_B0] * logT - e0T);
                 const double Pr = conc_temp * k0kinf;
                 const double i1Pr = 1.0 / (1.0 + Pr);
                 double F = 1.0, extra = 0.0, Xtroe = 0.0;
                 if constexpr ((fl & F_TROE) != 0) {
-                    constexpr double ta = pjs::RD[i][RD_TRA], T3 = pjs::RD[i][RD_T3], T1 = pjs::RD[i][RD_T1],
-                                     T2 = pjs::RD[i][RD_T2];
+                    const double ta = RDT[i][RD_TRA], T3 = RDT[i][RD_T3], T1 = RDT[i][RD_T1],
+                                 T2 = RDT[i][RD_T2];
                     const double e3 = exp(-T / T3), e1 = exp(-T / T1);
                     double Fcent = (1.0 - ta) * e3 + ta * e1;
                     double dF = -((1.0 - ta) / T3) * e3 - (ta / T1) * e1;
@@ -206,9 +221,9 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
                     const double iFc = 1.0 / Fcent;
                     Xtroe = lnF_AB * (INV_LN10 * Bt + (0.14 * INV_LN10) * At);
                     extra = (iFc * iden - lnF_AB * (-(0.67 * INV_LN10) * Bt + (1.1762 * INV_LN10) * At) * iFc) * dF -
-                            Xtroe * (pjs::RD[i][RD_B0] + e0T - 1.0) * invT;
+                            Xtroe * (RDT[i][RD_B0] + e0T - 1.0) * invT;
                 }
-                double dpr = (pjs::RD[i][RD_B04] + e0T - 1.0) * invT * i1Pr;
+                double dpr = (RDT[i][RD_B04] + e0T - 1.0) * invT * i1Pr;
                 double X;
                 if constexpr ((fl & F_LOW) != 0) { c = F * Pr * i1Pr; X = i1Pr - Xtroe; }
                 else { c = F * i1Pr; X = -Pr * i1Pr - Xtroe; dpr = -Pr * dpr; }
@@ -230,7 +245,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         const double ckf = c * kf, ckr = c * kr;
 
         // sparse values per molecule slot, accumulated straight into S (compile-time indices)
-        double gN = bM * pjs::RD[i][RD_ANM1];
+        double gN = bM * RDT[i][RD_ANM1];
         constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
         auto slot = [&](auto spc, const double gv) PJL_INL {
             constexpr int sp = decltype(spc)::value;
@@ -259,7 +274,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
                 constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
                 constexpr int es = pjs::EFF_SP[e][0];
                 // the last species' enhanced efficiency is already in gN (RD_ANM1)
-                if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, pjs::EFF_AM1[e][0] * bM);
+                if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, EFFT[e][0] * bM);
             });
         }
 
@@ -285,17 +300,17 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 #pragma unroll
     for (int k = 0; k < NSP; ++k) {
         H += hW[k] * om[k];
-        scp += om[k] * pjs::SP[k][1] * cpk[k];
+        scp += om[k] * SPT[k][1] * cpk[k];
         sjt += hW[k] * jt[k];
     }
     double* J = A.jac + s * A.j_ss;
     const double icp = 1.0 / cpavg;
     J[0] = -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg);
 #pragma unroll
-    for (int k = 0; k < LAST; ++k) J[(k + 1) * A.j_si] = pjs::SP[k][1] * jt[k];
+    for (int k = 0; k < LAST; ++k) J[(k + 1) * A.j_si] = SPT[k][1] * jt[k];
     static_for<LAST>([&](auto jc) PJL_INL {
         constexpr int j = decltype(jc)::value;
-        constexpr double wj = pjs::SP[j][3], iWj = pjs::SP[j][0];
+        const double wj = SPT[j][3], iWj = SPT[j][0];
         double tot = 0.0;
         static_for<NSP>([&](auto kc) PJL_INL {
             constexpr int k = decltype(kc)::value;
@@ -303,7 +318,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             double m = P[k] - wj * Q[k];
             if constexpr (si >= 0) m += S[si];
             tot += hW[k] * m;
-            if constexpr (k < LAST) J[(k + 1 + NSP * (j + 1)) * A.j_si] = (pjs::SP[k][1] * iWj) * m;
+            if constexpr (k < LAST) J[(k + 1 + NSP * (j + 1)) * A.j_si] = (SPT[k][1] * iWj) * m;
         });
         J[(NSP * (j + 1)) * A.j_si] = -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp;
     });

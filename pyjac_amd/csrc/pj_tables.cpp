@@ -364,6 +364,30 @@ std::string emit_spec_header(const Programs& p)
     const size_t nkc = p.kcg.size() / KCW;
     o += "constexpr int LT_KC = 0, LT_SP = " + std::to_string(nkc * 16) + ", LT_SIZE = " +
          std::to_string((nkc + nsp) * 16) + ";\n";
+    // coefficient tables read through the scalar cache (s_load) instead of being
+    // materialised as 64-bit literals: reaction doubles, efficiencies, species constants
+    auto dev_arr = [&](const char* name, const std::vector<double>& v, int width) {
+        const size_t rows = v.size() / width;
+        o += "__constant__ const double "; o += name;
+        o += "[" + std::to_string(rows ? rows : 1) + "][" + std::to_string(width) + "] = {";
+        if (!rows) o += "{}";
+        for (size_t r = 0; r < rows; ++r) {
+            o += "{";
+            for (int c = 0; c < width; ++c) { d(v[r * width + c]); o += ","; }
+            o += "},\n";
+        }
+        o += "};\n";
+    };
+    o += "#ifdef __HIPCC__\n";
+    dev_arr("RDT", p.rd, RDW);
+    dev_arr("EFFT", p.eff_am1, 1);
+    dev_arr("PLOGT", p.plog, PLW);
+    {
+        std::vector<double> spc;
+        for (int k = 0; k < nsp; ++k) for (int c = 0; c < 4; ++c) spc.push_back(p.sp[(size_t)k * SPW + c]);
+        dev_arr("SPT", spc, 4);
+    }
+    o += "#endif\n";
     o += "#ifdef __HIPCC__\n__device__ const double LTAB[LT_SIZE] = {\n";
     auto row = [&](const double* lo, const double* hi) {
         for (int c = 0; c < 7; ++c) { d(lo[c]); o += ","; }
