@@ -84,6 +84,36 @@ def cpu_baseline(w, tables, target_seconds=12.0):
                        'parallel-for over states (%d threads), %.1f s' % (passes, n, cores, dt))
 
 
+def also_workloads(primary, pyjac_amd, torch, np):
+    """Short kernel-only measurements of the other BASELINE.json configurations on
+    this GPU (reported next to the headline, never part of `value`)."""
+    out = {}
+    for key, n in (('h2', 1_000_000), ('gri', 200_000), ('usc', 50_000)):
+        if key == primary or not os.path.exists(WORKLOADS[key]['mech']):
+            continue
+        try:
+            w = WORKLOADS[key]
+            ev = pyjac_amd.Evaluator(w['mech'], specialize='build')
+            pres, y = make_states(w, ev.nsp, n, seed=20240901)
+            soa = ev.has_spec or ev.get_launch()['tile_states'] >= 16
+            L = pyjac_amd.LAYOUT_SOA if soa else pyjac_amd.LAYOUT_AOS
+            d_p = torch.from_numpy(pres).cuda()
+            d_y = torch.from_numpy(y if soa else np.ascontiguousarray(y.T)).cuda()
+            jac = torch.empty(ev.nsp * ev.nsp * n, dtype=torch.float64, device='cuda')
+            ev.time_jacobian(d_p, d_y, jac, 2, L, L)
+            ms = ev.time_jacobian(d_p, d_y, jac, 5, L, L)
+            gbs = n * ev.jacobian_bytes_per_state / ms / 1e6
+            out[key] = dict(workload=w['label'].replace('1e6', '%g' % n).replace('2e5', '%g' % n),
+                            states=n, kernel_ms=ms, jacobians_per_s=n / ms * 1e3,
+                            achieved_GBps=gbs, frac=gbs / HBM_PEAK_GBPS,
+                            kernel='pj_lane' if ev.has_spec else 'k_eval', launch=ev.get_launch())
+            del jac, d_y, d_p, ev
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            out[key] = {'error': repr(ex)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -93,6 +123,8 @@ def main():
     ap.add_argument('--states', type=int, default=0, help='states per GPU (default: workload size)')
     ap.add_argument('--layout', default='auto', choices=['auto', 'soa', 'aos'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true',
+                    help='skip the short extra measurements of the other workloads (N=1 only)')
     ap.add_argument('--validate-states', type=int, default=4096,
                     help='states per rank in the multi-GPU validation all-gather (outside the timed region)')
     a = ap.parse_args()
@@ -115,15 +147,16 @@ def main():
 
     wl = a.workload
     if wl == 'auto':
-        wl = 'gri' if os.path.exists(WORKLOADS['gri']['mech']) else 'h2'
+        # BASELINE.json configs[1]: the configuration its Target sentence is quoted on
+        wl = 'h2'
     w = WORKLOADS[wl]
-    ev = pyjac_amd.Evaluator(w['mech'])
+    ev = pyjac_amd.Evaluator(w['mech'], specialize='build')
     n = a.states or w['n']
     # every rank owns n states (weak scaling); global batch = world * n
     pres, y = make_states(w, ev.nsp, n, seed=20240901 + rank)
     lay = a.layout
     if lay == 'auto':
-        lay = 'soa' if ev.get_launch()['tile_states'] >= 16 else 'aos'
+        lay = 'soa' if (ev.has_spec or ev.get_launch()['tile_states'] >= 16) else 'aos'
     L = pyjac_amd.LAYOUT_SOA if lay == 'soa' else pyjac_amd.LAYOUT_AOS
     d_p = torch.from_numpy(pres).cuda()
     d_y = torch.from_numpy(y if L == pyjac_amd.LAYOUT_SOA else np.ascontiguousarray(y.T)).cuda()
@@ -195,6 +228,10 @@ def main():
         }
         if validation:
             line['validation_allgather'] = validation
+        line['config']['kernel'] = ('pj_lane (register-resident specialisation)' if ev.has_spec
+                                    else 'k_eval (table-driven)')
+        if world == 1 and not a.no_also:
+            line['also'] = also_workloads(wl, pyjac_amd, torch, np)
         if world == 1 and not a.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(w, ev.tables)

@@ -44,11 +44,31 @@ __device__ __forceinline__ void static_for_impl(F&& f)
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
 
+// does reaction i feed the last species' column (g_N != 0)?
+constexpr bool has_gn(int i)
+{
+    const int fl = pjs::RI[i][RI_FLAGS];
+    bool g = pjs::RD[i][RD_ANM1] != 0.0;
+    for (int t = 0; t < 3; ++t) {
+        g = g || pjs::RI[i][RI_R0 + t] == LAST;
+        if (fl & F_REV) g = g || pjs::RI[i][RI_P0 + t] == LAST;
+    }
+    if (fl & F_COLLIDER) g = g || pjs::RI[i][RI_COLLIDER] == LAST;
+    return g;
+}
+constexpr bool any_gn()
+{
+    for (int i = 0; i < NRXN; ++i) if (has_gn(i)) return true;
+    return false;
+}
+constexpr bool ANY_GN = any_gn();      // false: Q_k == P_k, one accumulator set less
+
 struct Args {
     long n;
     const double* pres;
     const double* y; long y_si, y_ss;
-    double* jac; long j_si, j_ss;
+    double* jac; long j_si, j_ss;      // jac already points at state s0's block
+    long s0;                           // first state of this launch chunk
     int sum_last;
 };
 
@@ -76,7 +96,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     for (int w = threadIdx.x; w < (int)(sizeof(pjs::EFFT) / 8); w += PJL_BLOCK) EFL[w][0] = pjs::EFFT[w][0];
     for (int w = threadIdx.x; w < NSP * 4; w += PJL_BLOCK) (&SPL[0][0])[w] = (&pjs::SPT[0][0])[w];
     __syncthreads();
-  for (long s = (long)blockIdx.x * PJL_BLOCK + threadIdx.x; s < A.n; s += (long)gridDim.x * PJL_BLOCK) {
+  for (long s = A.s0 + (long)blockIdx.x * PJL_BLOCK + threadIdx.x; s < A.n; s += (long)gridDim.x * PJL_BLOCK) {
     const double (*RDT)[RDW] = RDL;
     const double (*EFFT)[1] = EFL;
     const double (*SPT)[4] = SPL;
@@ -115,10 +135,11 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     }
     C[ONE] = 1.0;
 
-    double om[NSP], jt[NSP], P[NSP], Q[NSP], S[pjs::NNZ];
+    double om[NSP], jt[NSP], P[NSP], Q[ANY_GN ? NSP : 1], S[pjs::NNZ];
+    double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
     double jtq = 0.0;
 #pragma unroll
-    for (int k = 0; k < NSP; ++k) { om[k] = 0.0; jt[k] = 0.0; P[k] = 0.0; Q[k] = 0.0; }
+    for (int k = 0; k < NSP; ++k) { om[k] = 0.0; jt[k] = 0.0; P[k] = 0.0; if (ANY_GN) Q[k] = 0.0; }
 #pragma unroll
     for (int e = 0; e < pjs::NNZ; ++e) S[e] = 0.0;
 
@@ -162,14 +183,20 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 
         double kr = 0.0, TdlnKc = 0.0;
         if constexpr ((fl & F_REV) != 0) {
-            double lnKc = RDT[i][RD_LNPREF];
-            static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJL_INL {
-                constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
-                const double* a = LT + pjs::LT_KC + g * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
-                lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
-                TdlnKc += a[1] + T * (a[2] + T * (2.0 * a[3] + T * (3.0 * a[4] + 4.0 * a[5] * T))) + a[6] * invT;
-            });
-            kr = kf * exp(-lnKc);
+            constexpr int kcls = pjs::KC_CLASS[i][0];
+            if constexpr (pjs::KC_FIRST[i][0] != 0) {
+                double lnKc = RDT[i][RD_LNPREF], td = 0.0;
+                static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJL_INL {
+                    constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
+                    const double* a = LT + pjs::LT_KC + g * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                    lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
+                    td += a[1] + T * (a[2] + T * (2.0 * a[3] + T * (3.0 * a[4] + 4.0 * a[5] * T))) + a[6] * invT;
+                });
+                ekc[kcls] = exp(-lnKc);
+                tdk[kcls] = td;
+            }
+            kr = kf * ekc[kcls];
+            TdlnKc = tdk[kcls];
         }
 
         const double cr0 = C[pjs::RI[i][RI_R0]], cr1 = C[pjs::RI[i][RI_R1]], cr2 = C[pjs::RI[i][RI_R2]];
@@ -245,7 +272,8 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         const double ckf = c * kf, ckr = c * kr;
 
         // sparse values per molecule slot, accumulated straight into S (compile-time indices)
-        double gN = bM * RDT[i][RD_ANM1];
+        double gN = 0.0;
+        if constexpr (pjs::RD[i][RD_ANM1] != 0.0) gN = bM * RDT[i][RD_ANM1];
         constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
         auto slot = [&](auto spc, const double gv) PJL_INL {
             constexpr int sp = decltype(spc)::value;
@@ -288,7 +316,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             om[k] += nu * q_;
             jt[k] += nu * theta;
             P[k] += nu * rp;
-            Q[k] += nu * rq;
+            if constexpr (ANY_GN) Q[k] += nu * rq;
             if constexpr (k == LAST && i == pjs::LASTQ) jtq = nu * theta;
         });
     });
@@ -303,11 +331,12 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         scp += om[k] * SPT[k][1] * cpk[k];
         sjt += hW[k] * jt[k];
     }
-    double* J = A.jac + s * A.j_ss;
+    double* const Jl = A.jac + (s - A.s0) * A.j_ss;
+#define J_(e) Jl[(long)(e) * A.j_si]
     const double icp = 1.0 / cpavg;
-    J[0] = -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg);
+    J_(0) = -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg);
 #pragma unroll
-    for (int k = 0; k < LAST; ++k) J[(k + 1) * A.j_si] = SPT[k][1] * jt[k];
+    for (int k = 0; k < LAST; ++k) J_(k + 1) = SPT[k][1] * jt[k];
     static_for<LAST>([&](auto jc) PJL_INL {
         constexpr int j = decltype(jc)::value;
         const double wj = SPT[j][3], iWj = SPT[j][0];
@@ -315,12 +344,12 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         static_for<NSP>([&](auto kc) PJL_INL {
             constexpr int k = decltype(kc)::value;
             constexpr int si = pjs::SIDX[k][j];
-            double m = P[k] - wj * Q[k];
+            double m = ANY_GN ? P[k] - wj * Q[k] : P[k] - wj * P[k];
             if constexpr (si >= 0) m += S[si];
             tot += hW[k] * m;
-            if constexpr (k < LAST) J[(k + 1 + NSP * (j + 1)) * A.j_si] = (SPT[k][1] * iWj) * m;
+            if constexpr (k < LAST) J_(k + 1 + NSP * (j + 1)) = (SPT[k][1] * iWj) * m;
         });
-        J[(NSP * (j + 1)) * A.j_si] = -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp;
+        J_(NSP * (j + 1)) = -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp;
     });
 #undef PJL_INL
   }
@@ -338,8 +367,6 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
                      long j_si, long j_ss, int sum_last, void* stream)
 {
     if (n <= 0) return 0;
-    Args A{n, pres, y, y_si, y_ss, jac, j_si, j_ss, sum_last};
-    long blocks = (n + PJL_BLOCK - 1) / PJL_BLOCK;
     static long resident = 0;
     if (!resident) {
         int dev = 0, cus = 256, per_cu = 1;
@@ -348,8 +375,17 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
-    if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-    hipLaunchKernelGGL(k_lane, dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+    // launch in chunks whose per-lane byte offset into the Jacobian fits 32 bits
+    const long stride = j_ss > 0 ? j_ss : 1;
+    long chunk = (long)(0xffffffffUL / (8UL * (unsigned long)stride)) - 64;
+    if (chunk > n) chunk = n;
+    for (long s0 = 0; s0 < n; s0 += chunk) {
+        const long s1 = s0 + chunk < n ? s0 + chunk : n;
+        Args A{s1, pres, y, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, s0, sum_last};
+        long blocks = (s1 - s0 + PJL_BLOCK - 1) / PJL_BLOCK;
+        if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
+        hipLaunchKernelGGL(k_lane, dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

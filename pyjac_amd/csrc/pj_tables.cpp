@@ -359,6 +359,27 @@ std::string emit_spec_header(const Programs& p)
     arr_i("NET_SP", p.net_sp, 1);
     arr_d("NET_NU", p.net_nu, 1);
     arr_i("SIDX", sidx, nsp);
+    {
+        // reactions with identical equilibrium constants (same net stoichiometry: third-body
+        // variants, duplicates) share one class: exp(-ln Kc) is evaluated once per class
+        std::vector<int32_t> cls(p.nrxn, -1), first(p.nrxn, 0);
+        int ncls = 0;
+        for (int i = 0; i < p.nrxn; ++i) {
+            const int32_t* ri = &p.ri[(size_t)i * RIW];
+            if (!(ri[RI_FLAGS] & F_REV)) continue;
+            for (int h = 0; h < i && cls[i] < 0; ++h) {
+                const int32_t* rh = &p.ri[(size_t)h * RIW];
+                if (!(rh[RI_FLAGS] & F_REV) || rh[RI_KC_CNT] != ri[RI_KC_CNT]) continue;
+                if (p.rd[(size_t)h * RDW + RD_LNPREF] != p.rd[(size_t)i * RDW + RD_LNPREF]) continue;
+                if (memcmp(&p.kcg[(size_t)rh[RI_KC_PTR] * KCW], &p.kcg[(size_t)ri[RI_KC_PTR] * KCW],
+                           sizeof(double) * KCW * ri[RI_KC_CNT]) == 0) cls[i] = cls[h];
+            }
+            if (cls[i] < 0) { cls[i] = ncls++; first[i] = 1; }
+        }
+        o += "constexpr int NKCCLS = " + std::to_string(ncls ? ncls : 1) + ";\n";
+        arr_i("KC_CLASS", cls, 1);
+        arr_i("KC_FIRST", first, 1);
+    }
     // NASA range tables for LDS: one 16-double row per K_c group, then per species:
     // [lo0..lo6, 0, hi0..hi6, 0]; the kernel reads 7 doubles at row*16 + (T <= Tmid ? 0 : 8)
     const size_t nkc = p.kcg.size() / KCW;
