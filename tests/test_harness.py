@@ -1,0 +1,103 @@
+"""Functional / performance harness: CPU parts here, GPU parts marked gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MECHS, ROOT
+from pyjac_amd import functional_tester as ft
+from pyjac_amd import performance_tester as pt
+from pyjac_amd import synth
+
+
+def test_data_bin_roundtrip_and_mask(tmp_path):
+    a = np.load(os.path.join(ROOT, 'pyjac_amd', 'data', 'h2_pasr_output.npy'))
+    f = tmp_path / 'data.bin'
+    n = pt.write_data_bin(str(f), [a, a[:10]])
+    assert n == 1020 + 100 and os.path.getsize(f) == n * 13 * 8
+    pres, y = pt.read_initial_conditions(str(f), 1100, 10)
+    flat = a.reshape(-1, 13)
+    assert np.array_equal(pres[:1020], flat[:, 2]) and np.array_equal(y[0, :1020], flat[:, 1])
+    assert np.array_equal(y[1:, 7], flat[7, 3:12])
+    # apply_mask: species 1 of the file is the mechanism's last species
+    fmap = [0, 2, 3, 4, 5, 6, 7, 8, 9, 1]
+    _, y2 = pt.read_initial_conditions(str(f), 5, 10, fmap)
+    assert np.array_equal(y2[1:, 3], flat[3, 3:][fmap][:-1])
+    with pytest.raises(ValueError):
+        pt.read_initial_conditions(str(f), n + 1, 10)
+
+
+def test_error_metrics_match_reference_definitions():
+    rng = np.random.default_rng(0)
+    ref = rng.normal(size=100) * 10.0 ** rng.integers(-8, 8, 100)
+    ref[::7] = 0.0
+    test = ref * (1 + 1e-9 * rng.normal(size=100))
+    m = ft.jacobian_error_metrics(test, ref)
+    nz = np.abs(test) > 1e-30
+    assert m['max_rel'] == pytest.approx(np.max(np.abs((test[nz] - ref[nz]) / ref[nz])))
+    assert m['norm_err'] == pytest.approx(np.linalg.norm(test - ref) / np.linalg.norm(ref))
+    assert m['zero_diff'] == 0.0 and m['thr_max_rel'] <= m['max_rel']
+    Y = ft.normalise_states(np.array([[0.2, 0.3, 0.6]]))
+    assert abs(Y.sum() - 1) < 1e-15
+
+
+class _OracleModule:
+    """The CPU oracle behind the pyjacob function names (test double for the
+    reference's compiled module)."""
+
+    def __init__(self, tab):
+        import ctypes
+        from oracle.oracle import Oracle
+        self.o = Oracle(tab)
+        self.c = ctypes
+        self.P = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+    def py_eval_conc(self, T, P, mf, mw, rho, conc):
+        c = self.c
+        yN, a, b = c.c_double(), c.c_double(), c.c_double()
+        self.o.lib.pjo_eval_conc(self.o.h, T, P, self.P(mf[:-1].copy()), c.byref(yN), c.byref(a), c.byref(b),
+                                 self.P(conc))
+        mf[-1] = yN.value
+
+    def py_eval_rxn_rates(self, T, P, C, fwd, rev):
+        self.o.lib.pjo_eval_rxn_rates(self.o.h, T, P, self.P(C), self.P(fwd), self.P(rev))
+
+    def py_get_rxn_pres_mod(self, T, P, C, pm):
+        self.o.lib.pjo_get_rxn_pres_mod(self.o.h, T, P, self.P(C), self.P(pm))
+
+    def py_eval_spec_rates(self, fwd, rev, pm, sr):
+        last = self.c.cast(sr.ctypes.data + 8 * (sr.size - 1), self.c.POINTER(self.c.c_double))
+        self.o.lib.pjo_eval_spec_rates(self.o.h, self.P(fwd), self.P(rev), self.P(pm), self.P(sr), last)
+
+    def py_dydt(self, t, P, y, dy):
+        self.o.lib.pjo_dydt(self.o.h, t, P, self.P(y), self.P(dy))
+
+    def py_eval_jacobian(self, t, P, y, jac):
+        self.o.lib.pjo_eval_jacob(self.o.h, t, P, self.P(y), self.P(jac))
+
+
+@pytest.mark.gpu
+def test_functional_tester_on_pasr_states(tables):
+    """BASELINE.json config 1 through the tester's own call sequence and its
+    headline statistic (maximum of thresholded L2-norm relative error)."""
+    from pyjac_amd import pyjacob
+    ev = pyjacob.use_mechanism(MECHS['h2o2_n2'])
+    P, Y, T = synth.pasr_states(10)
+    sel = slice(0, None, 20)
+    stats = ft.run(pyjacob, _OracleModule(tables('h2o2_n2')), (ev.nsp, ev.n_fwd, ev.n_rev, ev.n_pres_mod),
+                   T[sel], P[sel], Y[sel], ev.mechanism.fwd_spec_map)
+    assert stats['max_thr_l2_rel'] < 1e-6 and stats['norm_err'].max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_speedtest_protocol(tmp_path, capsys):
+    import pyjac_amd
+    a = np.load(os.path.join(ROOT, 'pyjac_amd', 'data', 'h2_pasr_output.npy'))
+    f = tmp_path / 'data.bin'
+    n = pt.write_data_bin(str(f), [a] * 10)
+    ev = pyjac_amd.Evaluator(MECHS['h2o2_n2'])
+    pres, y = pt.read_initial_conditions(str(f), n, ev.nsp, ev.mechanism.fwd_spec_map)
+    r = pt.speedtest(ev, pres, y, repeats=2)
+    line = capsys.readouterr().out.strip().splitlines()[0]
+    assert line.split(',')[0] == str(n) and float(line.split(',')[1]) > 0     # "N,ms" (tester.c.in:31)
+    assert r['kernel_ms'] > 0 and r['end_to_end_ms'] >= r['kernel_ms'] * 0.5
