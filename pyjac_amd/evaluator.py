@@ -68,7 +68,8 @@ class Evaluator:
             hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
             # -ffast-math: reciprocal instead of IEEE division sequences and reassociation of
             # the long accumulation chains (+11 % on MI355X); parity stays ~1e-11
-            flags = os.environ.get('PJ_LANE_FLAGS', '-ffast-math').split()
+            flags = os.environ.get('PJ_LANE_FLAGS',
+                                   '-ffast-math -mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
             subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
                                   ['-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
                                    '-o', so, os.path.join(here, 'csrc', 'pj_lane.hip')])
