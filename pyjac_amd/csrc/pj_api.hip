@@ -52,7 +52,7 @@ PJ_DEV void phase0c(const DevMech& M, const Batch& B, const double* cin, const d
     const double T = Tin[gs], p = B.pres[gs];
     L.T = T; L.p = p; L.logT = log(T); L.invT = 1.0 / T; L.logp = log(p);
     L.Wbar = 1.0; L.rho = 1.0; L.invrho = 1.0; L.m = p / (RU_ * T); L.yN = 0.0;
-    L.cpavg = 1.0; L.dcp = 0.0; L.H = 0.0; L.scp = 0.0;
+    L.cpavg = 1.0; L.dcp = 0.0;
     for (int k = u; k < M.nsp; k += NU) {
         V[(M.v.C + k) * TS + s] = cin[k * B.o_ld + gs];
         V[(M.v.HW + k) * TS + s] = 0.0;
@@ -70,13 +70,13 @@ k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, doubl
     extern __shared__ __attribute__((aligned(16))) double V[];
     const int tid = threadIdx.x, NT = blockDim.x;
     const long ntiles = (B.n + TS - 1) / TS;
-    stage_prog<TS>(M, V, tid, NT);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         Lane L;
         if (mode & MODE_CONC_IN) {
             phase0c<TS>(M, B, cin, Tin, V, tid, NT, tile, L);
         } else {
             phase0a<TS>(M, B, V, tid, NT, tile, L);
+            phase_zero_tile<TS>(M, V, tid, NT);
             __syncthreads();
             phase0b<TS>(M, B, V, tid, NT, L);
             __syncthreads();
@@ -92,17 +92,15 @@ k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, doubl
         if (!(mode & ABL_P2)) phase2<TS>(M, B, V, tid, NT, L);
         __syncthreads();
         if (!(mode & MODE_CONC_IN)) {
-            if (!(mode & ABL_P3)) phase3<TS>(M, B, V, tid, NT, L);
+            if (!(mode & ABL_P3)) phase_scatter<TS>(M, V, tid, NT, !(mode & MODE_JAC));
             __syncthreads();
-            phase3c<TS>(M, B, V, tid, NT, L);
+            phase_fin1<TS>(M, V, tid, NT);
+            __syncthreads();
+            phase_fin2<TS>(M, B, V, tid, NT, L);
+            __syncthreads();
             if ((mode & MODE_JAC) && !(mode & ABL_P4)) {
-                const int nr = phase4_rounds<TS>(M, NT);
-                for (int r = 0; r < nr; ++r) {
-                    phase4a<TS>(M, B, V, tid, NT, L, r);
-                    PJ_WAVE_SYNC();
-                    phase4b<TS>(M, B, V, tid, NT, L, r);
-                    PJ_WAVE_SYNC();
-                }
+                phase_out_energy<TS>(M, B, V, tid, NT, L);
+                phase_out_block<TS>(M, B, V, tid, NT, L);
             }
         }
         __syncthreads();
@@ -163,8 +161,11 @@ struct pj_mech {
     bool on_device = false;
     int device = -1;
     DevBuf<double> sp, rd, eff_am1, kcg, plog, net_nu, sp_nu;
-    DevBuf<int32_t> ri, eff_sp, net_sp, sp_ptr, sp_rxn;
-    DevBuf<uint32_t> prog;
+    DevBuf<int32_t> ri, eff_sp, net_sp, sp_ptr, sp_rxn, fin_tgt, fin_part;
+    DevBuf<uint32_t> sched;
+    Schedule S;                // host copy; rebuilt when the launch geometry changes
+    int sched_nw = 0, sched_il = 0;
+    bool sched_on_device = false;
     int ts = 0, nt = 0;       // 0 = auto
     int num_cu = 256;
     Workspace ws, ws1;
@@ -200,31 +201,62 @@ int ensure_device(pj_mech* m)
     HIPCHK(m->kcg.upload(P.kcg)); HIPCHK(m->plog.upload(P.plog));
     HIPCHK(m->net_sp.upload(P.net_sp)); HIPCHK(m->net_nu.upload(P.net_nu));
     HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
-    HIPCHK(m->prog.upload(P.prog));
     DevMech& M = m->M;
     M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
     M.kcg = m->kcg.p; M.plog = m->plog.p; M.net_sp = m->net_sp.p; M.net_nu = m->net_nu.p;
     M.sp_ptr = m->sp_ptr.p; M.sp_rxn = m->sp_rxn.p; M.sp_nu = m->sp_nu.p;
-    M.prog = m->prog.p; M.prog_words = (int)P.prog.size();
-    M.p4en = P.p4en; M.p4c = P.p4c; M.p3en = P.p3en; M.p3c = P.p3c;
     m->on_device = true;
     return PJ_OK;
 }
 
-void pick_launch(const pj_mech* m, int* ts, int* nt, size_t* lds)
+// host: make sure the scatter schedule matches the launch geometry (NT/64 waves x 64/TS lanes)
+int ensure_schedule(pj_mech* m, int ts, int nt)
 {
-    const size_t per_state = (size_t)m->P.vm.NV * 8;
-    const size_t prog_bytes = m->M.prog_in_lds ? m->P.prog.size() * 4 : 0;
+    const int NW = nt / 64, IL = 64 / ts;
+    if (m->sched_nw == NW && m->sched_il == IL) return PJ_OK;
+    if (!build_schedule(m->P, NW, IL, m->S)) return fail(PJ_EUNSUPPORTED, m->P.error);
+    m->sched_nw = NW; m->sched_il = IL;
+    m->sched_on_device = false;
+    DevMech& M = m->M;
+    M.v = m->P.vm;
+    M.nv = m->P.vm.NV;
+    for (int w = 0; w < 16; ++w) {
+        M.sched_off[w] = m->S.off[w]; M.sched_rounds[w] = m->S.rounds[w];
+        M.sched_rounds_dense[w] = m->S.rounds_dense[w];
+    }
+    M.nfin = (int)m->S.fin_tgt.size();
+    return PJ_OK;
+}
+
+int pick_launch(pj_mech* m, int* ts, int* nt, size_t* lds)
+{
+    int n = m->nt > 0 ? m->nt : 256;
     int t = m->ts;
     if (t <= 0) {
         // largest tile whose working set leaves room for two workgroups per CU
         size_t budget = 80 * 1024;
         if (const char* e = getenv("PJ_LDS_BUDGET")) budget = (size_t)atol(e);
+        // the tile size does not depend on the schedule except for a few partial slots
+        const size_t per_state = (size_t)(m->P.vm.TB + m->P.vm.T_PART + SC_COUNT + 64) * 8;
         t = 64;
-        while (t > 1 && per_state * t + 2048 + prog_bytes > budget) t >>= 1;
+        while (t > 1 && per_state * t > budget) t >>= 1;
     }
-    int n = m->nt > 0 ? m->nt : 256;
-    *ts = t; *nt = n; *lds = per_state * t + (size_t)n * 8 + prog_bytes;
+    int rc = ensure_schedule(m, t, n);
+    if (rc) return rc;
+    *ts = t; *nt = n; *lds = (size_t)m->P.vm.NSLOT * 8 * t;
+    return PJ_OK;
+}
+
+int upload_schedule(pj_mech* m)
+{
+    if (m->sched_on_device) return PJ_OK;
+    m->sched.release(); m->fin_tgt.release(); m->fin_part.release();
+    HIPCHK(m->sched.upload(m->S.codes));
+    HIPCHK(m->fin_tgt.upload(m->S.fin_tgt));
+    HIPCHK(m->fin_part.upload(m->S.fin_part));
+    m->M.sched = m->sched.p; m->M.fin_tgt = m->fin_tgt.p; m->M.fin_part = m->fin_part.p;
+    m->sched_on_device = true;
+    return PJ_OK;
 }
 
 template <int TS>
@@ -253,7 +285,10 @@ int launch(pj_mech* m, const Batch& B, int mode, const double* cin, const double
     if (rc) return rc;
     int ts, nt;
     size_t lds;
-    pick_launch(m, &ts, &nt, &lds);
+    rc = pick_launch(m, &ts, &nt, &lds);
+    if (rc) return rc;
+    rc = upload_schedule(m);
+    if (rc) return rc;
     if (lds > 160 * 1024)
         return fail(PJ_EUNSUPPORTED, "mechanism working set exceeds 160 KiB of LDS per state");
     switch (ts) {
@@ -314,9 +349,6 @@ int pj_mech_create(const int32_t* I, long nI, const double* D, long nD, pj_mech*
     memset(&M, 0, sizeof(M));
     M.nsp = m->P.nsp; M.nrxn = m->P.nrxn; M.ng = m->P.ng; M.ne = m->P.ne; M.nv = m->P.vm.NV;
     M.lastq_rxn = m->P.lastq_rxn; M.sum_last = 0; M.v = m->P.vm;
-    M.prog_words = (int)m->P.prog.size();
-    M.prog_in_lds = m->P.prog.size() * 4 <= 8192;
-    if (const char* e = getenv("PJ_PROG_LDS")) M.prog_in_lds = atoi(e);
     if (const char* e = getenv("PJ_TS")) m->ts = atoi(e);
     if (const char* e = getenv("PJ_NT")) m->nt = atoi(e);
     *out = m;
@@ -342,7 +374,8 @@ void pj_mech_destroy(pj_mech* m)
     if (!m) return;
     if (m->on_device) {
         m->sp.release(); m->rd.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release();
-        m->net_nu.release(); m->sp_nu.release(); m->prog.release(); m->ri.release(); m->eff_sp.release();
+        m->net_nu.release(); m->sp_nu.release(); m->sched.release(); m->ri.release(); m->eff_sp.release();
+        m->fin_tgt.release(); m->fin_part.release();
         m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release();
         m->ws.release(); m->ws1.release();
     }
@@ -402,7 +435,8 @@ int pj_mech_set_launch(pj_mech* m, int tile_states, int threads)
 int pj_mech_get_launch(const pj_mech* m, int* tile_states, int* threads, int* lds_bytes)
 {
     int ts, nt; size_t lds;
-    pick_launch(m, &ts, &nt, &lds);
+    int rc = pick_launch(const_cast<pj_mech*>(m), &ts, &nt, &lds);
+    if (rc) return rc;
     if (tile_states) *tile_states = ts;
     if (threads) *threads = nt;
     if (lds_bytes) *lds_bytes = (int)lds;

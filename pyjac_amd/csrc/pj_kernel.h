@@ -49,26 +49,13 @@ struct DevMech {
     const int32_t* sp_ptr;
     const int32_t* sp_rxn;
     const double* sp_nu;
-    const uint32_t* prog;      // gather programs (global copy)
-    int prog_words, p4en, p4c, p3en, p3c;
-    int prog_in_lds;           // small programs are staged into LDS once per workgroup
+    // scatter schedule (pj_tables.h: Schedule), built for (NT / 64) wavefronts x (64 / TS) item lanes
+    const uint32_t* sched;
+    int sched_off[16], sched_rounds[16], sched_rounds_dense[16];
+    const int32_t* fin_tgt;
+    const int32_t* fin_part;
+    int nfin;
 };
-
-// LDS layout of a workgroup (doubles): V[nv][TS] | RED[NT] | program (32-bit words)
-template <int TS>
-PJ_DEV const uint32_t* lds_prog(const DevMech& M, const double* V, int NT)
-{
-    return M.prog_in_lds ? reinterpret_cast<const uint32_t*>(V + (size_t)M.nv * TS + NT) : M.prog;
-}
-
-// copy the gather programs into LDS (once per workgroup)
-template <int TS>
-PJ_DEV void stage_prog(const DevMech& M, double* V, int tid, int NT)
-{
-    if (!M.prog_in_lds) return;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(V + (size_t)M.nv * TS + NT);
-    for (int w = tid; w < M.prog_words; w += NT) dst[w] = M.prog[w];
-}
 
 // One launch's arguments.  Element (i, s) of a 2-D quantity lives at
 // base[i * si + s * ss]; SoA (pyJac's batch layout, pyjacob.cu:139-187) is
@@ -84,17 +71,10 @@ struct Batch {
 
 struct Lane {
     double T, logT, invT, p, logp, rho, invrho, Wbar, m, yN;
-    double cpavg, dcp, H, scp;     // per-state sums (phase 0b / 3c)
+    double cpavg, dcp;             // per-state sums (phase 0b)
     long gs;
     int valid;
 };
-
-#ifndef PJ_WAVE_SYNC
-// LDS hand-off between the lanes of ONE wavefront: LDS operations of a wave
-// execute in program order, so only the compiler has to be kept from
-// reordering the write and the dependent read.
-#define PJ_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
-#endif
 
 // ---------------------------------------------------------------- phase 0
 // eval_conc (rate_subs.py:1625-1710) + eval_h / eval_cp (rate_subs.py:1806-2086).
@@ -346,145 +326,142 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
     }
 }
 
-// ---------------------------------------------------------------- phase 3
-// eval_spec_rates (rate_subs.py:1297-1542) and the per-species dense vectors
-//   P_k = sum_i nu_ki [(Wbar/rho)(q_i - a_i) + bM_i],  Q_k = P_k + sum_i nu_ki gN_i.
+// ---------------------------------------------------------------- scatter
+// eval_spec_rates (rate_subs.py:1297-1542) and every sum over reactions of the
+// Jacobian in one pass: tile[target] += nu * V[source] for the terms listed in
+// the schedule.  Targets: omega_k, sum_i nu_ki theta_i, P_k, Q_k and the sparse
+// block S_kj.  Each wavefront owns its targets and its IL lanes touch distinct
+// ones per round, so these are plain LDS read-modify-writes; the codes are read
+// with coalesced loads, four rounds at a time.
 template <int TS>
-PJ_DEV void phase3(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
+PJ_DEV void phase_zero_tile(const DevMech& M, double* V, int tid, int NT)
 {
     const int s = tid % TS, u = tid / TS, NU = NT / TS;
-    const int last = M.nsp - 1;
-    for (int k = u; k < M.nsp; k += NU) {
-        double om = 0.0, jt = 0.0, P = 0.0, Q = 0.0, jtq = 0.0;
-        const uint32_t* PG = lds_prog<TS>(M, V, NT);
-        const uint32_t en = PG[M.p3en + k];
-        const uint2* cb = reinterpret_cast<const uint2*>(PG + M.p3c) + (en >> 8);
-        for (int b = 0; b < (int)(en & 255u); ++b) {
-            const uint2 cw = cb[b];
-            const uint32_t c4[4] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16};
-            #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int i = (int)(c4[x] >> 3);
-                const int inu = (int)(c4[x] & 7u) - 4;
-                if (inu == 0) continue;          // padding
-                const double nu = (double)inu;
-                const double th = V[(M.v.RTH + i) * TS + s];
-                om += nu * V[(M.v.RQ + i) * TS + s];
-                jt += nu * th;
-                P += nu * V[(M.v.RP + i) * TS + s];
-                Q += nu * V[(M.v.RQQ + i) * TS + s];
-                if (i == M.lastq_rxn) jtq = nu * th;
+    for (int t = u; t < M.v.NTILE + SC_COUNT; t += NU) V[(M.v.TB + t) * TS + s] = 0.0;
+}
+
+template <int TS>
+PJ_DEV void phase_scatter(const DevMech& M, double* V, int tid, int NT, bool dense_only)
+{
+    constexpr int IL = 64 / TS;
+    const int lane = tid % 64, s = lane % TS, il = lane / TS, w = tid / 64;
+    const uint32_t* sc = M.sched + M.sched_off[w] + il;
+    const int nr = dense_only ? M.sched_rounds_dense[w] : M.sched_rounds[w];
+    double* T = V + M.v.TB * TS + s;
+    for (int r = 0; r < nr; r += 4) {
+        const uint32_t c0 = sc[(r + 0) * IL], c1 = sc[(r + 1) * IL], c2 = sc[(r + 2) * IL], c3 = sc[(r + 3) * IL];
+        const double v0 = V[(c0 & 8191u) * TS + s], v1 = V[(c1 & 8191u) * TS + s];
+        const double v2 = V[(c2 & 8191u) * TS + s], v3 = V[(c3 & 8191u) * TS + s];
+        const int n0 = (int)(c0 >> 29) - 4, n1 = (int)(c1 >> 29) - 4, n2 = (int)(c2 >> 29) - 4, n3 = (int)(c3 >> 29) - 4;
+        if (n0) T[((c0 >> 13) & 65535u) * TS] += (double)n0 * v0;
+        if (n1) T[((c1 >> 13) & 65535u) * TS] += (double)n1 * v1;
+        if (n2) T[((c2 >> 13) & 65535u) * TS] += (double)n2 * v2;
+        if (n3) T[((c3 >> 13) & 65535u) * TS] += (double)n3 * v3;
+    }
+}
+
+// add the partial accumulators of split hub targets to their final slot
+template <int TS>
+PJ_DEV void phase_fin1(const DevMech& M, double* V, int tid, int NT)
+{
+    const int s = tid % TS, u = tid / TS;
+    if (u == 0) {
+        for (int q = 0; q < M.nfin; ++q)
+            V[(M.v.TB + M.fin_tgt[q]) * TS + s] += V[(M.v.TB + M.fin_part[q]) * TS + s];
+    }
+}
+
+// per-state scalars H = sum h_k W_k omega_k, HP, HQ (same with P_k, Q_k), SCP = sum omega_k W_k cp_k,
+// SJT = sum h_k W_k (sum_i nu_ki theta_i); species rates / dydt outputs (rate_subs.py:2171-2335)
+template <int TS>
+PJ_DEV void phase_fin2(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
+{
+    const int s = tid % TS, u = tid / TS, NU = NT / TS;
+    const int nsp = M.nsp, last = nsp - 1;
+    const double* T = V + M.v.TB * TS + s;
+    for (int r = u; r < SC_COUNT; r += NU) {
+        double acc = 0.0;
+        for (int k = 0; k < nsp; ++k) {
+            const double hW = V[(M.v.HW + k) * TS + s];
+            double x;
+            if (r == SC_H) x = hW * T[(M.v.T_OM + k) * TS];
+            else if (r == SC_HP) x = hW * T[(M.v.T_P + k) * TS];
+            else if (r == SC_HQ) x = hW * T[(M.v.T_Q + k) * TS];
+            else if (r == SC_SCP) x = T[(M.v.T_OM + k) * TS] * M.sp[k * SPW + 1] * V[(M.v.CP + k) * TS + s];
+            else {
+                // reference quirk (create_jacobian.py:2786-2818): the last species contributes
+                // only the d/dT of its last reaction unless sum_last is set
+                const double jt = (k == last && !M.sum_last) ? T[M.v.T_JTQ * TS] : T[(M.v.T_JT + k) * TS];
+                x = hW * jt;
             }
+            acc += x;
         }
-        // Reference quirk kept for parity (create_jacobian.py:2786-2818): only the
-        // last reaction's d/dT of the LAST species reaches jac[0].
-        if (k == last && !M.sum_last) jt = jtq;
-        const double Wk = M.sp[k * SPW + 1];
-        V[(M.v.AP + k) * TS + s] = P;
-        V[(M.v.AQ + k) * TS + s] = Q;
-        V[(M.v.AJT + k) * TS + s] = jt;
-        V[(M.v.AOM + k) * TS + s] = om;
-        if (L.valid) {
+        V[(M.v.SC + r) * TS + s] = acc;
+        if (r == SC_H && B.dy && L.valid) B.dy[L.gs] = -acc / (L.rho * L.cpavg);
+    }
+    if (L.valid && (B.spec_rates || B.dy)) {
+        for (int k = u; k < nsp; k += NU) {
+            const double om = T[(M.v.T_OM + k) * TS];
             if (B.spec_rates) B.spec_rates[k * B.o_ld + L.gs] = om;
-            if (B.dy && k < last) B.dy[(k + 1) * B.o_ld + L.gs] = om * Wk * L.invrho;
+            if (B.dy && k < last) B.dy[(k + 1) * B.o_ld + L.gs] = om * M.sp[k * SPW + 1] * L.invrho;
         }
     }
 }
 
-// per-state sums H = sum_k h_k W_k omega_k and SCP = sum_k omega_k W_k cp_k, needed by
-// the lanes that finish the energy row (il == 0) and by dT/dt of dydt
-// (rate_subs.py:2171-2335)
+// ---------------------------------------------------------------- output
+// Jacobian entries in memory order (create_jacobian.py:2850-2938 species block,
+// 2728-2845 d/dT column); every entry of the NSP x NSP block is written.
 template <int TS>
-PJ_DEV void phase3c(const DevMech& M, const Batch& B, double* V, int tid, int NT, Lane& L)
+PJ_DEV void phase_out_block(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
 {
-    const int s = tid % TS, il = (tid % 64) / TS, u = tid / TS;
-    if (il != 0) return;
-    double H = 0.0, scp = 0.0;
-    for (int k = 0; k < M.nsp; ++k) {
-        const double om = V[(M.v.AOM + k) * TS + s];
-        H += V[(M.v.HW + k) * TS + s] * om;
-        scp += om * M.sp[k * SPW + 1] * V[(M.v.CP + k) * TS + s];
+    const int s = tid % TS, u = tid / TS, NU = NT / TS;
+    const int nsp = M.nsp;
+    const double* T = V + M.v.TB * TS + s;
+    for (int e = u; e < nsp * nsp; e += NU) {
+        const int col = e / nsp, row = e - col * nsp;
+        if (row == 0) continue;                       // energy row: phase_out_energy
+        const int k = row - 1;
+        double val;
+        if (col == 0) {
+            val = M.sp[k * SPW + 1] * T[(M.v.T_JT + k) * TS];
+        } else {
+            const int j = col - 1;
+            const double* spj = M.sp + j * SPW;
+            val = (M.sp[k * SPW + 1] * spj[0]) *
+                  (T[(M.v.T_P + k) * TS] - spj[3] * T[(M.v.T_Q + k) * TS] + T[(M.v.T_S + k + nsp * j) * TS]);
+        }
+        if (L.valid) B.jac[e * B.j_si + L.gs * B.j_ss] = val;
     }
-    L.H = H; L.scp = scp;
-    if (u == 0 && B.dy && L.valid) B.dy[L.gs] = -H / (L.rho * L.cpavg);
 }
 
-// ---------------------------------------------------------------- phase 4
-// Jacobian, one column per wavefront per round (create_jacobian.py:2850-2938
-// species block, 3095-3234 energy row, 1853-1905 jac[0]).  Within a wavefront
-// the IL = 64/TS item lanes of a state walk the NSP+1 "rows" of the column in
-// chunks: row 0 is the energy entry, rows 1..NSP-1 the species rows, row NSP
-// the eliminated last species (it enters the energy row only).  Each lane
-// keeps its part of  sum_k h_k W_k M_kj  (phase4a) and the row-0 lane adds the
-// IL parts up through the RED exchange area (phase4b).  Every entry of the
-// NSP x NSP block is written.
+// energy row (create_jacobian.py:3095-3234) and jac[0] (create_jacobian.py:1853-1905)
 template <int TS>
-PJ_DEV int phase4_rounds(const DevMech& M, int NT) { return (M.nsp + NT / 64 - 1) / (NT / 64); }
-
-template <int TS>
-PJ_DEV void phase4a(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L, int round)
+PJ_DEV void phase_out_energy(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
 {
-    constexpr int IL = 64 / TS;
-    const int s = tid % TS, lane = tid % 64, il = lane / TS, w = tid / 64, NW = NT / 64;
+    const int s = tid % TS, u = tid / TS, NU = NT / TS;
     const int nsp = M.nsp, last = nsp - 1;
-    const int col = round * NW + w;
-    double part = 0.0;
-    if (col == 0) {
-        // d/dT column (create_jacobian.py:2728-2845): rows W_k * sum_i nu_ki theta_i
-        for (int r = (il == 0 ? IL : il); r <= nsp; r += IL) {
-            const int k = r - 1;
-            const double jt = V[(M.v.AJT + k) * TS + s];
-            part += V[(M.v.HW + k) * TS + s] * jt;
-            if (k < last && L.valid) B.jac[r * B.j_si + L.gs * B.j_ss] = M.sp[k * SPW + 1] * jt;
+    const double* T = V + M.v.TB * TS + s;
+    const double H = V[(M.v.SC + SC_H) * TS + s];
+    const double icp = 1.0 / L.cpavg;
+    // walk the columns from the last item lanes so the long column sums do not
+    // share a wavefront round with the first species-block entries
+    for (int col = NU - 1 - u; col < nsp; col += NU) {
+        double val;
+        if (col == 0) {
+            val = -(V[(M.v.SC + SC_SCP) * TS + s] - (L.dcp * icp) * H + L.rho * V[(M.v.SC + SC_SJT) * TS + s]) /
+                  (L.rho * L.cpavg);
+        } else {
+            const int j = col - 1;
+            const double* spj = M.sp + j * SPW;
+            double hs = 0.0;
+            const double* Sj = T + (M.v.T_S + nsp * j) * TS;
+            for (int k = 0; k < nsp; ++k) hs += V[(M.v.HW + k) * TS + s] * Sj[k * TS];
+            const double tot = V[(M.v.SC + SC_HP) * TS + s] - spj[3] * V[(M.v.SC + SC_HQ) * TS + s] + hs;
+            val = -tot * spj[0] * icp +
+                  (V[(M.v.CP + j) * TS + s] - V[(M.v.CP + last) * TS + s]) * H * L.invrho * icp * icp;
         }
-    } else if (col < nsp) {
-        const int j = col - 1;
-        const double wj = M.sp[j * SPW + 3];
-        const double iWj = M.sp[j * SPW + 0];
-        const uint32_t* PG = lds_prog<TS>(M, V, NT);
-        const uint32_t* ep = PG + M.p4en + nsp * j;
-        const uint2* cb = reinterpret_cast<const uint2*>(PG + M.p4c);
-        for (int r = (il == 0 ? IL : il); r <= nsp; r += IL) {
-            const int k = r - 1;
-            const uint32_t en = ep[k];
-            double sum = V[(M.v.AP + k) * TS + s] - wj * V[(M.v.AQ + k) * TS + s];
-            const uint2* c = cb + (en >> 8);
-            for (int b = 0; b < (int)(en & 255u); ++b) {
-                const uint2 cw = c[b];
-                const uint32_t c0 = cw.x & 0xffffu, c1 = cw.x >> 16, c2 = cw.y & 0xffffu, c3 = cw.y >> 16;
-                sum += (double)((int)(c0 & 7u) - 4) * V[(c0 >> 3) * TS + s] +
-                       (double)((int)(c1 & 7u) - 4) * V[(c1 >> 3) * TS + s] +
-                       (double)((int)(c2 & 7u) - 4) * V[(c2 >> 3) * TS + s] +
-                       (double)((int)(c3 & 7u) - 4) * V[(c3 >> 3) * TS + s];
-            }
-            part += V[(M.v.HW + k) * TS + s] * sum;
-            if (k < last && L.valid)
-                B.jac[(r + nsp * col) * B.j_si + L.gs * B.j_ss] = (M.sp[k * SPW + 1] * iWj) * sum;
-        }
+        if (L.valid) B.jac[(nsp * col) * B.j_si + L.gs * B.j_ss] = val;
     }
-    V[M.v.RED * TS + tid] = part;
-}
-
-template <int TS>
-PJ_DEV void phase4b(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L, int round)
-{
-    constexpr int IL = 64 / TS;
-    const int s = tid % TS, lane = tid % 64, il = lane / TS, w = tid / 64, NW = NT / 64;
-    const int nsp = M.nsp, last = nsp - 1;
-    const int col = round * NW + w;
-    if (col >= nsp || il != 0) return;
-    double tot = 0.0;
-    for (int x = 0; x < IL; ++x) tot += V[M.v.RED * TS + w * 64 + x * TS + s];
-    double val;
-    if (col == 0) {
-        val = -(L.scp - (L.dcp / L.cpavg) * L.H + L.rho * tot) / (L.rho * L.cpavg);
-    } else {
-        const int j = col - 1;
-        const double icp = 1.0 / L.cpavg;
-        val = -tot * M.sp[j * SPW + 0] * icp +
-              (V[(M.v.CP + j) * TS + s] - V[(M.v.CP + last) * TS + s]) * L.H * L.invrho * icp * icp;
-    }
-    if (L.valid) B.jac[(nsp * col) * B.j_si + L.gs * B.j_ss] = val;
 }
 
 }  // namespace pj

@@ -226,9 +226,14 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
     v.HW = o; o += nsp; v.CP = o; o += nsp; v.YC = o; o += nsp; v.YD = o; o += nsp;
     v.RQ = o; o += nrxn; v.RTH = o; o += nrxn; v.RP = o; o += nrxn; v.RQQ = o; o += nrxn;
     v.G = o; o += ng;
-    v.AP = o; o += nsp; v.AQ = o; o += nsp; v.AJT = o; o += nsp; v.AOM = o; o += nsp;
-    v.RED = o;                       // partial-sum exchange area: NT doubles, NOT scaled by TS
     v.NV = o;
+    v.TB = o;
+    v.T_OM = 0; v.T_JT = nsp; v.T_P = 2 * nsp; v.T_Q = 3 * nsp; v.T_S = 4 * nsp;
+    v.T_JTQ = v.T_S + nsp * (nsp - 1);
+    v.T_PART = v.T_JTQ + 1;
+    v.NTILE = v.T_PART;
+    v.SC = v.TB + v.NTILE;
+    v.NSLOT = v.SC + SC_COUNT;
 
     // ---- P3: per species gather (device reaction order) ----
     p.sp_ptr.assign(nsp + 1, 0);
@@ -265,6 +270,28 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
             }
         }
     }
+    // ---- scatter-phase terms ----
+    for (int d = 0; d < nrxn; ++d) {
+        const int32_t* ri = &p.ri[(size_t)d * RIW];
+        const int gb = ri[RI_GBASE];
+        for (int q = 0; q < ri[RI_NET_CNT]; ++q) {
+            const int k = p.net_sp[ri[RI_NET_PTR] + q];
+            const int nu = (int)p.net_nu[ri[RI_NET_PTR] + q];
+            p.contribs.push_back({v.RQ + d, v.T_OM + k, nu, true});
+            p.contribs.push_back({v.RTH + d, v.T_JT + k, nu, true});
+            p.contribs.push_back({v.RP + d, v.T_P + k, nu, true});
+            p.contribs.push_back({v.RQQ + d, v.T_Q + k, nu, true});
+            if (k == last && d == p.lastq_rxn) p.contribs.push_back({v.RTH + d, v.T_JTQ, nu, true});
+        }
+        for (size_t t = 0; t < gslot_sp[d].size(); ++t) {
+            const int j = gslot_sp[d][t];
+            if (j >= last) continue;
+            for (int q = 0; q < ri[RI_NET_CNT]; ++q)
+                p.contribs.push_back({v.G + gb + (int)t, v.T_S + p.net_sp[ri[RI_NET_PTR] + q] + nsp * j,
+                                      (int)p.net_nu[ri[RI_NET_PTR] + q], false});
+        }
+    }
+
     auto pack = [&](const std::vector<std::vector<uint16_t>>& lists, uint16_t pad, int* en_off, int* c_off) -> bool {
         *en_off = (int)p.prog.size();
         p.prog.resize(p.prog.size() + lists.size());
@@ -289,6 +316,88 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
             for (int q = p.sp_ptr[k]; q < p.sp_ptr[k + 1]; ++q)
                 l3[k].push_back((uint16_t)((p.sp_rxn[q] << 3) | ((int)p.sp_nu[q] + 4)));
         if (!pack(l3, (uint16_t)4, &p.p3en, &p.p3c)) { p.error = "P3 program overflow"; return false; }
+    }
+    return true;
+}
+
+bool build_schedule(Programs& p, int NW, int IL, Schedule& out)
+{
+    if (NW < 1 || NW > 16 || IL < 1 || IL > 64) { p.error = "bad schedule geometry"; return false; }
+    VMap& v = p.vm;
+    out = Schedule();
+    out.NW = NW; out.IL = IL;
+    // terms per target
+    const int nt0 = v.T_PART;
+    std::vector<std::vector<int>> by_tgt(nt0);
+    for (int c = 0; c < (int)p.contribs.size(); ++c) by_tgt[p.contribs[c].tgt].push_back(c);
+    const long total = (long)p.contribs.size();
+    const int R = (int)std::max<long>(8, (total + (long)NW * IL - 1) / ((long)NW * IL));   // balanced rounds
+    // split hub targets of the dense vectors into partial accumulators of <= R terms
+    struct Tgt { int slot; std::vector<int> terms; bool dense; };
+    std::vector<Tgt> tg;
+    int nextp = v.T_PART;
+    for (int t = 0; t < nt0; ++t) {
+        auto& l = by_tgt[t];
+        if (l.empty()) continue;
+        const bool dense = p.contribs[l[0]].dense;
+        if ((int)l.size() <= R || !dense) { tg.push_back({t, l, dense}); continue; }
+        const int parts = ((int)l.size() + R - 1) / R;
+        for (int q = 0; q < parts; ++q) {
+            Tgt x{q == 0 ? t : nextp, {}, true};
+            for (int e = q; e < (int)l.size(); e += parts) x.terms.push_back(l[e]);
+            if (q > 0) { out.fin_tgt.push_back(t); out.fin_part.push_back(nextp); ++nextp; }
+            tg.push_back(std::move(x));
+        }
+    }
+    v.NTILE = nextp;
+    v.SC = v.TB + v.NTILE;
+    v.NSLOT = v.SC + SC_COUNT;
+    if (v.NTILE >= 65536 || v.NV >= 8192) { p.error = "mechanism too large for the scatter encoding"; return false; }
+    // ownership: heaviest target to the least loaded wavefront; dense and sparse balanced separately
+    std::vector<std::vector<int>> own_d(NW), own_s(NW);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<int> idx;
+        for (int i = 0; i < (int)tg.size(); ++i) if (tg[i].dense == (pass == 0)) idx.push_back(i);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return tg[a].terms.size() > tg[b].terms.size(); });
+        std::vector<long> load(NW, 0);
+        for (int i : idx) {
+            int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            (pass == 0 ? own_d : own_s)[w].push_back(i);
+            load[w] += (long)tg[i].terms.size();
+        }
+    }
+    // rounds: up to IL distinct targets per round, most remaining terms first
+    auto emit = [&](const std::vector<int>& owned, std::vector<uint32_t>& codes) {
+        std::vector<std::pair<int, int>> rem;      // (remaining, index into owned)
+        std::vector<size_t> pos(owned.size(), 0);
+        int rounds = 0;
+        for (;;) {
+            rem.clear();
+            for (int i = 0; i < (int)owned.size(); ++i) {
+                const int left = (int)tg[owned[i]].terms.size() - (int)pos[i];
+                if (left > 0) rem.push_back({left, i});
+            }
+            if (rem.empty()) break;
+            std::partial_sort(rem.begin(), rem.begin() + std::min<size_t>(IL, rem.size()), rem.end(),
+                              [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+            for (int l = 0; l < IL; ++l) {
+                uint32_t code = 4u << 29;        // no-op
+                if (l < (int)rem.size()) {
+                    const int i = rem[l].second;
+                    const Contrib& c = p.contribs[tg[owned[i]].terms[pos[i]++]];
+                    code = (uint32_t)c.src | ((uint32_t)tg[owned[i]].slot << 13) | ((uint32_t)(c.nu + 4) << 29);
+                }
+                codes.push_back(code);
+            }
+            ++rounds;
+        }
+        while (rounds % 4) { for (int l = 0; l < IL; ++l) codes.push_back(4u << 29); ++rounds; }
+        return rounds;
+    };
+    for (int w = 0; w < NW; ++w) {
+        out.off[w] = (int)out.codes.size();
+        out.rounds_dense[w] = emit(own_d[w], out.codes);
+        out.rounds[w] = out.rounds_dense[w] + emit(own_s[w], out.codes);
     }
     return true;
 }

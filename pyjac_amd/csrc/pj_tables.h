@@ -47,9 +47,32 @@ struct VMap {
     int C = 0, ONE = 0, HW = 0, CP = 0, YC = 0, YD = 0;
     int RQ = 0, RTH = 0, RP = 0, RQQ = 0;                    // [nrxn] each
     int G = 0;                                               // [ng]
-    int AP = 0, AQ = 0, AJT = 0, AOM = 0;                    // [nsp] each
-    int RED = 0;                                             // start of the NT-double exchange area (not x TS)
-    int NV = 0;
+    int NV = 0;                                              // slots written by phases 0-2
+    // accumulation tile (targets of the scatter phase), slot = TB + target:
+    //   T_OM + k, T_JT + k, T_P + k, T_Q + k   dense vectors (omega_k, sum nu theta, P_k, Q_k)
+    //   T_S + k + nsp*j                        sparse block S_kj (k < nsp incl. last species, j < nsp-1)
+    //   T_JTQ                                  d/dT of the last species from the one reaction the
+    //                                          reference keeps (create_jacobian.py:2786-2818)
+    //   T_PART ...                             partial accumulators of split hub targets
+    int TB = 0, T_OM = 0, T_JT = 0, T_P = 0, T_Q = 0, T_S = 0, T_JTQ = 0, T_PART = 0;
+    int NTILE = 0;                                           // incl. partials (set by build_schedule)
+    int SC = 0;                                              // 5 per-state scalars after the tile
+    int NSLOT = 0;                                           // total slots per state
+};
+enum { SC_H, SC_HP, SC_HQ, SC_SCP, SC_SJT, SC_COUNT };
+
+// one term of the scatter phase: tile[tgt] += nu * V[src]
+struct Contrib { int src, tgt, nu; bool dense; };
+
+// Conflict-free scatter schedule for NW wavefronts x IL item lanes: every tile
+// target is owned by one wavefront; within a round the IL lanes of a wavefront
+// update distinct targets, so plain LDS read-modify-writes need no atomics and
+// no barrier.  Dense-vector terms come first (rates-only launches stop there).
+struct Schedule {
+    int NW = 0, IL = 0;
+    std::vector<uint32_t> codes;       // [wave][round][il]: src | tgt << 13 | (nu + 4) << 29
+    int off[16] = {0}, rounds[16] = {0}, rounds_dense[16] = {0};
+    std::vector<int32_t> fin_tgt, fin_part;   // partial slot -> final target (added after the scatter)
 };
 
 struct Programs {
@@ -75,8 +98,12 @@ struct Programs {
     std::vector<uint32_t> prog;
     int p4en = 0, p4c = 0, p3en = 0, p3c = 0;
     int lastq_rxn = -1;            // device index of the F_LASTQ reaction
+    std::vector<Contrib> contribs;
     std::string error;
 };
+
+// (re)builds the schedule and fixes vm.NTILE / vm.SC / vm.NSLOT for this geometry
+bool build_schedule(Programs& p, int NW, int IL, Schedule& out);
 
 // 64-bit FNV-1a of the device programs: identifies a mechanism for the
 // register-resident specialisation (pj_lane.hip).

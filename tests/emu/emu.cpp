@@ -10,7 +10,6 @@
 struct uint2 { unsigned x, y; };
 using std::exp; using std::log; using std::fmax;
 #define PJ_DEV static inline
-#define PJ_WAVE_SYNC() ((void)0)
 #include "../../pyjac_amd/csrc/pj_kernel.h"
 #include "../../pyjac_amd/csrc/pj_tables.cpp"
 
@@ -19,23 +18,21 @@ using namespace pj;
 template <int TS>
 static void run_tiles(const DevMech& M, const Batch& B, int NT, int want_jac)
 {
-    std::vector<double> V((size_t)M.nv * TS + NT + (M.prog_words + 1) / 2 + 1);
-    for (int tid = 0; tid < NT; ++tid) stage_prog<TS>(M, V.data(), tid, NT);
+    std::vector<double> V((size_t)M.v.NSLOT * TS);
     std::vector<Lane> L(NT);
     const long ntiles = (B.n + TS - 1) / TS;
     for (long t = 0; t < ntiles; ++t) {
         for (int tid = 0; tid < NT; ++tid) phase0a<TS>(M, B, V.data(), tid, NT, t, L[tid]);
+        for (int tid = 0; tid < NT; ++tid) phase_zero_tile<TS>(M, V.data(), tid, NT);
         for (int tid = 0; tid < NT; ++tid) phase0b<TS>(M, B, V.data(), tid, NT, L[tid]);
         for (int tid = 0; tid < NT; ++tid) phase0c_scale<TS>(M, B, V.data(), tid, NT, L[tid]);
         for (int tid = 0; tid < NT; ++tid) phase2<TS>(M, B, V.data(), tid, NT, L[tid]);
-        for (int tid = 0; tid < NT; ++tid) phase3<TS>(M, B, V.data(), tid, NT, L[tid]);
-        for (int tid = 0; tid < NT; ++tid) phase3c<TS>(M, B, V.data(), tid, NT, L[tid]);
+        for (int tid = 0; tid < NT; ++tid) phase_scatter<TS>(M, V.data(), tid, NT, !want_jac);
+        for (int tid = 0; tid < NT; ++tid) phase_fin1<TS>(M, V.data(), tid, NT);
+        for (int tid = 0; tid < NT; ++tid) phase_fin2<TS>(M, B, V.data(), tid, NT, L[tid]);
         if (want_jac) {
-            const int nr = phase4_rounds<TS>(M, NT);
-            for (int r = 0; r < nr; ++r) {
-                for (int tid = 0; tid < NT; ++tid) phase4a<TS>(M, B, V.data(), tid, NT, L[tid], r);
-                for (int tid = 0; tid < NT; ++tid) phase4b<TS>(M, B, V.data(), tid, NT, L[tid], r);
-            }
+            for (int tid = 0; tid < NT; ++tid) phase_out_energy<TS>(M, B, V.data(), tid, NT, L[tid]);
+            for (int tid = 0; tid < NT; ++tid) phase_out_block<TS>(M, B, V.data(), tid, NT, L[tid]);
         }
     }
 }
@@ -54,8 +51,12 @@ extern "C" int emu_run(const int32_t* I, long nI, const double* D, long nD, long
     M.eff_sp = P.eff_sp.data(); M.eff_am1 = P.eff_am1.data(); M.kcg = P.kcg.data();
     M.plog = P.plog.data(); M.net_sp = P.net_sp.data(); M.net_nu = P.net_nu.data();
     M.sp_ptr = P.sp_ptr.data(); M.sp_rxn = P.sp_rxn.data(); M.sp_nu = P.sp_nu.data();
-    M.prog = P.prog.data(); M.prog_words = (int)P.prog.size();
-    M.p4en = P.p4en; M.p4c = P.p4c; M.p3en = P.p3en; M.p3c = P.p3c; M.prog_in_lds = (TS % 2 == 0);
+    Schedule S;
+    if (!build_schedule(P, NT / 64, 64 / TS, S)) return -3;
+    M.v = P.vm; M.nv = P.vm.NV;
+    M.sched = S.codes.data();
+    for (int w = 0; w < 16; ++w) { M.sched_off[w] = S.off[w]; M.sched_rounds[w] = S.rounds[w]; M.sched_rounds_dense[w] = S.rounds_dense[w]; }
+    M.fin_tgt = S.fin_tgt.data(); M.fin_part = S.fin_part.data(); M.nfin = (int)S.fin_tgt.size();
     Batch B;
     B.n = n; B.pres = pres; B.y = y_soa; B.y_si = n; B.y_ss = 1;
     B.jac = jac;
