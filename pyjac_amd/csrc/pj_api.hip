@@ -70,16 +70,26 @@ k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, doubl
     extern __shared__ __attribute__((aligned(16))) double V[];
     const int tid = threadIdx.x, NT = blockDim.x;
     const long ntiles = (B.n + TS - 1) / TS;
+#ifdef PJ_TIMING
+    long long tacc[10] = {0}, tprev = clock64();
+#define PJ_TICK(i) { __syncthreads(); const long long tn = clock64(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define PJ_TICK(i)
+#endif
+    stage_consts<TS>(M, V, tid, NT);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         Lane L;
         if (mode & MODE_CONC_IN) {
             phase0c<TS>(M, B, cin, Tin, V, tid, NT, tile, L);
         } else {
             phase0a<TS>(M, B, V, tid, NT, tile, L);
+            PJ_TICK(0)
             phase_zero_tile<TS>(M, V, tid, NT);
             __syncthreads();
+            PJ_TICK(1)
             phase0b<TS>(M, B, V, tid, NT, L);
             __syncthreads();
+            PJ_TICK(2)
             phase0c_scale<TS>(M, B, V, tid, NT, L);
             if (aux && tid / TS == 0 && L.valid) {
                 // y_N, mw_avg, rho of eval_conc (rate_subs.py:1595-1597)
@@ -89,22 +99,35 @@ k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, doubl
             }
         }
         __syncthreads();
+        PJ_TICK(3)
         if (!(mode & ABL_P2)) phase2<TS>(M, B, V, tid, NT, L);
         __syncthreads();
+        PJ_TICK(4)
         if (!(mode & MODE_CONC_IN)) {
             if (!(mode & ABL_P3)) phase_scatter<TS>(M, V, tid, NT, !(mode & MODE_JAC));
             __syncthreads();
+            PJ_TICK(5)
             phase_fin1<TS>(M, V, tid, NT);
             __syncthreads();
-            phase_fin2<TS>(M, B, V, tid, NT, L);
+            PJ_TICK(6)
+            phase_fin2a<TS>(M, B, V, tid, NT, L);
             __syncthreads();
+            phase_fin2b<TS>(M, B, V, tid, NT, L);
+            __syncthreads();
+            PJ_TICK(7)
             if ((mode & MODE_JAC) && !(mode & ABL_P4)) {
                 phase_out_energy<TS>(M, B, V, tid, NT, L);
+                PJ_TICK(8)
                 phase_out_block<TS>(M, B, V, tid, NT, L);
             }
         }
         __syncthreads();
+        PJ_TICK(9)
     }
+#ifdef PJ_TIMING
+    if (Tin && !(mode & MODE_CONC_IN) && tid == 0 && blockIdx.x < 64)
+        for (int i = 0; i < 10; ++i) const_cast<double*>(Tin)[blockIdx.x * 10 + i] = (double)tacc[i];
+#endif
 }
 
 // eval_spec_rates from caller-supplied rates (pyjacob_wrapper.pyx:11); one thread per state
@@ -160,8 +183,8 @@ struct pj_mech {
     DevMech M;
     bool on_device = false;
     int device = -1;
-    DevBuf<double> sp, rd, eff_am1, kcg, plog, net_nu, sp_nu;
-    DevBuf<int32_t> ri, eff_sp, net_sp, sp_ptr, sp_rxn, fin_tgt, fin_part;
+    DevBuf<double> sp, rd, rtd, eff_am1, kcg, plog, net_nu, sp_nu;
+    DevBuf<int32_t> ri, rti, eff_sp, net_sp, sp_ptr, sp_rxn, fin_tgt, fin_part, fin_cnt;
     DevBuf<uint32_t> sched;
     Schedule S;                // host copy; rebuilt when the launch geometry changes
     int sched_nw = 0, sched_il = 0;
@@ -197,12 +220,13 @@ int ensure_device(pj_mech* m)
     m->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     Programs& P = m->P;
     HIPCHK(m->sp.upload(P.sp)); HIPCHK(m->ri.upload(P.ri)); HIPCHK(m->rd.upload(P.rd));
+    HIPCHK(m->rti.upload(P.rti)); HIPCHK(m->rtd.upload(P.rtd));
     HIPCHK(m->eff_sp.upload(P.eff_sp)); HIPCHK(m->eff_am1.upload(P.eff_am1));
     HIPCHK(m->kcg.upload(P.kcg)); HIPCHK(m->plog.upload(P.plog));
     HIPCHK(m->net_sp.upload(P.net_sp)); HIPCHK(m->net_nu.upload(P.net_nu));
     HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
     DevMech& M = m->M;
-    M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
+    M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.rti = m->rti.p; M.rtd = m->rtd.p; M.nrp = P.nrp; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
     M.kcg = m->kcg.p; M.plog = m->plog.p; M.net_sp = m->net_sp.p; M.net_nu = m->net_nu.p;
     M.sp_ptr = m->sp_ptr.p; M.sp_rxn = m->sp_rxn.p; M.sp_nu = m->sp_nu.p;
     m->on_device = true;
@@ -237,24 +261,25 @@ int pick_launch(pj_mech* m, int* ts, int* nt, size_t* lds)
         size_t budget = 80 * 1024;
         if (const char* e = getenv("PJ_LDS_BUDGET")) budget = (size_t)atol(e);
         // the tile size does not depend on the schedule except for a few partial slots
-        const size_t per_state = (size_t)(m->P.vm.TB + m->P.vm.T_PART + SC_COUNT + 64) * 8;
+        const size_t per_state = (size_t)(m->P.vm.TB + m->P.vm.T_PART + SC_COUNT * (m->P.nsp + 1) + 64) * 8;
         t = 64;
         while (t > 1 && per_state * t > budget) t >>= 1;
     }
     int rc = ensure_schedule(m, t, n);
     if (rc) return rc;
-    *ts = t; *nt = n; *lds = (size_t)m->P.vm.NSLOT * 8 * t;
+    *ts = t; *nt = n; *lds = (size_t)m->P.vm.NSLOT * 8 * t + (size_t)3 * m->P.nsp * 8;
     return PJ_OK;
 }
 
 int upload_schedule(pj_mech* m)
 {
     if (m->sched_on_device) return PJ_OK;
-    m->sched.release(); m->fin_tgt.release(); m->fin_part.release();
+    m->sched.release(); m->fin_tgt.release(); m->fin_part.release(); m->fin_cnt.release();
     HIPCHK(m->sched.upload(m->S.codes));
     HIPCHK(m->fin_tgt.upload(m->S.fin_tgt));
     HIPCHK(m->fin_part.upload(m->S.fin_part));
-    m->M.sched = m->sched.p; m->M.fin_tgt = m->fin_tgt.p; m->M.fin_part = m->fin_part.p;
+    HIPCHK(m->fin_cnt.upload(m->S.fin_cnt));
+    m->M.sched = m->sched.p; m->M.fin_tgt = m->fin_tgt.p; m->M.fin_part = m->fin_part.p; m->M.fin_cnt = m->fin_cnt.p;
     m->sched_on_device = true;
     return PJ_OK;
 }
@@ -373,9 +398,9 @@ void pj_mech_destroy(pj_mech* m)
 {
     if (!m) return;
     if (m->on_device) {
-        m->sp.release(); m->rd.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release();
+        m->sp.release(); m->rd.release(); m->rtd.release(); m->rti.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release();
         m->net_nu.release(); m->sp_nu.release(); m->sched.release(); m->ri.release(); m->eff_sp.release();
-        m->fin_tgt.release(); m->fin_part.release();
+        m->fin_tgt.release(); m->fin_part.release(); m->fin_cnt.release();
         m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release();
         m->ws.release(); m->ws1.release();
     }
@@ -480,6 +505,20 @@ int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_
     B.spec_rates = d_spec_rates; B.dy = d_dy;
     return launch(m, B, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
+
+#ifdef PJ_TIMING
+// debug build only: per-phase cycle counts of the first 64 workgroups (d_dbg: 640 doubles)
+int pj_debug_phase_cycles(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
+                          double* d_jac, int jac_layout, double* d_dbg)
+{
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    B.n = n; B.pres = d_pres; B.y = d_y; B.jac = d_jac; B.o_ld = n;
+    set_layout(n, m->P.nsp, y_layout, &B.y_si, &B.y_ss);
+    set_layout(n, m->P.nsp * m->P.nsp, jac_layout, &B.j_si, &B.j_ss);
+    return launch(m, B, MODE_JAC, nullptr, d_dbg, nullptr, nullptr);
+}
+#endif
 
 int pj_time_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
                          double* d_jac, int jac_layout, void* stream, int iters, double* ms_per_launch)

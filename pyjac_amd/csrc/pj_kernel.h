@@ -40,6 +40,9 @@ struct DevMech {
     const double* sp;
     const int32_t* ri;
     const double* rd;
+    const int32_t* rti;        // field-major reaction tables (pj_tables.h)
+    const double* rtd;
+    int nrp;
     const int32_t* eff_sp;
     const double* eff_am1;
     const double* kcg;
@@ -54,6 +57,7 @@ struct DevMech {
     int sched_off[16], sched_rounds[16], sched_rounds_dense[16];
     const int32_t* fin_tgt;
     const int32_t* fin_part;
+    const int32_t* fin_cnt;
     int nfin;
 };
 
@@ -68,6 +72,31 @@ struct Batch {
     double* conc; double* fwd; double* rev; double* pres_mod; double* spec_rates; double* dy;
     long o_ld;                               // SoA leading dimension of the rate outputs
 };
+
+// species constants shared by all states of the workgroup, staged once:
+// KC[0*nsp + k] = 1/W_k, KC[1*nsp + k] = W_k, KC[2*nsp + k] = W_k / W_N
+template <int TS>
+PJ_DEV double* lds_kc(const DevMech& M, double* V) { return V + (size_t)M.v.NSLOT * TS; }
+template <int TS>
+PJ_DEV const double* lds_kc(const DevMech& M, const double* V) { return V + (size_t)M.v.NSLOT * TS; }
+
+template <int TS>
+PJ_DEV void stage_consts(const DevMech& M, double* V, int tid, int NT)
+{
+    double* KC = lds_kc<TS>(M, V);
+    for (int k = tid; k < M.nsp; k += NT) {
+        KC[k] = M.sp[k * SPW + 0];
+        KC[M.nsp + k] = M.sp[k * SPW + 1];
+        KC[2 * M.nsp + k] = M.sp[k * SPW + 3];
+    }
+}
+
+#ifndef PJ_LDS_ADD
+// tile[x] += v without waiting for the old value: non-returning LDS atomic
+// (ds_add_f64).  The schedule gives every target to one wavefront and LDS
+// executes a wavefront's operations in order, so the sum order is fixed.
+#define PJ_LDS_ADD(ptr, v) (void)__hip_atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#endif
 
 struct Lane {
     double T, logT, invT, p, logp, rho, invrho, Wbar, m, yN;
@@ -121,16 +150,18 @@ PJ_DEV void phase0b(const DevMech& M, const Batch& B, double* V, int tid, int NT
 {
     const int s = tid % TS, u = tid / TS, NU = NT / TS;
     const int nsp = M.nsp, last = nsp - 1;
+    const double* KC = lds_kc<TS>(M, V);
     double sumY = 0.0, sumYW = 0.0, cpa = 0.0, dcp = 0.0;
+#pragma unroll 8
     for (int k = 0; k < last; ++k) {
         const double Yk = V[(M.v.C + k) * TS + s];
         sumY += Yk;
-        sumYW += Yk * M.sp[k * SPW + 0];
+        sumYW += Yk * KC[k];
         cpa += V[(M.v.YC + k) * TS + s];
         dcp += V[(M.v.YD + k) * TS + s];
     }
     const double yN = 1.0 - sumY;
-    sumYW += yN * M.sp[last * SPW + 0];
+    sumYW += yN * KC[last];
     cpa += yN * V[(M.v.YC + last) * TS + s];
     dcp += yN * V[(M.v.YD + last) * TS + s];
     L.yN = yN;
@@ -149,7 +180,7 @@ PJ_DEV void phase0c_scale(const DevMech& M, const Batch& B, double* V, int tid, 
     const int nsp = M.nsp, last = nsp - 1;
     for (int k = u; k < nsp; k += NU) {
         const double Yk = (k == last) ? L.yN : V[(M.v.C + k) * TS + s];
-        const double Ck = L.rho * Yk * M.sp[k * SPW + 0];
+        const double Ck = L.rho * Yk * lds_kc<TS>(M, V)[k];
         V[(M.v.C + k) * TS + s] = Ck;
         if (B.conc && L.valid) B.conc[k * B.o_ld + L.gs] = Ck;
     }
@@ -166,16 +197,21 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
     const double T = L.T, logT = L.logT, invT = L.invT;
     const int last = M.nsp - 1;
     for (int i = u; i < M.nrxn; i += NU) {
-        const int32_t* ri = M.ri + i * RIW;
-        const double* rd = M.rd + i * RDW;
-        const int fl = ri[RI_FLAGS];
+        // field-major tables: lane i reads element i of every field -> coalesced, and all
+        // loads of a reaction are issued together (one memory round trip)
+        const int32_t* rti = M.rti + i;
+        const double* rtd = M.rtd + i;
+        const int NRP = M.nrp;
+#define RI_(f) rti[(f) * NRP]
+#define RD_(f) rtd[(f) * NRP]
+        const int fl = RI_(RI_FLAGS);
 
         // ---- forward rate constant and T d(ln kf)/dT ----
         double lnk, dlnk;
         if (fl & F_PLOG) {
             // rate_subs.py:598-632; create_jacobian.py:1687-1850
-            const double* P = M.plog + ri[RI_PLOG_PTR] * PLW;
-            const int np = ri[RI_PLOG_CNT];
+            const double* P = M.plog + RI_(RI_PLOG_PTR) * PLW;
+            const int np = RI_(RI_PLOG_CNT);
             int q = 0;
             while (q < np && L.p > P[q * PLW]) ++q;      // first breakpoint with p <= P_q
             if (q == 0 || q == np) {
@@ -192,17 +228,24 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
                 dlnk = r1[3] + r1[4] * invT + ((r2[3] - r1[3]) + (r2[4] - r1[4]) * invT) * f;
             }
         } else {
-            lnk = rd[RD_LNA] + rd[RD_B] * logT - rd[RD_TA] * invT;
-            dlnk = rd[RD_B] + rd[RD_TA] * invT;
+            lnk = RD_(RD_LNA) + RD_(RD_B) * logT - RD_(RD_TA) * invT;
+            dlnk = RD_(RD_B) + RD_(RD_TA) * invT;
         }
-        const double kf = rd[RD_SGN] * exp(lnk);
+        const double kf = RD_(RD_SGN) * exp(lnk);
 
         // ---- equilibrium constant (pre-summed NASA groups, rate_subs.py:660-809) ----
         double kr = 0.0, TdlnKc = 0.0;
         if (fl & F_REV) {
-            double lnKc = rd[RD_LNPREF];
-            const double* g = M.kcg + ri[RI_KC_PTR] * KCW;
-            for (int c = 0; c < ri[RI_KC_CNT]; ++c, g += KCW) {
+            double lnKc = RD_(RD_LNPREF);
+            {   // group 0 sits inline in the field-major table
+                const int o = (T <= RD_(RDW + 0)) ? RDW + 1 : RDW + 8;
+                const double a0 = RD_(o), a1 = RD_(o + 1), a2 = RD_(o + 2), a3 = RD_(o + 3), a4 = RD_(o + 4),
+                             a5 = RD_(o + 5), a6 = RD_(o + 6);
+                lnKc += a0 + a1 * logT + T * (a2 + T * (a3 + T * (a4 + a5 * T))) - a6 * invT;
+                TdlnKc += a1 + T * (a2 + T * (2.0 * a3 + T * (3.0 * a4 + 4.0 * a5 * T))) + a6 * invT;
+            }
+            const double* g = M.kcg + (RI_(RI_KC_PTR) + 1) * KCW;      // species with other T_mid: rare
+            for (int c = 1; c < RI_(RI_KC_CNT); ++c, g += KCW) {
                 const double* a = (T <= g[0]) ? g + 1 : g + 8;
                 lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
                 TdlnKc += a[1] + T * (a[2] + T * (2.0 * a[3] + T * (3.0 * a[4] + 4.0 * a[5] * T))) + a[6] * invT;
@@ -211,8 +254,8 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         }
 
         // ---- concentration products ----
-        const double cr0 = V[ri[RI_R0] * TS + s], cr1 = V[ri[RI_R1] * TS + s], cr2 = V[ri[RI_R2] * TS + s];
-        const double cp0 = V[ri[RI_P0] * TS + s], cp1 = V[ri[RI_P1] * TS + s], cp2 = V[ri[RI_P2] * TS + s];
+        const double cr0 = V[RI_(RI_R0) * TS + s], cr1 = V[RI_(RI_R1) * TS + s], cr2 = V[RI_(RI_R2) * TS + s];
+        const double cp0 = V[RI_(RI_P0) * TS + s], cp1 = V[RI_(RI_P1) * TS + s], cp2 = V[RI_(RI_P2) * TS + s];
         const double Rf = kf * (cr0 * cr1 * cr2);
         const double Rr = kr * (cp0 * cp1 * cp2);
         const double R = Rf - Rr;
@@ -221,30 +264,34 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         double c = 1.0, lead = 0.0, a_extra = 0.0, bM = 0.0, bcol = 0.0;
         if (fl & (F_THD | F_PDEP)) {
             double Mc = L.m;
-            for (int e = 0; e < ri[RI_EFF_CNT]; ++e)
-                Mc += M.eff_am1[ri[RI_EFF_PTR] + e] * V[M.eff_sp[ri[RI_EFF_PTR] + e] * TS + s];
+            const int necnt = RI_(RI_EFF_CNT);
+#pragma unroll
+            for (int e = 0; e < EFF_INL; ++e)      // inline slots: padding is (ONE, 0.0)
+                Mc += RD_(RDW + KCW + e) * V[RI_(RIW + e) * TS + s];
+            for (int e = EFF_INL; e < necnt; ++e)
+                Mc += M.eff_am1[RI_(RI_EFF_PTR) + e] * V[M.eff_sp[RI_(RI_EFF_PTR) + e] * TS + s];
             if (fl & F_THD) {
                 c = Mc;
                 lead = -c * R * invT;
                 if (fl & F_EFFTYPE) { bM = R; a_extra = c * R; }
             } else {
-                const int col = ri[RI_COLLIDER];
+                const int col = RI_(RI_COLLIDER);
                 const double conc_temp = (col >= 0) ? V[col * TS + s] : Mc;
-                const double e0T = rd[RD_E0] * invT;
-                const double k0kinf = exp(rd[RD_LNAR] + rd[RD_B0] * logT - e0T);
+                const double e0T = RD_(RD_E0) * invT;
+                const double k0kinf = exp(RD_(RD_LNAR) + RD_(RD_B0) * logT - e0T);
                 const double Pr = conc_temp * k0kinf;
                 const double i1Pr = 1.0 / (1.0 + Pr);
                 double F = 1.0, extra = 0.0, Xtroe = 0.0;
                 if (fl & F_TROE) {
                     // create_jacobian.py:1066-1111, 1240-1294
-                    const double ta = rd[RD_TRA];
-                    const double e3 = exp(-T / rd[RD_T3]), e1 = exp(-T / rd[RD_T1]);
+                    const double ta = RD_(RD_TRA);
+                    const double e3 = exp(-T / RD_(RD_T3)), e1 = exp(-T / RD_(RD_T1));
                     double Fcent = (1.0 - ta) * e3 + ta * e1;
-                    double dF = -((1.0 - ta) / rd[RD_T3]) * e3 - (ta / rd[RD_T1]) * e1;
+                    double dF = -((1.0 - ta) / RD_(RD_T3)) * e3 - (ta / RD_(RD_T1)) * e1;
                     if (fl & F_TROE4) {
-                        const double e2 = exp(-rd[RD_T2] * invT);
+                        const double e2 = exp(-RD_(RD_T2) * invT);
                         Fcent += e2;
-                        dF += rd[RD_T2] * invT * invT * e2;
+                        dF += RD_(RD_T2) * invT * invT * e2;
                     }
                     const double lF = log(fmax(Fcent, 1.0e-300));
                     const double lgF = lF * INV_LN10;
@@ -259,10 +306,10 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
                     const double iFc = 1.0 / Fcent;
                     Xtroe = lnF_AB * (INV_LN10 * Bt + (0.14 * INV_LN10) * At);
                     extra = (iFc * iden - lnF_AB * (-(0.67 * INV_LN10) * Bt + (1.1762 * INV_LN10) * At) * iFc) * dF -
-                            Xtroe * (rd[RD_B0] + e0T - 1.0) * invT;
+                            Xtroe * (RD_(RD_B0) + e0T - 1.0) * invT;
                 }
                 // get_pdep_dt (create_jacobian.py:1135-1191): beta difference as printed ('%.4e')
-                double dpr = (rd[RD_B04] + e0T - 1.0) * invT * i1Pr;
+                double dpr = (RD_(RD_B04) + e0T - 1.0) * invT * i1Pr;
                 double X;
                 if (fl & F_LOW) { c = F * Pr * i1Pr; X = i1Pr - Xtroe; }
                 else { c = F * i1Pr; X = -Pr * i1Pr - Xtroe; dpr = -Pr * dpr; }
@@ -277,7 +324,7 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         }
 
         // ---- d/dT (create_jacobian.py:1398-1529) ----
-        const double nr = rd[RD_NR], np_ = rd[RD_NP];
+        const double nr = RD_(RD_NR), np_ = RD_(RD_NP);
         double el = R * dlnk + Rf * (1.0 - nr);
         if (fl & F_REV) el -= Rr * ((1.0 - np_) - TdlnKc);
         const double theta = (fl & F_NO_DT) ? 0.0 : (lead + c * invT * el) * L.invrho;
@@ -287,28 +334,29 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
 
         // ---- sparse column values g (one per molecule slot) ----
         const double ckf = c * kf, ckr = c * kr;
-        int g = M.v.G + ri[RI_GBASE];
-        double gN = bM * rd[RD_ANM1];
+        int g = M.v.G + RI_(RI_GBASE);
+        double gN = bM * RD_(RD_ANM1);
         #define PJ_GSLOT(spidx, val)                                        \
             if ((spidx) != M.v.ONE) {                                       \
                 const double gv = (val);                                    \
                 V[g * TS + s] = gv; ++g;                                    \
                 if ((spidx) == last) gN += gv;                              \
             }
-        PJ_GSLOT(ri[RI_R0], ckf * (cr1 * cr2))
-        PJ_GSLOT(ri[RI_R1], ckf * (cr0 * cr2))
-        PJ_GSLOT(ri[RI_R2], ckf * (cr0 * cr1))
+        PJ_GSLOT(RI_(RI_R0), ckf * (cr1 * cr2))
+        PJ_GSLOT(RI_(RI_R1), ckf * (cr0 * cr2))
+        PJ_GSLOT(RI_(RI_R2), ckf * (cr0 * cr1))
         if (fl & F_REV) {
-            PJ_GSLOT(ri[RI_P0], -ckr * (cp1 * cp2))
-            PJ_GSLOT(ri[RI_P1], -ckr * (cp0 * cp2))
-            PJ_GSLOT(ri[RI_P2], -ckr * (cp0 * cp1))
+            PJ_GSLOT(RI_(RI_P0), -ckr * (cp1 * cp2))
+            PJ_GSLOT(RI_(RI_P1), -ckr * (cp0 * cp2))
+            PJ_GSLOT(RI_(RI_P2), -ckr * (cp0 * cp1))
         }
-        if (fl & F_COLLIDER) { PJ_GSLOT(ri[RI_COLLIDER], bcol) }
+        if (fl & F_COLLIDER) { PJ_GSLOT(RI_(RI_COLLIDER), bcol) }
         #undef PJ_GSLOT
         if (fl & F_EFFTYPE)      // (alpha_ij - 1) b_i for the enhanced-collider columns
-            for (int e = 0; e < ri[RI_EFF_CNT]; ++e) {
-                const int es = M.eff_sp[ri[RI_EFF_PTR] + e];
-                if (es != last) { V[g * TS + s] = M.eff_am1[ri[RI_EFF_PTR] + e] * bM; ++g; }
+            for (int e = 0; e < RI_(RI_EFF_CNT); ++e) {
+                const int es = (e < EFF_INL) ? RI_(RIW + e) : M.eff_sp[RI_(RI_EFF_PTR) + e];
+                const double am1 = (e < EFF_INL) ? RD_(RDW + KCW + e) : M.eff_am1[RI_(RI_EFF_PTR) + e];
+                if (es != last) { V[g * TS + s] = am1 * bM; ++g; }
             }
 
         const double q = c * R;
@@ -319,11 +367,13 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         V[(M.v.RQQ + i) * TS + s] = rp + gN;
 
         if (L.valid) {
-            if (B.fwd) B.fwd[ri[RI_ORIG] * B.o_ld + L.gs] = Rf;
-            if (B.rev && ri[RI_REV_IDX] >= 0) B.rev[ri[RI_REV_IDX] * B.o_ld + L.gs] = Rr;
-            if (B.pres_mod && ri[RI_PRES_IDX] >= 0) B.pres_mod[ri[RI_PRES_IDX] * B.o_ld + L.gs] = c;
+            if (B.fwd) B.fwd[RI_(RI_ORIG) * B.o_ld + L.gs] = Rf;
+            if (B.rev && RI_(RI_REV_IDX) >= 0) B.rev[RI_(RI_REV_IDX) * B.o_ld + L.gs] = Rr;
+            if (B.pres_mod && RI_(RI_PRES_IDX) >= 0) B.pres_mod[RI_(RI_PRES_IDX) * B.o_ld + L.gs] = c;
         }
     }
+#undef RI_
+#undef RD_
 }
 
 // ---------------------------------------------------------------- scatter
@@ -337,7 +387,7 @@ template <int TS>
 PJ_DEV void phase_zero_tile(const DevMech& M, double* V, int tid, int NT)
 {
     const int s = tid % TS, u = tid / TS, NU = NT / TS;
-    for (int t = u; t < M.v.NTILE + SC_COUNT; t += NU) V[(M.v.TB + t) * TS + s] = 0.0;
+    for (int t = u; t < M.v.NTILE; t += NU) V[(M.v.TB + t) * TS + s] = 0.0;
 }
 
 template <int TS>
@@ -348,15 +398,32 @@ PJ_DEV void phase_scatter(const DevMech& M, double* V, int tid, int NT, bool den
     const uint32_t* sc = M.sched + M.sched_off[w] + il;
     const int nr = dense_only ? M.sched_rounds_dense[w] : M.sched_rounds[w];
     double* T = V + M.v.TB * TS + s;
+    // The schedule guarantees that the 4 x IL targets of a group are distinct, so the
+    // four read-modify-writes of a lane are independent: one round trip to LDS per group.
+    // codes are prefetched two groups ahead (their L2 latency exceeds one group's work)
+    uint32_t c[4], c1[4], c2[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        c[x] = (nr > 0) ? sc[x * IL] : (4u << 29);
+        c1[x] = (nr > 4) ? sc[(4 + x) * IL] : (4u << 29);
+    }
     for (int r = 0; r < nr; r += 4) {
-        const uint32_t c0 = sc[(r + 0) * IL], c1 = sc[(r + 1) * IL], c2 = sc[(r + 2) * IL], c3 = sc[(r + 3) * IL];
-        const double v0 = V[(c0 & 8191u) * TS + s], v1 = V[(c1 & 8191u) * TS + s];
-        const double v2 = V[(c2 & 8191u) * TS + s], v3 = V[(c3 & 8191u) * TS + s];
-        const int n0 = (int)(c0 >> 29) - 4, n1 = (int)(c1 >> 29) - 4, n2 = (int)(c2 >> 29) - 4, n3 = (int)(c3 >> 29) - 4;
-        if (n0) T[((c0 >> 13) & 65535u) * TS] += (double)n0 * v0;
-        if (n1) T[((c1 >> 13) & 65535u) * TS] += (double)n1 * v1;
-        if (n2) T[((c2 >> 13) & 65535u) * TS] += (double)n2 * v2;
-        if (n3) T[((c3 >> 13) & 65535u) * TS] += (double)n3 * v3;
+        const bool more = r + 8 < nr;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) c2[x] = more ? sc[(r + 8 + x) * IL] : (4u << 29);
+        double v[4], t[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            v[x] = V[(c[x] & 8191u) * TS + s];
+            t[x] = T[((c[x] >> 13) & 65535u) * TS];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int nu = (int)(c[x] >> 29) - 4;
+            if (nu) T[((c[x] >> 13) & 65535u) * TS] = t[x] + (double)nu * v[x];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { c[x] = c1[x]; c1[x] = c2[x]; }
     }
 }
 
@@ -364,47 +431,59 @@ PJ_DEV void phase_scatter(const DevMech& M, double* V, int tid, int NT, bool den
 template <int TS>
 PJ_DEV void phase_fin1(const DevMech& M, double* V, int tid, int NT)
 {
-    const int s = tid % TS, u = tid / TS;
-    if (u == 0) {
-        for (int q = 0; q < M.nfin; ++q)
-            V[(M.v.TB + M.fin_tgt[q]) * TS + s] += V[(M.v.TB + M.fin_part[q]) * TS + s];
+    const int s = tid % TS, u = tid / TS, NU = NT / TS;
+    double* T = V + M.v.TB * TS + s;
+    // one item lane per split target; its partials sit in consecutive slots
+    for (int q = u; q < M.nfin; q += NU) {
+        const int t = M.fin_tgt[q], p0 = M.fin_part[q], cnt = M.fin_cnt[q];
+        double acc = T[t * TS];
+#pragma unroll 4
+        for (int z = 0; z < cnt; ++z) acc += T[(p0 + z) * TS];
+        T[t * TS] = acc;
     }
 }
 
 // per-state scalars H = sum h_k W_k omega_k, HP, HQ (same with P_k, Q_k), SCP = sum omega_k W_k cp_k,
-// SJT = sum h_k W_k (sum_i nu_ki theta_i); species rates / dydt outputs (rate_subs.py:2171-2335)
+// SJT = sum h_k W_k (sum_i nu_ki theta_i): products per species (fin2a), then five
+// row sums (fin2b); species rates / dydt outputs (rate_subs.py:2171-2335)
 template <int TS>
-PJ_DEV void phase_fin2(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
+PJ_DEV void phase_fin2a(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
 {
     const int s = tid % TS, u = tid / TS, NU = NT / TS;
     const int nsp = M.nsp, last = nsp - 1;
     const double* T = V + M.v.TB * TS + s;
-    for (int r = u; r < SC_COUNT; r += NU) {
-        double acc = 0.0;
-        for (int k = 0; k < nsp; ++k) {
-            const double hW = V[(M.v.HW + k) * TS + s];
-            double x;
-            if (r == SC_H) x = hW * T[(M.v.T_OM + k) * TS];
-            else if (r == SC_HP) x = hW * T[(M.v.T_P + k) * TS];
-            else if (r == SC_HQ) x = hW * T[(M.v.T_Q + k) * TS];
-            else if (r == SC_SCP) x = T[(M.v.T_OM + k) * TS] * M.sp[k * SPW + 1] * V[(M.v.CP + k) * TS + s];
-            else {
-                // reference quirk (create_jacobian.py:2786-2818): the last species contributes
-                // only the d/dT of its last reaction unless sum_last is set
-                const double jt = (k == last && !M.sum_last) ? T[M.v.T_JTQ * TS] : T[(M.v.T_JT + k) * TS];
-                x = hW * jt;
-            }
-            acc += x;
+    const double* KC = lds_kc<TS>(M, V);
+    for (int k = u; k < nsp; k += NU) {
+        const double hW = V[(M.v.HW + k) * TS + s];
+        const double om = T[(M.v.T_OM + k) * TS];
+        // reference quirk (create_jacobian.py:2786-2818): the last species contributes only
+        // the d/dT of its last reaction unless sum_last is set
+        const double jt = (k == last && !M.sum_last) ? T[M.v.T_JTQ * TS] : T[(M.v.T_JT + k) * TS];
+        const double Wk = KC[nsp + k];
+        V[(M.v.X + SC_H * nsp + k) * TS + s] = hW * om;
+        V[(M.v.X + SC_HP * nsp + k) * TS + s] = hW * T[(M.v.T_P + k) * TS];
+        V[(M.v.X + SC_HQ * nsp + k) * TS + s] = hW * T[(M.v.T_Q + k) * TS];
+        V[(M.v.X + SC_SCP * nsp + k) * TS + s] = om * Wk * V[(M.v.CP + k) * TS + s];
+        V[(M.v.X + SC_SJT * nsp + k) * TS + s] = hW * jt;
+        if (L.valid) {
+            if (B.spec_rates) B.spec_rates[k * B.o_ld + L.gs] = om;
+            if (B.dy && k < last) B.dy[(k + 1) * B.o_ld + L.gs] = om * Wk * L.invrho;
         }
+    }
+}
+
+template <int TS>
+PJ_DEV void phase_fin2b(const DevMech& M, const Batch& B, double* V, int tid, int NT, const Lane& L)
+{
+    const int s = tid % TS, u = tid / TS, NU = NT / TS;
+    const int nsp = M.nsp;
+    for (int r = u; r < SC_COUNT; r += NU) {
+        const double* X = V + (M.v.X + r * nsp) * TS + s;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < nsp; ++k) acc += X[k * TS];
         V[(M.v.SC + r) * TS + s] = acc;
         if (r == SC_H && B.dy && L.valid) B.dy[L.gs] = -acc / (L.rho * L.cpavg);
-    }
-    if (L.valid && (B.spec_rates || B.dy)) {
-        for (int k = u; k < nsp; k += NU) {
-            const double om = T[(M.v.T_OM + k) * TS];
-            if (B.spec_rates) B.spec_rates[k * B.o_ld + L.gs] = om;
-            if (B.dy && k < last) B.dy[(k + 1) * B.o_ld + L.gs] = om * M.sp[k * SPW + 1] * L.invrho;
-        }
     }
 }
 
@@ -417,20 +496,17 @@ PJ_DEV void phase_out_block(const DevMech& M, const Batch& B, double* V, int tid
     const int s = tid % TS, u = tid / TS, NU = NT / TS;
     const int nsp = M.nsp;
     const double* T = V + M.v.TB * TS + s;
+    const double* KC = lds_kc<TS>(M, V);
+#pragma unroll 4
     for (int e = u; e < nsp * nsp; e += NU) {
         const int col = e / nsp, row = e - col * nsp;
-        if (row == 0) continue;                       // energy row: phase_out_energy
-        const int k = row - 1;
-        double val;
-        if (col == 0) {
-            val = M.sp[k * SPW + 1] * T[(M.v.T_JT + k) * TS];
-        } else {
-            const int j = col - 1;
-            const double* spj = M.sp + j * SPW;
-            val = (M.sp[k * SPW + 1] * spj[0]) *
-                  (T[(M.v.T_P + k) * TS] - spj[3] * T[(M.v.T_Q + k) * TS] + T[(M.v.T_S + k + nsp * j) * TS]);
-        }
-        if (L.valid) B.jac[e * B.j_si + L.gs * B.j_ss] = val;
+        const int k = row > 0 ? row - 1 : 0, j = col > 0 ? col - 1 : 0;
+        const double Wk = KC[nsp + k];
+        // d/dT column: W_k sum_i nu_ki theta_i ; species block: (W_k/W_j)(P_k - w_j Q_k + S_kj)
+        const double blk = (Wk * KC[j]) * (T[(M.v.T_P + k) * TS] - KC[2 * nsp + j] * T[(M.v.T_Q + k) * TS] +
+                                           T[(M.v.T_S + k + nsp * j) * TS]);
+        const double val = (col == 0) ? Wk * T[(M.v.T_JT + k) * TS] : blk;
+        if (row > 0 && L.valid) B.jac[e * B.j_si + L.gs * B.j_ss] = val;   // row 0: phase_out_energy
     }
 }
 
@@ -452,9 +528,11 @@ PJ_DEV void phase_out_energy(const DevMech& M, const Batch& B, double* V, int ti
                   (L.rho * L.cpavg);
         } else {
             const int j = col - 1;
-            const double* spj = M.sp + j * SPW;
+            const double* KC = lds_kc<TS>(M, V);
+            const double spj[4] = {KC[j], 0.0, 0.0, KC[2 * nsp + j]};
             double hs = 0.0;
             const double* Sj = T + (M.v.T_S + nsp * j) * TS;
+#pragma unroll 8
             for (int k = 0; k < nsp; ++k) hs += V[(M.v.HW + k) * TS + s] * Sj[k * TS];
             const double tot = V[(M.v.SC + SC_HP) * TS + s] - spj[3] * V[(M.v.SC + SC_HQ) * TS + s] + hs;
             val = -tot * spj[0] * icp +

@@ -233,7 +233,8 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
     v.T_PART = v.T_JTQ + 1;
     v.NTILE = v.T_PART;
     v.SC = v.TB + v.NTILE;
-    v.NSLOT = v.SC + SC_COUNT;
+    v.X = v.SC + SC_COUNT;
+    v.NSLOT = v.X + SC_COUNT * nsp;
 
     // ---- P3: per species gather (device reaction order) ----
     p.sp_ptr.assign(nsp + 1, 0);
@@ -270,6 +271,25 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
             }
         }
     }
+    // ---- field-major reaction tables ----
+    p.nrp = (nrxn + 63) / 64 * 64;
+    p.rti.assign((size_t)(RIW + EFF_INL) * p.nrp, 0);
+    p.rtd.assign((size_t)(RDW + KCW + EFF_INL) * p.nrp, 0.0);
+    for (int d = 0; d < p.nrp; ++d) {
+        const int src = d < nrxn ? d : 0;        // padding rows repeat reaction 0 (never stored)
+        const int32_t* ri = &p.ri[(size_t)src * RIW];
+        const double* rd = &p.rd[(size_t)src * RDW];
+        for (int f = 0; f < RIW; ++f) p.rti[(size_t)f * p.nrp + d] = ri[f];
+        for (int f = 0; f < RDW; ++f) p.rtd[(size_t)f * p.nrp + d] = rd[f];
+        if (ri[RI_KC_CNT] > 0)
+            for (int f = 0; f < KCW; ++f) p.rtd[(size_t)(RDW + f) * p.nrp + d] = p.kcg[(size_t)ri[RI_KC_PTR] * KCW + f];
+        for (int e = 0; e < EFF_INL; ++e) {
+            const bool has = e < ri[RI_EFF_CNT];
+            p.rti[(size_t)(RIW + e) * p.nrp + d] = has ? p.eff_sp[ri[RI_EFF_PTR] + e] : ONE;
+            p.rtd[(size_t)(RDW + KCW + e) * p.nrp + d] = has ? p.eff_am1[ri[RI_EFF_PTR] + e] : 0.0;
+        }
+    }
+
     // ---- scatter-phase terms ----
     for (int d = 0; d < nrxn; ++d) {
         const int32_t* ri = &p.ri[(size_t)d * RIW];
@@ -323,16 +343,20 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
 bool build_schedule(Programs& p, int NW, int IL, Schedule& out)
 {
     if (NW < 1 || NW > 16 || IL < 1 || IL > 64) { p.error = "bad schedule geometry"; return false; }
+    constexpr int GW = 4;            // rounds applied together by the kernel (independent read-modify-writes)
     VMap& v = p.vm;
     out = Schedule();
     out.NW = NW; out.IL = IL;
-    // terms per target
     const int nt0 = v.T_PART;
     std::vector<std::vector<int>> by_tgt(nt0);
     for (int c = 0; c < (int)p.contribs.size(); ++c) by_tgt[p.contribs[c].tgt].push_back(c);
-    const long total = (long)p.contribs.size();
-    const int R = (int)std::max<long>(8, (total + (long)NW * IL - 1) / ((long)NW * IL));   // balanced rounds
-    // split hub targets of the dense vectors into partial accumulators of <= R terms
+    // A target may appear once per GROUP of GW rounds (so the GW updates of a lane and of
+    // its neighbours never alias).  Targets with more terms than a balanced wavefront has
+    // groups are split into partial accumulators that phase_fin1 adds up afterwards.
+    long nd = 0, ns = 0;
+    for (auto& c : p.contribs) (c.dense ? nd : ns)++;
+    const int Rd = (int)std::max<long>(4, (nd + (long)NW * IL * GW - 1) / ((long)NW * IL * GW));
+    const int Rs = (int)std::max<long>(4, (ns + (long)NW * IL * GW - 1) / ((long)NW * IL * GW));
     struct Tgt { int slot; std::vector<int> terms; bool dense; };
     std::vector<Tgt> tg;
     int nextp = v.T_PART;
@@ -340,18 +364,21 @@ bool build_schedule(Programs& p, int NW, int IL, Schedule& out)
         auto& l = by_tgt[t];
         if (l.empty()) continue;
         const bool dense = p.contribs[l[0]].dense;
-        if ((int)l.size() <= R || !dense) { tg.push_back({t, l, dense}); continue; }
+        const int R = dense ? Rd : Rs;
+        if ((int)l.size() <= R) { tg.push_back({t, l, dense}); continue; }
         const int parts = ((int)l.size() + R - 1) / R;
         for (int q = 0; q < parts; ++q) {
-            Tgt x{q == 0 ? t : nextp, {}, true};
+            Tgt x{q == 0 ? t : nextp, {}, dense};
             for (int e = q; e < (int)l.size(); e += parts) x.terms.push_back(l[e]);
-            if (q > 0) { out.fin_tgt.push_back(t); out.fin_part.push_back(nextp); ++nextp; }
+            if (q == 1) { out.fin_tgt.push_back(t); out.fin_part.push_back(nextp); out.fin_cnt.push_back(parts - 1); }
+            if (q > 0) ++nextp;
             tg.push_back(std::move(x));
         }
     }
     v.NTILE = nextp;
     v.SC = v.TB + v.NTILE;
-    v.NSLOT = v.SC + SC_COUNT;
+    v.X = v.SC + SC_COUNT;
+    v.NSLOT = v.X + SC_COUNT * p.nsp;
     if (v.NTILE >= 65536 || v.NV >= 8192) { p.error = "mechanism too large for the scatter encoding"; return false; }
     // ownership: heaviest target to the least loaded wavefront; dense and sparse balanced separately
     std::vector<std::vector<int>> own_d(NW), own_s(NW);
@@ -366,9 +393,10 @@ bool build_schedule(Programs& p, int NW, int IL, Schedule& out)
             load[w] += (long)tg[i].terms.size();
         }
     }
-    // rounds: up to IL distinct targets per round, most remaining terms first
+    // groups: up to GW*IL distinct targets per group (most remaining terms first), laid out as
+    // GW rounds of IL codes
     auto emit = [&](const std::vector<int>& owned, std::vector<uint32_t>& codes) {
-        std::vector<std::pair<int, int>> rem;      // (remaining, index into owned)
+        std::vector<std::pair<int, int>> rem;
         std::vector<size_t> pos(owned.size(), 0);
         int rounds = 0;
         for (;;) {
@@ -378,20 +406,20 @@ bool build_schedule(Programs& p, int NW, int IL, Schedule& out)
                 if (left > 0) rem.push_back({left, i});
             }
             if (rem.empty()) break;
-            std::partial_sort(rem.begin(), rem.begin() + std::min<size_t>(IL, rem.size()), rem.end(),
+            const size_t take = std::min<size_t>((size_t)GW * IL, rem.size());
+            std::partial_sort(rem.begin(), rem.begin() + take, rem.end(),
                               [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
-            for (int l = 0; l < IL; ++l) {
+            for (int l = 0; l < GW * IL; ++l) {
                 uint32_t code = 4u << 29;        // no-op
-                if (l < (int)rem.size()) {
+                if (l < (int)take) {
                     const int i = rem[l].second;
                     const Contrib& c = p.contribs[tg[owned[i]].terms[pos[i]++]];
                     code = (uint32_t)c.src | ((uint32_t)tg[owned[i]].slot << 13) | ((uint32_t)(c.nu + 4) << 29);
                 }
                 codes.push_back(code);
             }
-            ++rounds;
+            rounds += GW;
         }
-        while (rounds % 4) { for (int l = 0; l < IL; ++l) codes.push_back(4u << 29); ++rounds; }
         return rounds;
     };
     for (int w = 0; w < NW; ++w) {

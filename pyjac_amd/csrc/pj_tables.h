@@ -38,6 +38,7 @@ enum { RI_FLAGS, RI_R0, RI_R1, RI_R2, RI_P0, RI_P1, RI_P2, RI_EFF_PTR, RI_EFF_CN
        RI_NET_PTR, RI_NET_CNT, RI_ORIG, RI_REV_IDX, RI_PRES_IDX };
 enum { RD_LNA, RD_B, RD_TA, RD_SGN, RD_NR, RD_NP, RD_LNPREF, RD_LNAR, RD_B0, RD_E0,
        RD_B04, RD_TRA, RD_T3, RD_T1, RD_T2, RD_ANM1 };
+constexpr int EFF_INL = 8;  // enhanced colliders held inline in the field-major tables
 constexpr int PLW = 5;    // plog row: P ('%.4e'), lnP, lnA, b, Ta
 constexpr int KCW = 15;   // kc group: tmid, lo[7], hi[7]
 
@@ -57,6 +58,7 @@ struct VMap {
     int TB = 0, T_OM = 0, T_JT = 0, T_P = 0, T_Q = 0, T_S = 0, T_JTQ = 0, T_PART = 0;
     int NTILE = 0;                                           // incl. partials (set by build_schedule)
     int SC = 0;                                              // 5 per-state scalars after the tile
+    int X = 0;                                               // [5][nsp] products feeding those scalars
     int NSLOT = 0;                                           // total slots per state
 };
 enum { SC_H, SC_HP, SC_HQ, SC_SCP, SC_SJT, SC_COUNT };
@@ -72,7 +74,8 @@ struct Schedule {
     int NW = 0, IL = 0;
     std::vector<uint32_t> codes;       // [wave][round][il]: src | tgt << 13 | (nu + 4) << 29
     int off[16] = {0}, rounds[16] = {0}, rounds_dense[16] = {0};
-    std::vector<int32_t> fin_tgt, fin_part;   // partial slot -> final target (added after the scatter)
+    // split targets: final slot, first partial slot, number of partials (consecutive slots)
+    std::vector<int32_t> fin_tgt, fin_part, fin_cnt;
 };
 
 struct Programs {
@@ -99,6 +102,13 @@ struct Programs {
     int p4en = 0, p4c = 0, p3en = 0, p3c = 0;
     int lastq_rxn = -1;            // device index of the F_LASTQ reaction
     std::vector<Contrib> contribs;
+    // field-major ("SoA") copies of the reaction records for the table-driven kernel:
+    // consecutive item lanes hold consecutive reactions, so rti[f*nrp + i] / rtd[f*nrp + i]
+    // are coalesced.  rtd also carries K_c group 0 (KCW fields) and up to EFF_INL
+    // enhanced colliders per reaction inline (rti: species or ONE, rtd: alpha - 1).
+    int nrp = 0;                   // nrxn padded to a multiple of 64
+    std::vector<int32_t> rti;      // [(RIW + EFF_INL) * nrp]
+    std::vector<double> rtd;       // [(RDW + KCW + EFF_INL) * nrp]
     std::string error;
 };
 

@@ -10,6 +10,7 @@
 struct uint2 { unsigned x, y; };
 using std::exp; using std::log; using std::fmax;
 #define PJ_DEV static inline
+#define PJ_LDS_ADD(ptr, v) (*(ptr) += (v))
 #include "../../pyjac_amd/csrc/pj_kernel.h"
 #include "../../pyjac_amd/csrc/pj_tables.cpp"
 
@@ -18,7 +19,8 @@ using namespace pj;
 template <int TS>
 static void run_tiles(const DevMech& M, const Batch& B, int NT, int want_jac)
 {
-    std::vector<double> V((size_t)M.v.NSLOT * TS);
+    std::vector<double> V((size_t)M.v.NSLOT * TS + 3 * M.nsp);
+    for (int tid = 0; tid < NT; ++tid) stage_consts<TS>(M, V.data(), tid, NT);
     std::vector<Lane> L(NT);
     const long ntiles = (B.n + TS - 1) / TS;
     for (long t = 0; t < ntiles; ++t) {
@@ -29,7 +31,8 @@ static void run_tiles(const DevMech& M, const Batch& B, int NT, int want_jac)
         for (int tid = 0; tid < NT; ++tid) phase2<TS>(M, B, V.data(), tid, NT, L[tid]);
         for (int tid = 0; tid < NT; ++tid) phase_scatter<TS>(M, V.data(), tid, NT, !want_jac);
         for (int tid = 0; tid < NT; ++tid) phase_fin1<TS>(M, V.data(), tid, NT);
-        for (int tid = 0; tid < NT; ++tid) phase_fin2<TS>(M, B, V.data(), tid, NT, L[tid]);
+        for (int tid = 0; tid < NT; ++tid) phase_fin2a<TS>(M, B, V.data(), tid, NT, L[tid]);
+        for (int tid = 0; tid < NT; ++tid) phase_fin2b<TS>(M, B, V.data(), tid, NT, L[tid]);
         if (want_jac) {
             for (int tid = 0; tid < NT; ++tid) phase_out_energy<TS>(M, B, V.data(), tid, NT, L[tid]);
             for (int tid = 0; tid < NT; ++tid) phase_out_block<TS>(M, B, V.data(), tid, NT, L[tid]);
@@ -48,6 +51,7 @@ extern "C" int emu_run(const int32_t* I, long nI, const double* D, long nD, long
     M.nsp = P.nsp; M.nrxn = P.nrxn; M.ng = P.ng; M.ne = P.ne; M.nv = P.vm.NV;
     M.lastq_rxn = P.lastq_rxn; M.sum_last = sum_last; M.v = P.vm;
     M.sp = P.sp.data(); M.ri = P.ri.data(); M.rd = P.rd.data();
+    M.rti = P.rti.data(); M.rtd = P.rtd.data(); M.nrp = P.nrp;
     M.eff_sp = P.eff_sp.data(); M.eff_am1 = P.eff_am1.data(); M.kcg = P.kcg.data();
     M.plog = P.plog.data(); M.net_sp = P.net_sp.data(); M.net_nu = P.net_nu.data();
     M.sp_ptr = P.sp_ptr.data(); M.sp_rxn = P.sp_rxn.data(); M.sp_nu = P.sp_nu.data();
@@ -56,7 +60,7 @@ extern "C" int emu_run(const int32_t* I, long nI, const double* D, long nD, long
     M.v = P.vm; M.nv = P.vm.NV;
     M.sched = S.codes.data();
     for (int w = 0; w < 16; ++w) { M.sched_off[w] = S.off[w]; M.sched_rounds[w] = S.rounds[w]; M.sched_rounds_dense[w] = S.rounds_dense[w]; }
-    M.fin_tgt = S.fin_tgt.data(); M.fin_part = S.fin_part.data(); M.nfin = (int)S.fin_tgt.size();
+    M.fin_tgt = S.fin_tgt.data(); M.fin_part = S.fin_part.data(); M.fin_cnt = S.fin_cnt.data(); M.nfin = (int)S.fin_tgt.size();
     Batch B;
     B.n = n; B.pres = pres; B.y = y_soa; B.y_si = n; B.y_ss = 1;
     B.jac = jac;
