@@ -63,8 +63,11 @@ PJ_DEV void phase0c(const DevMech& M, const Batch& B, const double* cin, const d
     if (u == 0) V[M.v.ONE * TS + s] = 1.0;
 }
 
+#ifndef PJ_KEVAL_WAVES
+#define PJ_KEVAL_WAVES 3      // waves per SIMD the register allocation is bounded for (<= 168 VGPRs)
+#endif
 template <int TS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, PJ_KEVAL_WAVES)
 k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, double* aux)
 {
     extern __shared__ __attribute__((aligned(16))) double V[];
@@ -185,7 +188,9 @@ struct pj_mech {
     int device = -1;
     DevBuf<double> sp, rd, rtd, eff_am1, kcg, plog, net_nu, sp_nu;
     DevBuf<int32_t> ri, rti, eff_sp, net_sp, sp_ptr, sp_rxn, fin_tgt, fin_part, fin_cnt;
-    DevBuf<uint32_t> sched;
+    DevBuf<uint32_t> sched, ecol;
+    DevBuf<uint16_t> smap;
+    DevBuf<int32_t> ecol_ptr;
     Schedule S;                // host copy; rebuilt when the launch geometry changes
     int sched_nw = 0, sched_il = 0;
     bool sched_on_device = false;
@@ -221,12 +226,14 @@ int ensure_device(pj_mech* m)
     Programs& P = m->P;
     HIPCHK(m->sp.upload(P.sp)); HIPCHK(m->ri.upload(P.ri)); HIPCHK(m->rd.upload(P.rd));
     HIPCHK(m->rti.upload(P.rti)); HIPCHK(m->rtd.upload(P.rtd));
+    HIPCHK(m->smap.upload(P.smap)); HIPCHK(m->ecol_ptr.upload(P.ecol_ptr)); HIPCHK(m->ecol.upload(P.ecol));
     HIPCHK(m->eff_sp.upload(P.eff_sp)); HIPCHK(m->eff_am1.upload(P.eff_am1));
     HIPCHK(m->kcg.upload(P.kcg)); HIPCHK(m->plog.upload(P.plog));
     HIPCHK(m->net_sp.upload(P.net_sp)); HIPCHK(m->net_nu.upload(P.net_nu));
     HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
     DevMech& M = m->M;
-    M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.rti = m->rti.p; M.rtd = m->rtd.p; M.nrp = P.nrp; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
+    M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.rti = m->rti.p; M.rtd = m->rtd.p; M.nrp = P.nrp;
+    M.smap = m->smap.p; M.ecol_ptr = m->ecol_ptr.p; M.ecol = m->ecol.p; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
     M.kcg = m->kcg.p; M.plog = m->plog.p; M.net_sp = m->net_sp.p; M.net_nu = m->net_nu.p;
     M.sp_ptr = m->sp_ptr.p; M.sp_rxn = m->sp_rxn.p; M.sp_nu = m->sp_nu.p;
     m->on_device = true;
@@ -398,7 +405,8 @@ void pj_mech_destroy(pj_mech* m)
 {
     if (!m) return;
     if (m->on_device) {
-        m->sp.release(); m->rd.release(); m->rtd.release(); m->rti.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release();
+        m->sp.release(); m->rd.release(); m->rtd.release(); m->rti.release();
+        m->smap.release(); m->ecol_ptr.release(); m->ecol.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release();
         m->net_nu.release(); m->sp_nu.release(); m->sched.release(); m->ri.release(); m->eff_sp.release();
         m->fin_tgt.release(); m->fin_part.release(); m->fin_cnt.release();
         m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release();

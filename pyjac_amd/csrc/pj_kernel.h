@@ -40,6 +40,9 @@ struct DevMech {
     const double* sp;
     const int32_t* ri;
     const double* rd;
+    const uint16_t* smap;      // sparse-block slot map and per-column non-zero rows (pj_tables.h)
+    const int32_t* ecol_ptr;
+    const uint32_t* ecol;
     const int32_t* rti;        // field-major reaction tables (pj_tables.h)
     const double* rtd;
     int nrp;
@@ -502,9 +505,10 @@ PJ_DEV void phase_out_block(const DevMech& M, const Batch& B, double* V, int tid
         const int col = e / nsp, row = e - col * nsp;
         const int k = row > 0 ? row - 1 : 0, j = col > 0 ? col - 1 : 0;
         const double Wk = KC[nsp + k];
+        const unsigned si = M.smap[k + nsp * j];
+        const double Skj = (si != 0xFFFFu) ? T[(M.v.T_S + (int)si) * TS] : 0.0;
         // d/dT column: W_k sum_i nu_ki theta_i ; species block: (W_k/W_j)(P_k - w_j Q_k + S_kj)
-        const double blk = (Wk * KC[j]) * (T[(M.v.T_P + k) * TS] - KC[2 * nsp + j] * T[(M.v.T_Q + k) * TS] +
-                                           T[(M.v.T_S + k + nsp * j) * TS]);
+        const double blk = (Wk * KC[j]) * (T[(M.v.T_P + k) * TS] - KC[2 * nsp + j] * T[(M.v.T_Q + k) * TS] + Skj);
         const double val = (col == 0) ? Wk * T[(M.v.T_JT + k) * TS] : blk;
         if (row > 0 && L.valid) B.jac[e * B.j_si + L.gs * B.j_ss] = val;   // row 0: phase_out_energy
     }
@@ -531,9 +535,11 @@ PJ_DEV void phase_out_energy(const DevMech& M, const Batch& B, double* V, int ti
             const double* KC = lds_kc<TS>(M, V);
             const double spj[4] = {KC[j], 0.0, 0.0, KC[2 * nsp + j]};
             double hs = 0.0;
-            const double* Sj = T + (M.v.T_S + nsp * j) * TS;
-#pragma unroll 8
-            for (int k = 0; k < nsp; ++k) hs += V[(M.v.HW + k) * TS + s] * Sj[k * TS];
+#pragma unroll 4
+            for (int q = M.ecol_ptr[j]; q < M.ecol_ptr[j + 1]; ++q) {
+                const uint32_t ks = M.ecol[q];
+                hs += V[(M.v.HW + (int)(ks >> 16)) * TS + s] * T[(M.v.T_S + (int)(ks & 0xFFFFu)) * TS];
+            }
             const double tot = V[(M.v.SC + SC_HP) * TS + s] - spj[3] * V[(M.v.SC + SC_HQ) * TS + s] + hs;
             val = -tot * spj[0] * icp +
                   (V[(M.v.CP + j) * TS + s] - V[(M.v.CP + last) * TS + s]) * H * L.invrho * icp * icp;

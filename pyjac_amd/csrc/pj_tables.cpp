@@ -312,6 +312,35 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         }
     }
 
+    // ---- compact the sparse block: slots only for structurally non-zero S_kj ----
+    {
+        const int full = nsp * (nsp - 1);
+        std::vector<char> used(full, 0);
+        for (auto& c : p.contribs) if (!c.dense) used[c.tgt - v.T_S] = 1;
+        p.smap.assign(full, 0xFFFF);
+        p.ecol_ptr.assign(nsp, 0);
+        int n = 0;
+        for (int j = 0; j < nsp - 1; ++j) {
+            for (int k = 0; k < nsp; ++k)
+                if (used[k + nsp * j]) {
+                    p.smap[k + nsp * j] = (uint16_t)n;
+                    p.ecol.push_back(((uint32_t)k << 16) | (uint32_t)n);
+                    ++n;
+                }
+            p.ecol_ptr[j + 1] = (int)p.ecol.size();
+        }
+        if (n >= 0xFFFF) { p.error = "sparse block too large"; return false; }
+        p.nnz = n;
+        for (auto& c : p.contribs) if (!c.dense) c.tgt = v.T_S + p.smap[c.tgt - v.T_S];
+        v.T_JTQ = v.T_S + n;
+        for (auto& c : p.contribs) if (c.dense && c.tgt == v.T_S + full) c.tgt = v.T_JTQ;
+        v.T_PART = v.T_JTQ + 1;
+        v.NTILE = v.T_PART;
+        v.SC = v.TB + v.NTILE;
+        v.X = v.SC + SC_COUNT;
+        v.NSLOT = v.X + SC_COUNT * nsp;
+    }
+
     auto pack = [&](const std::vector<std::vector<uint16_t>>& lists, uint16_t pad, int* en_off, int* c_off) -> bool {
         *en_off = (int)p.prog.size();
         p.prog.resize(p.prog.size() + lists.size());

@@ -51,7 +51,8 @@ struct VMap {
     int NV = 0;                                              // slots written by phases 0-2
     // accumulation tile (targets of the scatter phase), slot = TB + target:
     //   T_OM + k, T_JT + k, T_P + k, T_Q + k   dense vectors (omega_k, sum nu theta, P_k, Q_k)
-    //   T_S + k + nsp*j                        sparse block S_kj (k < nsp incl. last species, j < nsp-1)
+    //   T_S + smap[k + nsp*j]                  sparse block S_kj (k < nsp incl. last species, j < nsp-1):
+    //                                          only structurally non-zero entries own a slot
     //   T_JTQ                                  d/dT of the last species from the one reaction the
     //                                          reference keeps (create_jacobian.py:2786-2818)
     //   T_PART ...                             partial accumulators of split hub targets
@@ -106,6 +107,12 @@ struct Programs {
     // consecutive item lanes hold consecutive reactions, so rti[f*nrp + i] / rtd[f*nrp + i]
     // are coalesced.  rtd also carries K_c group 0 (KCW fields) and up to EFF_INL
     // enhanced colliders per reaction inline (rti: species or ONE, rtd: alpha - 1).
+    // sparse-block slot map: smap[k + nsp*j] = slot relative to T_S or 0xFFFF (structural zero);
+    // per column j the non-zero rows as (k << 16 | slot), CSR by column (energy-row sums)
+    std::vector<uint16_t> smap;
+    std::vector<int32_t> ecol_ptr;
+    std::vector<uint32_t> ecol;
+    int nnz = 0;
     int nrp = 0;                   // nrxn padded to a multiple of 64
     std::vector<int32_t> rti;      // [(RIW + EFF_INL) * nrp]
     std::vector<double> rtd;       // [(RDW + KCW + EFF_INL) * nrp]

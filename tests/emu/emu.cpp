@@ -52,6 +52,7 @@ extern "C" int emu_run(const int32_t* I, long nI, const double* D, long nD, long
     M.lastq_rxn = P.lastq_rxn; M.sum_last = sum_last; M.v = P.vm;
     M.sp = P.sp.data(); M.ri = P.ri.data(); M.rd = P.rd.data();
     M.rti = P.rti.data(); M.rtd = P.rtd.data(); M.nrp = P.nrp;
+    M.smap = P.smap.data(); M.ecol_ptr = P.ecol_ptr.data(); M.ecol = P.ecol.data();
     M.eff_sp = P.eff_sp.data(); M.eff_am1 = P.eff_am1.data(); M.kcg = P.kcg.data();
     M.plog = P.plog.data(); M.net_sp = P.net_sp.data(); M.net_nu = P.net_nu.data();
     M.sp_ptr = P.sp_ptr.data(); M.sp_rxn = P.sp_rxn.data(); M.sp_nu = P.sp_nu.data();
