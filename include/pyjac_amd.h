@@ -93,6 +93,11 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
 int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
                       double* d_conc, double* d_fwd, double* d_rev, double* d_pres_mod,
                       double* d_spec_rates, double* d_dy, void* stream);
+/* Finite-difference Jacobian of dydt: the reference's comparison arm
+ * (pyjac/performance_tester/fd_jacob.c:10-113, fd_jacob.cu:23-96: first order, CVODE-style
+ * increment r_j = max(sqrt(eps)|y_j|, r0/ewt_j)); NSP+1 dydt launches.  y must be SoA. */
+int pj_eval_fd_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y,
+                            double* d_jac, int jac_layout, void* stream);
 /* Launch the Jacobian kernel `iters` times on `stream` bracketed by HIP events
  * recorded on that stream; *ms_per_launch receives the average. */
 int pj_time_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y,

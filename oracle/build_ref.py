@@ -60,6 +60,13 @@ def build_ref(mech_path: str, name: str, last_spec: str = None, force: bool = Fa
     for p in procs:
         if p.wait():
             raise RuntimeError('compile failed')
+    # the reference's finite-difference arm, compiled where it lies with its entry point renamed
+    fd_src = os.path.join(REF, 'pyjac', 'performance_tester', 'fd_jacob.c')
+    if os.path.exists(fd_src):
+        o = os.path.join(work, 'fd_jacob.c.o')
+        subprocess.check_call(['gcc', '-std=gnu99', '-O3', '-mtune=native', '-fPIC', '-include', 'string.h',
+                               '-Deval_jacob=fd_eval_jacob', '-I', work, '-c', fd_src, '-o', o])
+        objs.append(o)
     subprocess.check_call(['gcc', '-shared', '-fopenmp', '-o', out] + objs + ['-lm'])
     return out
 

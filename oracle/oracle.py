@@ -54,6 +54,7 @@ class Oracle:
         L.pjo_eval_spec_rates.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
         L.pjo_dydt.argtypes = [vp, d, d, _dp, _dp]
         L.pjo_eval_jacob.argtypes = [vp, d, d, _dp, _dp]
+        L.pjo_fd_jacob.argtypes = [vp, d, d, _dp, _dp]
         L.pjo_batch_jacob.argtypes = [vp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
         L.pjo_batch_dydt.argtypes = [vp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
 
@@ -87,6 +88,13 @@ class Oracle:
         jac = np.zeros(n * n)
         self.lib.pjo_eval_jacob(self.h, 0.0, pres, _p(y), _p(jac))
         return dict(conc=conc, fwd=fwd, rev=rev, pres_mod=pm, spec_rates=sr, dydt=dy, jac=jac)
+
+    def fd_jacob(self, pres: float, y: np.ndarray) -> np.ndarray:
+        """fd_jacob.c:10-113 on the oracle's dydt."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        jac = np.zeros(self.nsp * self.nsp)
+        self.lib.pjo_fd_jacob(self.h, 0.0, pres, _p(y), _p(jac))
+        return jac
 
     # ---- batch (state-major) ----
     def batch_jacob(self, pres: np.ndarray, y_aos: np.ndarray, nthreads: int = 0) -> np.ndarray:
@@ -127,6 +135,8 @@ class Reference:
         L.eval_spec_rates.argtypes = [_dp, _dp, _dp, _dp, _dp]
         L.dydt.argtypes = [d, d, _dp, _dp]
         L.eval_jacob.argtypes = [d, d, _dp, _dp]
+        if hasattr(L, 'fd_eval_jacob'):
+            L.fd_eval_jacob.argtypes = [d, d, _dp, _dp]
         L.ref_batch_jacob.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
         L.ref_batch_dydt.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
 
@@ -157,6 +167,13 @@ class Reference:
         jac = np.zeros(n * n)
         L.eval_jacob(0.0, pres, _p(y), _p(jac))
         return dict(conc=conc, fwd=fwd, rev=rev, pres_mod=pm, spec_rates=sr, dydt=dy, jac=jac)
+
+    def fd_jacob(self, pres: float, y: np.ndarray):
+        """The reference's own finite-difference arm (performance_tester/fd_jacob.c)."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        jac = np.zeros(self.nsp * self.nsp)
+        self.lib.fd_eval_jacob(0.0, pres, _p(y), _p(jac))
+        return jac
 
     def batch_jacob(self, pres, y_aos, nthreads: int = 0):
         num = pres.shape[0]

@@ -630,6 +630,34 @@ void pjo_eval_jacob(const pjo_mech *m, double t, double pres, const double *y, d
     free(buf);
 }
 
+/* Finite-difference Jacobian of dydt, pyjac/performance_tester/fd_jacob.c:10-113
+ * (FD_ORD 1, CVODE-style increment).  jac[NSP*NSP] column-major. */
+#include <float.h>
+void pjo_fd_jacob(const pjo_mech *m, double t, double pres, const double *cy, double *jac)
+{
+    const int n = m->nsp;
+    const double ATOL = 1e-15, RTOL = 1e-8;
+    double *y = (double *)malloc(sizeof(double) * 4 * n);
+    double *dy = y + n, *ewt = dy + n, *ftemp = ewt + n;
+    memcpy(y, cy, n * sizeof(double));
+    pjo_dydt(m, t, pres, y, dy);
+    for (int i = 0; i < n; ++i) ewt[i] = ATOL + (RTOL * fabs(y[i]));
+    const double srur = sqrt(DBL_EPSILON);
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) sum += (ewt[i] * dy[i]) * (ewt[i] * dy[i]);
+    const double fac = sqrt(sum / ((double)(n)));
+    const double r0 = 1000.0 * RTOL * DBL_EPSILON * ((double)(n)) * fac;
+    for (int j = 0; j < n; ++j) {
+        const double yj_orig = y[j];
+        const double r = fmax(srur * fabs(yj_orig), r0 / ewt[j]);
+        y[j] = yj_orig + r;
+        pjo_dydt(m, t, pres, y, ftemp);
+        for (int i = 0; i < n; ++i) jac[i + n * j] = (ftemp[i] - dy[i]) / r;
+        y[j] = yj_orig;
+    }
+    free(y);
+}
+
 /* ---- batch drivers (state-major AoS in/out; OpenMP over states) ----
  * Mirrors the reference speed test's protocol
  * (pyjac/performance_tester/tester.c.in:23-31): one parallel-for over states,

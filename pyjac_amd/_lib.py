@@ -43,6 +43,7 @@ SIGNATURES = {
                                             ctypes.c_int, _vp]),
     'pj_eval_rates_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_int,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pj_eval_fd_jacobian_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, _vp, ctypes.c_int, _vp]),
     'pj_time_jacobian_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_int, _vp,
                                             ctypes.c_int, _vp, ctypes.c_int, _dp]),
     'pj_init': (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -152,6 +152,46 @@ __global__ void k_spec_rates(DevMech M, long n, const double* fwd, const double*
     }
 }
 
+// ---- finite-difference Jacobian helpers (fd_jacob.c:56-111) ----
+__global__ void k_fd_setup(long n, int nsp, const double* y, const double* dy0, double* r)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const double ATOL = 1e-15, RTOL = 1e-8, EPS = 2.2204460492503131e-16;
+    double sum = 0.0;
+    for (int i = 0; i < nsp; ++i) {
+        const double ewt = ATOL + (RTOL * fabs(y[i * n + s]));
+        const double e = ewt * dy0[i * n + s];
+        sum += e * e;
+    }
+    const double fac = sqrt(sum / ((double)nsp));
+    const double r0 = 1000.0 * RTOL * EPS * ((double)nsp) * fac;
+    const double srur = sqrt(EPS);
+    for (int j = 0; j < nsp; ++j) {
+        const double yj = y[j * n + s];
+        const double ewt = ATOL + (RTOL * fabs(yj));
+        r[j * n + s] = fmax(srur * fabs(yj), r0 / ewt);
+    }
+}
+
+__global__ void k_fd_perturb(long n, int j, const double* y, const double* r, double* ytmp)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    if (j > 0) ytmp[(j - 1) * n + s] = y[(j - 1) * n + s];
+    ytmp[j * n + s] = y[j * n + s] + r[j * n + s];
+}
+
+__global__ void k_fd_col(long n, int nsp, int j, const double* dyj, const double* dy0, const double* r,
+                         double* jac, long j_si, long j_ss)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const double rj = r[j * n + s];
+    for (int i = 0; i < nsp; ++i)
+        jac[(long)(i + nsp * j) * j_si + s * j_ss] = (dyj[i * n + s] - dy0[i * n + s]) / rj;
+}
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -512,6 +552,39 @@ int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_
     B.conc = d_conc; B.fwd = d_fwd; B.rev = d_rev; B.pres_mod = d_pres_mod;
     B.spec_rates = d_spec_rates; B.dy = d_dy;
     return launch(m, B, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int pj_eval_fd_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, double* d_jac,
+                            int jac_layout, void* stream)
+{
+    if (!m || n < 0) return fail(PJ_EINVAL, "bad argument");
+    if (n == 0) return PJ_OK;
+    if (!d_pres || !d_y || !d_jac) return fail(PJ_EINVAL, "null device pointer");
+    int rc = ensure_device(m);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nsp = m->P.nsp, bytes = sizeof(double) * nsp * (size_t)n;
+    double* buf = nullptr;
+    hipError_t e = hipMalloc((void**)&buf, 4 * bytes);
+    if (e != hipSuccess) return fail(PJ_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    double *ytmp = buf, *dy0 = buf + nsp * n, *dyj = dy0 + nsp * n, *r = dyj + nsp * n;
+    long j_si, j_ss;
+    set_layout(n, (int)(nsp * nsp), jac_layout, &j_si, &j_ss);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    rc = pj_eval_rates_dev(m, n, d_pres, d_y, PJ_LAYOUT_SOA, nullptr, nullptr, nullptr, nullptr, nullptr, dy0, stream);
+    if (!rc) {
+        hipLaunchKernelGGL(k_fd_setup, dim3(grid), dim3(256), 0, st, n, (int)nsp, d_y, dy0, r);
+        (void)hipMemcpyAsync(ytmp, d_y, bytes, hipMemcpyDeviceToDevice, st);
+        for (int j = 0; j < (int)nsp && !rc; ++j) {
+            hipLaunchKernelGGL(k_fd_perturb, dim3(grid), dim3(256), 0, st, n, j, d_y, r, ytmp);
+            rc = pj_eval_rates_dev(m, n, d_pres, ytmp, PJ_LAYOUT_SOA, nullptr, nullptr, nullptr, nullptr, nullptr, dyj, stream);
+            hipLaunchKernelGGL(k_fd_col, dim3(grid), dim3(256), 0, st, n, (int)nsp, j, dyj, dy0, r, d_jac, j_si, j_ss);
+        }
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (rc) return rc;
+    return hipGetLastError() == hipSuccess ? PJ_OK : fail(PJ_EHIP, "finite-difference kernels failed");
 }
 
 #ifdef PJ_TIMING

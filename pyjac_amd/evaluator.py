@@ -149,6 +149,18 @@ class Evaluator:
                                            p('spec_rates'), p('dydt'), self._stream()))
         return outs
 
+    def fd_jacobian(self, pres, y, out=None, jac_layout=LAYOUT_SOA):
+        """Finite-difference Jacobian of dydt (the reference's comparison arm,
+        performance_tester/fd_jacob.c); y SoA (NSP, n)."""
+        import torch
+        n = pres.numel()
+        if out is None:
+            shape = (self.nsp * self.nsp, n) if jac_layout == LAYOUT_SOA else (n, self.nsp * self.nsp)
+            out = torch.empty(shape, dtype=torch.float64, device=pres.device)
+        check(_lib.lib().pj_eval_fd_jacobian_dev(self._h, n, pres.data_ptr(), y.data_ptr(), out.data_ptr(),
+                                                 jac_layout, self._stream()))
+        return out
+
     def time_jacobian(self, pres, y, out, iters: int, y_layout=LAYOUT_SOA, jac_layout=LAYOUT_SOA):
         """Average kernel time (ms) over `iters` launches, HIP events on the
         launch stream (pj_time_jacobian_dev)."""

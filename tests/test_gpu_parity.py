@@ -232,3 +232,27 @@ def test_specialised_lane_kernel(name, layout, tables, torch_cuda):
     assert mx < RTOL and fro < 1e-9, (name, layout, mx, fro)
     mx, fro = thresholded_rel_err(spec, gen)
     assert mx < RTOL and fro < 1e-9, ('spec vs table-driven', mx, fro)
+
+
+def test_finite_difference_arm(tables, torch_cuda):
+    """N3: the reference's FD Jacobian (fd_jacob.c) on the GPU dydt.  A forward difference
+    amplifies the ~1e-16 differences between GPU and CPU dydt by 1/r ~ 1e8 / |y_j|, so the
+    comparison is relative to each column's scale; it also has to agree with the analytical
+    Jacobian to truncation error."""
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev('h2o2_n2')
+    n = 300
+    pres, y = synth.dist_b(n, ev.nsp, seed=5, Tlo=900, Thi=2200)
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    fd = ev.fd_jacobian(d_p, d_y).cpu().numpy().T.reshape(n, ev.nsp, ev.nsp)          # [s][col][row]
+    o = Oracle(tables('h2o2_n2'))
+    ref = np.array([o.fd_jacob(float(pres[s]), y[:, s].copy()) for s in range(n)]).reshape(n, ev.nsp, ev.nsp)
+    colscale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
+    assert (np.abs(fd - ref) / colscale).max() < 1e-5
+    ana = ev.jacobian(d_p, d_y).cpu().numpy().T.reshape(n, ev.nsp, ev.nsp)
+    # first-order differences carry truncation error (large where a tiny Y_j gets the r0/ewt
+    # increment); the bulk of the entries must still agree with the analytical Jacobian
+    rel = np.abs(fd - ana) / (np.abs(ana).max(axis=2, keepdims=True) + 1e-300)
+    assert np.median(rel) < 1e-6 and np.percentile(rel, 90) < 1e-3
