@@ -212,7 +212,10 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % wl)
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+            # PMC-measured HBM bytes of this kernel (profiles/README.md); a streaming map, so
+            # a launch over n states moves n / states_per_launch times the profiled bytes
+            tj = json.load(open(tpath))
+            traffic = tj['hbm_bytes_per_launch'] * n / tj.get('states_per_launch', n)
         line = {
             'metric': 'fp64 analytical Jacobians/s', 'value': value, 'unit': 'Jacobians/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
