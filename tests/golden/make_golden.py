@@ -25,6 +25,8 @@ CASES = {
     'h2o2_n2': os.path.join(ROOT, 'pyjac_amd', 'data', 'h2o2_n2.inp'),
     'h2o2': os.path.join(HERE, 'h2o2.inp'),
     'synth_alltypes': os.path.join(HERE, 'synth_alltypes.inp'),
+    'gri30_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'gri30_shaped.inp'),
+    'usc2_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'),
 }
 
 
@@ -38,6 +40,10 @@ def states_for(name, nsp):
         sel = slice(3, None, 17)
         P, T = P[sel], T[sel]
         Y = Y[sel, :9] / Y[sel, :9].sum(axis=1, keepdims=True)
+    elif name in ('gri30_shaped', 'usc2_shaped'):
+        n = 12 if name == 'gri30_shaped' else 4
+        P, ysoa = synth.dist_b(n, nsp, seed=77, Tlo=600, Thi=2500)
+        return P, np.ascontiguousarray(ysoa.T)
     else:
         rng = np.random.default_rng(7)
         n = 120

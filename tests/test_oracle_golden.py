@@ -10,7 +10,7 @@ from oracle.oracle import Oracle, Reference
 KEYS = ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped'])
 def test_oracle_matches_reference_golden(name, golden, tables):
     g = golden(name)
     tab = tables(name)
@@ -22,7 +22,7 @@ def test_oracle_matches_reference_golden(name, golden, tables):
         for k in KEYS:
             mx, fro = thresholded_rel_err(out[k], g[k][s])
             # rates are bit-for-bit; the Jacobian differs by summation order only
-            tol = 1e-13 if k != 'jac' else 5e-11
+            tol = 1e-13 if k != 'jac' else (5e-11 if tab.nsp <= 16 else 5e-9)
             assert mx <= tol, (name, s, k, mx)
             assert fro <= 1e-13
 
@@ -39,14 +39,14 @@ def test_oracle_writes_full_jacobian_block(tables):
     assert np.isfinite(jac).all()
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped'])
 def test_oracle_matches_reference_live(name, tables):
     if not Reference.available(name):
         pytest.skip('oracle/_ref not built (no /root/reference here)')
     tab = tables(name)
     o, r = Oracle(tab), Reference(name)
     rng = np.random.default_rng(11)
-    n = 64
+    n = 64 if tab.nsp <= 16 else 16
     T = rng.uniform(350, 3000, n)
     P = 101325 * 10 ** rng.uniform(-2, 2, n)
     Y = rng.uniform(0, 1, (n, tab.nsp)) ** 3 + 1e-9
@@ -54,7 +54,7 @@ def test_oracle_matches_reference_live(name, tables):
     y = np.concatenate([T[:, None], Y[:, :-1]], axis=1)
     a, b = o.batch_jacob(P, y), r.batch_jacob(P, y)
     mx, fro = thresholded_rel_err(a, b)
-    assert mx < 1e-9 and fro < 1e-12
+    assert mx < (1e-9 if tab.nsp <= 16 else 1e-7) and fro < 1e-12
     mx, fro = thresholded_rel_err(o.batch_dydt(P, y), r.batch_dydt(P, y))
     assert mx < 1e-12
 
