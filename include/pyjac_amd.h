@@ -75,7 +75,11 @@ int pj_mech_get_launch(const pj_mech* m, int* tile_states, int* threads, int* ld
 unsigned long long pj_mech_spec_hash(const pj_mech* m);
 /* write the constexpr header consumed by pj_lane.hip (-DPJS_HEADER='"path"') */
 int pj_mech_emit_spec(const pj_mech* m, const char* header_path);
-/* dlopen a library built from pj_lane.hip for this mechanism (hash-checked) and
+/* same header plus the row-block partition consumed by pj_rows.hip: the state-per-lane
+ * kernels for mechanisms whose sparse Jacobian block exceeds the register file; acc_budget =
+ * accumulator doubles a row block may hold in registers */
+int pj_mech_emit_rows_spec(const pj_mech* m, const char* header_path, int acc_budget);
+/* dlopen a library built from pj_lane.hip / pj_rows.hip for this mechanism (hash-checked) and
  * route pj_eval_jacobian_dev / pj_run / pj_eval_jacob through it */
 int pj_mech_attach_spec(pj_mech* m, const char* library_path);
 /* 1 if a specialised kernel is attached */

@@ -475,6 +475,17 @@ int pj_mech_emit_spec(const pj_mech* m, const char* header_path)
     return ok ? PJ_OK : fail(PJ_EIO, "short write");
 }
 
+int pj_mech_emit_rows_spec(const pj_mech* m, const char* header_path, int acc_budget)
+{
+    if (acc_budget < 8) return fail(PJ_EINVAL, "accumulator budget too small");
+    FILE* f = fopen(header_path, "w");
+    if (!f) return fail(PJ_EIO, std::string("cannot write ") + header_path);
+    const std::string h = emit_spec_header(m->P) + emit_rows_tables(m->P, acc_budget);
+    const bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
+    fclose(f);
+    return ok ? PJ_OK : fail(PJ_EIO, "short write");
+}
+
 int pj_mech_attach_spec(pj_mech* m, const char* library_path)
 {
     void* lib = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);

@@ -1,0 +1,704 @@
+// pj_rows.hip -- state-per-lane Jacobian kernels for MEDIUM / LARGE mechanisms.
+//
+// pj_lane.hip keeps a whole Jacobian in the registers of one lane; that stops at ~15 species.
+// Here the same formulation is cut into kernels whose live set fits the 512 registers a lane
+// owns at one wavefront per SIMD, all with one thermochemical state per lane and SoA-coalesced
+// memory traffic:
+//
+//   k_rates<R0,R1>   reactions [R0,R1): Arrhenius / PLOG, K_c, third-body / falloff / Troe factor
+//                    and the per-reaction derivative scalars.  The d/dT column (sum nu theta) is
+//                    finished here; what the row kernels need goes to an HBM scratch array
+//                    scr[slot][state]: c*k_f, c*k_r and, for pressure-dependent reactions,
+//                    rp, b_M, b_col (~2.4 doubles per reaction)
+//   k_rows<B0,B1>    row blocks [B0,B1) of the Jacobian: a block is a group of species rows whose
+//                    accumulators (omega_k, P_k, Q_k and the structurally non-zero
+//                    S_kj of those rows) fit the register budget; it re-reads the scratch values
+//                    of every reaction that touches one of its rows, rebuilds the cheap
+//                    concentration products, accumulates with compile-time register indices and
+//                    stores its rows of the Jacobian.  Concentrations sit in LDS (one column per
+//                    lane); energy-row partial sums are added to row 0 in memory at the end.
+//   k_fin            turns the raw energy-row sums into the d(dT/dt)/d. row.
+//
+// The mechanism is injected as constexpr tables (pj::emit_spec_header + pj::emit_rows_tables ->
+// PJS_HEADER); every loop is a compile-time loop.  The kernels of one library are compiled as
+// separate translation units (PJR_PART) so that a 53-species mechanism builds in parallel.
+//
+// Same formulation as pj_lane.hip / pj_kernel.h; reference emitters:
+// pyjac/core/rate_subs.py:254-2335, pyjac/core/create_jacobian.py:2189-3298.
+//
+// PJR_PART = 0: host entry points + k_fin;  PJR_PART = 1: k_rates<PJR_R0,PJR_R1>;
+// PJR_PART = 2: k_rows<PJR_B0,PJR_B1>.  PJR_ID is the launch-order index of the part.
+#ifdef PJR_HOST_EMU
+#include "hip_shim.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "pj_tables.h"
+#include PJS_HEADER
+
+using namespace pj;
+
+#ifndef PJR_BLOCK
+#define PJR_BLOCK 256
+#endif
+#ifndef PJR_DEPTH
+#define PJR_DEPTH 16       // visits whose scratch values are in flight
+#endif
+#define PJR_TILE 256        // states per scratch tile
+#ifdef PJR_HOST_EMU
+#define PJR_SCHED_BARRIER()
+#else
+#define PJR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+struct PjrArgs {
+    long n;                            // states of this chunk
+    const double* pres;                // chunk base
+    const double* y; long y_si, y_ss;  // chunk base
+    double* jac; long j_si, j_ss;      // chunk base
+    double* scr; long ld;              // scratch [ld / PJR_TILE][NSCR + 3][PJR_TILE]
+    int sum_last;
+};
+typedef void (*pjr_launch_fn)(const PjrArgs&, void* stream);
+extern "C" void pjr_register(int id, int kind, pjr_launch_fn fn);
+
+namespace {
+
+constexpr double RU_ = 8314.4621;
+constexpr double INV_LN10 = 0.434294481903251828;
+constexpr int NSP = pjs::NSP, NRXN = pjs::NRXN, LAST = pjs::NSP - 1, ONE = pjs::NSP;
+constexpr int S_TH = 0, S_KF = 1, S_KR = 2, S_RP = 3, S_BM = 4, S_BC = 5;
+constexpr int SUM_H = pjs::NSCR, SUM_SCP = pjs::NSCR + 1, SUM_SJT = pjs::NSCR + 2;
+
+#define PJR_INL __attribute__((always_inline))
+// compile-time loop: f(std::integral_constant<int, I0 + i>) for i = 0..N-1 (flat fold, no recursion)
+template <int I0, class F, int... Is>
+__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, I0 + Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (N > 0) static_for_seq<0>(f, std::make_integer_sequence<int, N>{});
+}
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_range(F&& f)
+{
+    if constexpr (I1 > I0) static_for_seq<I0>(f, std::make_integer_sequence<int, I1 - I0>{});
+}
+
+// scratch layout [state tile][slot][PJR_TILE]: everything one workgroup reads and writes is one
+// contiguous (NSCR + 3) * 2 KB region (DRAM-page and TLB locality), each wave access is 512 B
+#ifndef PJR_SCR_TILED
+#define PJR_SCR_TILED 1
+#endif
+#ifndef PJR_XPIPE
+#define PJR_XPIPE 0        // 1: issue the next block's first loads before this block's stores (measured: -7 %)
+#endif
+#if PJR_SCR_TILED
+#define PJR_SSTRIDE(A) PJR_TILE
+__device__ __forceinline__ double* scr_of(const PjrArgs& A, long s)
+{
+    return A.scr + (s / PJR_TILE) * ((long)(pjs::NSCR + 3) * PJR_TILE) + (s % PJR_TILE);
+}
+#else
+#define PJR_SSTRIDE(A) (A).ld
+__device__ __forceinline__ double* scr_of(const PjrArgs& A, long s) { return A.scr + s; }
+#endif
+
+// per-state scalars and concentrations shared by the kernels
+struct State {
+    double T, p, Wbar, rho, invrho, mconc;
+    double C[NSP + 1];
+};
+
+__device__ __forceinline__ void load_state(const PjrArgs& A, long s, State& L)
+{
+    const double* y = A.y + s * A.y_ss;
+    L.T = y[0];
+    L.p = A.pres[s];
+    double sumY = 0.0, sumYW = 0.0;
+    static_for<LAST>([&](auto kc) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        L.C[k] = y[(k + 1) * A.y_si];
+        sumY += L.C[k];
+        sumYW += L.C[k] * pjs::SP[k][0];
+    });
+    const double yN = 1.0 - sumY;
+    L.C[LAST] = yN;
+    sumYW += yN * pjs::SP[LAST][0];
+    L.Wbar = 1.0 / sumYW;
+    L.rho = L.p * L.Wbar / (RU_ * L.T);
+    L.invrho = 1.0 / L.rho;
+    L.mconc = L.p / (RU_ * L.T);
+}
+// mass fractions -> concentrations (after the mass-fraction weighted sums were taken)
+__device__ __forceinline__ void to_conc(State& L)
+{
+    static_for<NSP>([&](auto kc) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        L.C[k] = L.rho * L.C[k] * pjs::SP[k][0];
+    });
+    L.C[ONE] = 1.0;
+}
+
+#if PJR_PART == 1
+// ------------------------------------------------------------------------------------------
+// k_rates<R0,R1>
+// ------------------------------------------------------------------------------------------
+constexpr int R0_ = PJR_R0, R1_ = PJR_R1;
+constexpr int kc_lo()
+{
+    int lo = 1 << 30;
+    for (int i = R0_; i < R1_; ++i)
+        if ((pjs::RI[i][RI_FLAGS] & F_REV) && pjs::RI[i][RI_KC_CNT] > 0 && pjs::RI[i][RI_KC_PTR] < lo)
+            lo = pjs::RI[i][RI_KC_PTR];
+    return lo == (1 << 30) ? 0 : lo;
+}
+constexpr int kc_hi()
+{
+    int hi = 0;
+    for (int i = R0_; i < R1_; ++i)
+        if ((pjs::RI[i][RI_FLAGS] & F_REV) && pjs::RI[i][RI_KC_PTR] + pjs::RI[i][RI_KC_CNT] > hi)
+            hi = pjs::RI[i][RI_KC_PTR] + pjs::RI[i][RI_KC_CNT];
+    return hi < kc_lo() ? kc_lo() : hi;
+}
+constexpr int KC_LO = kc_lo(), KC_N = kc_hi() - kc_lo();
+// first reaction of [R0,R1) that uses K_c class c evaluates it
+constexpr bool kc_first_in_range(int i)
+{
+    for (int h = R0_; h < i; ++h)
+        if ((pjs::RI[h][RI_FLAGS] & F_REV) && pjs::KC_CLASS[h][0] == pjs::KC_CLASS[i][0]) return false;
+    return true;
+}
+constexpr int NEFF = (int)(sizeof(pjs::EFF_AM1) / sizeof(pjs::EFF_AM1[0]));
+
+__global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
+{
+    // real-valued coefficient tables of this reaction range, staged once per workgroup and
+    // read with uniform ds_reads (as 64-bit literals they would be hoisted and spilled)
+    __shared__ __attribute__((aligned(16))) double LT[(KC_N > 0 ? KC_N : 1) * 16];
+    __shared__ __attribute__((aligned(16))) double RDL[R1_ - R0_][RDW];
+    __shared__ __attribute__((aligned(16))) double EFL[NEFF];
+    for (int w = threadIdx.x; w < KC_N * 16; w += PJR_BLOCK) LT[w] = pjs::LTAB[pjs::LT_KC + KC_LO * 16 + w];
+    for (int w = threadIdx.x; w < (R1_ - R0_) * RDW; w += PJR_BLOCK) (&RDL[0][0])[w] = (&pjs::RDT[R0_][0])[w];
+    for (int w = threadIdx.x; w < NEFF; w += PJR_BLOCK) EFL[w] = pjs::EFFT[w][0];
+    __syncthreads();
+    for (long s = (long)blockIdx.x * PJR_BLOCK + threadIdx.x; s < A.n; s += (long)gridDim.x * PJR_BLOCK) {
+        State L;
+        load_state(A, s, L);
+        to_conc(L);
+        const double T = L.T, p = L.p, logT = log(T), invT = 1.0 / T, logp = log(p);
+        const double invrho = L.invrho, Wbar = L.Wbar, mconc = L.mconc;
+        const double* C = L.C;
+        double* const scr = scr_of(A, s);
+#define SCR_(slot) scr[(long)(slot) * PJR_SSTRIDE(A)]
+        double* const Jl = A.jac + s * A.j_ss;
+#define J_(e) Jl[(long)(e) * A.j_si]
+        if constexpr (R0_ == 0) {
+            // this part also clears what the row kernels accumulate into
+            SCR_(SUM_H) = 0.0; SCR_(SUM_SCP) = 0.0;
+            static_for<LAST>([&](auto jc) PJR_INL { J_(NSP * (decltype(jc)::value + 1)) = 0.0; });
+        }
+        double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
+        // d/dT column: sum_q nu_kq theta_q needs nothing but theta, so it is finished here and
+        // theta never goes through the scratch array
+        double jt[NSP], jtq = 0.0;
+        static_for<NSP>([&](auto kc) PJR_INL { jt[decltype(kc)::value] = 0.0; });
+        static_range<R0_, R1_>([&](auto ic) PJR_INL {
+            constexpr int i = decltype(ic)::value;
+            constexpr int fl = pjs::RI[i][RI_FLAGS];
+            const double* rd = RDL[i - R0_];
+            double lnk, dlnk;
+            if constexpr ((fl & F_PLOG) != 0) {
+                constexpr int pp = pjs::RI[i][RI_PLOG_PTR], np = pjs::RI[i][RI_PLOG_CNT];
+                // interval select chain over the breakpoints (rate_subs.py:598-632)
+                lnk = pjs::PLOG[pp][2] + pjs::PLOG[pp][3] * logT - pjs::PLOG[pp][4] * invT;
+                dlnk = pjs::PLOG[pp][3] + pjs::PLOG[pp][4] * invT;
+                static_for<np - 1>([&](auto qc) PJR_INL {
+                    constexpr int q = decltype(qc)::value + 1;
+                    constexpr double P1 = pjs::PLOG[pp + q - 1][0], L1 = pjs::PLOG[pp + q - 1][1],
+                                     A1 = pjs::PLOG[pp + q - 1][2], B1 = pjs::PLOG[pp + q - 1][3],
+                                     E1 = pjs::PLOG[pp + q - 1][4];
+                    constexpr double P2 = pjs::PLOG[pp + q][0], L2 = pjs::PLOG[pp + q][1],
+                                     A2 = pjs::PLOG[pp + q][2], B2 = pjs::PLOG[pp + q][3],
+                                     E2 = pjs::PLOG[pp + q][4];
+                    const double k1 = A1 + B1 * logT - E1 * invT;
+                    const double k2 = A2 + B2 * logT - E2 * invT;
+                    const double f = (logp - L1) / (L2 - L1);
+                    const bool in = p > P1 && p <= P2;
+                    lnk = in ? k1 + (k2 - k1) * f : lnk;
+                    dlnk = in ? B1 + E1 * invT + ((B2 - B1) + (E2 - E1) * invT) * f : dlnk;
+                });
+                {
+                    constexpr double Pn = pjs::PLOG[pp + np - 1][0], An = pjs::PLOG[pp + np - 1][2],
+                                     Bn = pjs::PLOG[pp + np - 1][3], En = pjs::PLOG[pp + np - 1][4];
+                    const bool hi = p > Pn;
+                    lnk = hi ? An + Bn * logT - En * invT : lnk;
+                    dlnk = hi ? Bn + En * invT : dlnk;
+                }
+            } else {
+                lnk = rd[RD_LNA] + rd[RD_B] * logT - rd[RD_TA] * invT;
+                dlnk = rd[RD_B] + rd[RD_TA] * invT;
+            }
+            const double kf = (pjs::RD[i][RD_SGN] < 0.0) ? -exp(lnk) : exp(lnk);
+
+            double kr = 0.0, TdlnKc = 0.0;
+            if constexpr ((fl & F_REV) != 0) {
+                constexpr int kcls = pjs::KC_CLASS[i][0];
+                if constexpr (kc_first_in_range(i)) {
+                    double lnKc = rd[RD_LNPREF], td = 0.0;
+                    static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJR_INL {
+                        constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
+                        const double* a = LT + (g - KC_LO) * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                        lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
+                        td += a[1] + T * (a[2] + T * (2.0 * a[3] + T * (3.0 * a[4] + 4.0 * a[5] * T))) + a[6] * invT;
+                    });
+                    ekc[kcls] = exp(-lnKc);
+                    tdk[kcls] = td;
+                }
+                kr = kf * ekc[kcls];
+                TdlnKc = tdk[kcls];
+            }
+
+            const double cr0 = C[pjs::RI[i][RI_R0]], cr1 = C[pjs::RI[i][RI_R1]], cr2 = C[pjs::RI[i][RI_R2]];
+            const double cp0 = C[pjs::RI[i][RI_P0]], cp1 = C[pjs::RI[i][RI_P1]], cp2 = C[pjs::RI[i][RI_P2]];
+            const double Rf = kf * (cr0 * cr1 * cr2);
+            const double Rr = kr * (cp0 * cp1 * cp2);
+            const double R = Rf - Rr;
+
+            double c = 1.0, lead = 0.0, a_extra = 0.0, bM = 0.0, bcol = 0.0;
+            if constexpr ((fl & (F_THD | F_PDEP)) != 0) {
+                double Mc = mconc;
+                static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
+                    constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                    Mc += EFL[e] * C[pjs::EFF_SP[e][0]];
+                });
+                if constexpr ((fl & F_THD) != 0) {
+                    c = Mc;
+                    lead = -c * R * invT;
+                    if constexpr ((fl & F_EFFTYPE) != 0) { bM = R; a_extra = c * R; }
+                } else {
+                    constexpr int col = pjs::RI[i][RI_COLLIDER];
+                    double conc_temp = Mc;
+                    if constexpr (col >= 0) conc_temp = C[col >= 0 ? col : 0];
+                    const double e0T = rd[RD_E0] * invT;
+                    const double k0kinf = exp(rd[RD_LNAR] + rd[RD_B0] * logT - e0T);
+                    const double Pr = conc_temp * k0kinf;
+                    const double i1Pr = 1.0 / (1.0 + Pr);
+                    double F = 1.0, extra = 0.0, Xtroe = 0.0;
+                    if constexpr ((fl & F_TROE) != 0) {
+                        const double ta = rd[RD_TRA], T3 = rd[RD_T3], T1 = rd[RD_T1], T2 = rd[RD_T2];
+                        const double e3 = exp(-T / T3), e1 = exp(-T / T1);
+                        double Fcent = (1.0 - ta) * e3 + ta * e1;
+                        double dF = -((1.0 - ta) / T3) * e3 - (ta / T1) * e1;
+                        if constexpr ((fl & F_TROE4) != 0) {
+                            const double e2 = exp(-T2 * invT);
+                            Fcent += e2;
+                            dF += T2 * invT * invT * e2;
+                        }
+                        const double lF = log(fmax(Fcent, 1.0e-300));
+                        const double lgF = lF * INV_LN10;
+                        const double lgPr = log(fmax(Pr, 1.0e-300)) * INV_LN10;
+                        const double At = lgPr - 0.67 * lgF - 0.4;
+                        const double Bt = 0.806 - 1.1762 * lgF - 0.14 * lgPr;
+                        const double iB = 1.0 / Bt;
+                        const double iden = 1.0 / (1.0 + At * At * iB * iB);
+                        F = exp(lF * iden);
+                        const double lnF_AB = 2.0 * lF * At * iB * iB * iB * iden * iden;
+                        const double iFc = 1.0 / Fcent;
+                        Xtroe = lnF_AB * (INV_LN10 * Bt + (0.14 * INV_LN10) * At);
+                        extra = (iFc * iden - lnF_AB * (-(0.67 * INV_LN10) * Bt + (1.1762 * INV_LN10) * At) * iFc) * dF -
+                                Xtroe * (rd[RD_B0] + e0T - 1.0) * invT;
+                    }
+                    double dpr = (rd[RD_B04] + e0T - 1.0) * invT * i1Pr;
+                    double X;
+                    if constexpr ((fl & F_LOW) != 0) { c = F * Pr * i1Pr; X = i1Pr - Xtroe; }
+                    else { c = F * i1Pr; X = -Pr * i1Pr - Xtroe; dpr = -Pr * dpr; }
+                    lead = c * (dpr + extra) * R;
+                    if constexpr ((fl & (F_EFFTYPE | F_COLLIDER)) != 0) {
+                        const double pmt = X * R;
+                        a_extra = c * pmt;
+                        const double bb = pmt * k0kinf * F * i1Pr;
+                        if constexpr ((fl & F_COLLIDER) != 0) bcol = bb; else bM = bb;
+                    }
+                }
+            }
+
+            constexpr double nr = pjs::RD[i][RD_NR], np_ = pjs::RD[i][RD_NP];
+            if constexpr ((fl & F_NO_DT) == 0) {
+                double el = R * dlnk + Rf * (1.0 - nr);
+                if constexpr ((fl & F_REV) != 0) el -= Rr * ((1.0 - np_) - TdlnKc);
+                const double theta = (lead + c * invT * el) * invrho;
+                static_for<pjs::RI[i][RI_NET_CNT]>([&](auto qc) PJR_INL {
+                    constexpr int q = pjs::RI[i][RI_NET_PTR] + decltype(qc)::value;
+                    constexpr int k = pjs::NET_SP[q][0];
+                    jt[k] += pjs::NET_NU[q][0] * theta;
+                    if constexpr (k == LAST && i == pjs::LASTQ) jtq = pjs::NET_NU[q][0] * theta;
+                });
+            }
+            SCR_(pjs::SCR[i][S_KF]) = c * kf;
+            if constexpr (pjs::SCR[i][S_KR] >= 0) SCR_(pjs::SCR[i][S_KR]) = c * kr;
+            if constexpr (pjs::SCR[i][S_RP] >= 0) {
+                const double a = c * (nr * Rf - ((fl & F_REV) ? np_ * Rr : 0.0)) + a_extra;
+                SCR_(pjs::SCR[i][S_RP]) = (Wbar * invrho) * (c * R - a) + bM;
+            }
+            if constexpr (pjs::SCR[i][S_BM] >= 0) SCR_(pjs::SCR[i][S_BM]) = bM;
+            if constexpr (pjs::SCR[i][S_BC] >= 0) SCR_(pjs::SCR[i][S_BC]) = bcol;
+        });
+        // reference quirk (create_jacobian.py:2786-2818): the last species keeps only the d/dT
+        // term of one reaction unless sum_last is set (see pj_kernel.h)
+        if (!A.sum_last) jt[LAST] = (pjs::LASTQ >= R0_ && pjs::LASTQ < R1_) ? jtq : 0.0;
+        double sjt = 0.0;
+        static_for<NSP>([&](auto kc) PJR_INL {
+            constexpr int k = decltype(kc)::value;
+            const bool lo = T <= pjs::SP[k][2];
+            double a[6];
+            static_for<6>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value;
+                a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+            });
+            const double hW = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                                     T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+            sjt += hW * jt[k];
+            if constexpr (k < LAST) {
+                if constexpr (R0_ == 0) J_(k + 1) = pjs::SP[k][1] * jt[k];
+                else J_(k + 1) += pjs::SP[k][1] * jt[k];
+            }
+        });
+        if constexpr (R0_ == 0) SCR_(SUM_SJT) = sjt; else SCR_(SUM_SJT) += sjt;
+#undef J_
+#undef SCR_
+    }
+}
+
+void launch_part(const PjrArgs& A, void* stream)
+{
+    static long resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 256, per_cu = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rates, PJR_BLOCK, 0);
+        resident = (long)cus * (per_cu > 0 ? per_cu : 1);
+    }
+    long blocks = (A.n + PJR_BLOCK - 1) / PJR_BLOCK;
+    if (blocks > resident) blocks = resident;
+    hipLaunchKernelGGL(k_rates, dim3((unsigned)blocks), dim3(PJR_BLOCK), 0, (hipStream_t)stream, A);
+}
+struct Reg { Reg() { pjr_register(PJR_ID, 1, launch_part); } } reg_;
+#endif  // PJR_PART == 1
+
+#if PJR_PART == 2
+// ------------------------------------------------------------------------------------------
+// k_rows<B0,B1>
+// ------------------------------------------------------------------------------------------
+constexpr int B0_ = PJR_B0, B1_ = PJR_B1;
+
+// does reaction i carry an enhanced efficiency of the last species?
+template <int i>
+constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
+
+__global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
+{
+    // Concentrations live in LDS, one column per lane (bank-conflict free): the registers they
+    // would occupy are worth more as landing space for scratch loads in flight -- at one
+    // wavefront per SIMD the bytes in flight per lane bound the achieved HBM bandwidth.
+    __shared__ double CL[NSP][PJR_BLOCK];
+    const long s = (long)blockIdx.x * PJR_BLOCK + threadIdx.x;
+    if (s >= A.n) return;
+    const int tid = threadIdx.x;
+    double T, invrho, Wbar;
+    {
+        State L;
+        load_state(A, s, L);
+        to_conc(L);
+        T = L.T; invrho = L.invrho; Wbar = L.Wbar;
+        static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
+    }
+    auto conc = [&](auto spc) PJR_INL {
+        constexpr int sp = decltype(spc)::value;
+        if constexpr (sp == ONE) return 1.0; else return CL[sp][tid];
+    };
+    // energy-row partial sums: rarely touched, so the register allocator parks them in AGPRs
+    double E[LAST > 0 ? LAST : 1];
+    const double* const scr = scr_of(A, s);
+#define LD_(slot) scr[(long)(slot) * PJR_SSTRIDE(A)]
+    double* const Jl = A.jac + s * A.j_ss;
+#define J_(e) Jl[(long)(e) * A.j_si]
+    static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] = 0.0; });
+    double H = 0.0, SCP = 0.0;
+
+    // scratch values are fetched PJR_DEPTH visits ahead into a register ring; the scheduling
+    // barrier after every visit keeps the loads where they are issued (left alone, the
+    // scheduler hoists all of a block's loads to its top and spills the accumulators).
+    double ring[PJR_DEPTH][6];
+    auto issue_bv = [&](auto bc, auto vc) PJR_INL {
+        constexpr int v = decltype(vc)::value;
+        constexpr int i = pjs::BLK_RX[pjs::BLK_RX_PTR[decltype(bc)::value][0] + v][0];
+        static_for<6>([&](auto cc) PJR_INL {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (pjs::SCR[i][c] >= 0) ring[v % PJR_DEPTH][c] = LD_(pjs::SCR[i][c]);
+        });
+    };
+    auto prologue = [&](auto bc) PJR_INL {
+        constexpr int b = decltype(bc)::value;
+        constexpr int nv = pjs::BLK_RX_PTR[b + 1][0] - pjs::BLK_RX_PTR[b][0];
+        static_for<(nv < PJR_DEPTH ? nv : PJR_DEPTH)>([&](auto vc) PJR_INL { issue_bv(bc, vc); });
+    };
+    prologue(std::integral_constant<int, B0_>{});
+
+    static_range<B0_, B1_>([&](auto bc) PJR_INL {
+        constexpr int b = decltype(bc)::value;
+#if !PJR_XPIPE
+        if constexpr (b > B0_) prologue(bc);
+#endif
+        constexpr int r0 = pjs::BLK_ROW_PTR[b][0], nrows = pjs::BLK_ROW_PTR[b + 1][0] - r0;
+        constexpr int v0 = pjs::BLK_RX_PTR[b][0], nv = pjs::BLK_RX_PTR[b + 1][0] - v0;
+        double om[nrows], P[nrows], Q[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
+        static_for<nrows>([&](auto rc) PJR_INL {
+            constexpr int r = decltype(rc)::value;
+            om[r] = 0.0; P[r] = 0.0; Q[r] = 0.0;
+        });
+        static_for<pjs::BLK_NNZ[b][0]>([&](auto ec) PJR_INL { S[decltype(ec)::value] = 0.0; });
+
+        auto issue = [&](auto vc) PJR_INL { issue_bv(bc, vc); };
+        static_for<nv>([&](auto vc) PJR_INL {
+            constexpr int v = decltype(vc)::value;
+            constexpr int i = pjs::BLK_RX[v0 + v][0];
+            constexpr int fl = pjs::RI[i][RI_FLAGS];
+            double ckr = 0.0, bM = 0.0, bcol = 0.0, rp_ld = 0.0;
+            const double ckf = ring[v % PJR_DEPTH][S_KF];
+            if constexpr (pjs::SCR[i][S_KR] >= 0) ckr = ring[v % PJR_DEPTH][S_KR];
+            if constexpr (pjs::SCR[i][S_RP] >= 0) rp_ld = ring[v % PJR_DEPTH][S_RP];
+            if constexpr (pjs::SCR[i][S_BM] >= 0) bM = ring[v % PJR_DEPTH][S_BM];
+            if constexpr (pjs::SCR[i][S_BC] >= 0) bcol = ring[v % PJR_DEPTH][S_BC];
+            if constexpr (v + PJR_DEPTH < nv) issue(std::integral_constant<int, v + PJR_DEPTH>{});
+            const double cr0 = conc(std::integral_constant<int, pjs::RI[i][RI_R0]>{}),
+                         cr1 = conc(std::integral_constant<int, pjs::RI[i][RI_R1]>{}),
+                         cr2 = conc(std::integral_constant<int, pjs::RI[i][RI_R2]>{});
+            const double cp0 = conc(std::integral_constant<int, pjs::RI[i][RI_P0]>{}),
+                         cp1 = conc(std::integral_constant<int, pjs::RI[i][RI_P1]>{}),
+                         cp2 = conc(std::integral_constant<int, pjs::RI[i][RI_P2]>{});
+            const double Rf = ckf * (cr0 * cr1 * cr2);       // c * R_f
+            const double Rr = ckr * (cp0 * cp1 * cp2);       // c * R_r
+            const double q_ = Rf - Rr;
+            constexpr double nr = pjs::RD[i][RD_NR], np_ = pjs::RD[i][RD_NP];
+            double rp;
+            if constexpr (pjs::SCR[i][S_RP] >= 0) rp = rp_ld;
+            else rp = (Wbar * invrho) * ((1.0 - nr) * Rf - ((fl & F_REV) ? (1.0 - np_) * Rr : 0.0));
+
+            double gN = 0.0;
+            if constexpr (has_anm1<i>()) gN = bM * pjs::RD[i][RD_ANM1];
+            constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
+            auto slot = [&](auto spc, const double gv) PJR_INL {
+                constexpr int sp = decltype(spc)::value;
+                if constexpr (sp == LAST) gN += gv;
+                else if constexpr (sp != ONE) {
+                    static_for<ncnt>([&](auto qc) PJR_INL {
+                        constexpr int q = np0 + decltype(qc)::value;
+                        constexpr int k = pjs::NET_SP[q][0];
+                        if constexpr (pjs::ROW_BLK[k][0] == b) {
+                            constexpr int si = pjs::SLOC[k][sp];
+                            static_assert(si >= 0, "sparse pattern and program disagree");
+                            S[si] += pjs::NET_NU[q][0] * gv;
+                        }
+                    });
+                }
+            };
+            slot(std::integral_constant<int, pjs::RI[i][RI_R0]>{}, ckf * (cr1 * cr2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_R1]>{}, ckf * (cr0 * cr2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_R2]>{}, ckf * (cr0 * cr1));
+            if constexpr ((fl & F_REV) != 0) {
+                slot(std::integral_constant<int, pjs::RI[i][RI_P0]>{}, -ckr * (cp1 * cp2));
+                slot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -ckr * (cp0 * cp2));
+                slot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -ckr * (cp0 * cp1));
+            }
+            if constexpr ((fl & F_COLLIDER) != 0)
+                slot(std::integral_constant<int, (pjs::RI[i][RI_COLLIDER] >= 0 ? pjs::RI[i][RI_COLLIDER] : ONE)>{}, bcol);
+            if constexpr ((fl & F_EFFTYPE) != 0) {
+                static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
+                    constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                    constexpr int es = pjs::EFF_SP[e][0];
+                    // the last species' enhanced efficiency is already in gN (RD_ANM1)
+                    if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, pjs::EFF_AM1[e][0] * bM);
+                });
+            }
+            const double rq = rp + gN;
+            static_for<ncnt>([&](auto qc) PJR_INL {
+                constexpr int q = np0 + decltype(qc)::value;
+                constexpr int k = pjs::NET_SP[q][0];
+                if constexpr (pjs::ROW_BLK[k][0] == b) {
+                    constexpr int r = pjs::ROWLOC[k][0];
+                    constexpr double nu = pjs::NET_NU[q][0];
+                    om[r] += nu * q_;
+                    P[r] += nu * rp;
+                    Q[r] += nu * rq;
+                }
+            });
+            PJR_SCHED_BARRIER();
+        });
+#if PJR_XPIPE
+        if constexpr (b + 1 < B1_) prologue(std::integral_constant<int, b + 1>{});
+        PJR_SCHED_BARRIER();
+#endif
+
+        // rows of this block: NASA properties of its species, outputs, energy-row partials
+        double hW[nrows];
+        static_for<nrows>([&](auto rc) PJR_INL {
+            constexpr int r = decltype(rc)::value;
+            constexpr int k = pjs::BLK_ROWS[r0 + r][0];
+            const bool lo = T <= pjs::SP[k][2];
+            double a[6];
+            static_for<6>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value;
+                a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+            });
+            hW[r] = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                           T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+            const double cpk = (RU_ * pjs::SP[k][0]) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+            H += hW[r] * om[r];
+            SCP += om[r] * pjs::SP[k][1] * cpk;
+        });
+        static_for<LAST>([&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+            constexpr double wj = pjs::SP[j][3], iWj = pjs::SP[j][0];
+            double tot = 0.0;
+            static_for<nrows>([&](auto rc) PJR_INL {
+                constexpr int r = decltype(rc)::value;
+                constexpr int k = pjs::BLK_ROWS[r0 + r][0];
+                constexpr int si = pjs::SLOC[k][j];
+                double m = P[r] - wj * Q[r];
+                if constexpr (si >= 0) m += S[si];
+                tot += hW[r] * m;
+                if constexpr (k < LAST) J_(k + 1 + NSP * (j + 1)) = (pjs::SP[k][1] * iWj) * m;
+            });
+            E[j] += tot;
+        });
+    });
+
+    // hand the partial sums to k_fin through memory (kernels of one batch run in stream order)
+    double* const sw = scr_of(A, s);
+    sw[(long)SUM_H * PJR_SSTRIDE(A)] += H;
+    sw[(long)SUM_SCP * PJR_SSTRIDE(A)] += SCP;
+    static_for<LAST>([&](auto jc) PJR_INL {
+        constexpr int j = decltype(jc)::value;
+        J_(NSP * (j + 1)) += E[j];
+    });
+#undef J_
+#undef LD_
+}
+
+void launch_part(const PjrArgs& A, void* stream)
+{
+    const long blocks = (A.n + PJR_BLOCK - 1) / PJR_BLOCK;
+    hipLaunchKernelGGL(k_rows, dim3((unsigned)blocks), dim3(PJR_BLOCK), 0, (hipStream_t)stream, A);
+}
+struct Reg { Reg() { pjr_register(PJR_ID, 2, launch_part); } } reg_;
+#endif  // PJR_PART == 2
+
+#if PJR_PART == 0
+// ------------------------------------------------------------------------------------------
+// k_fin + host side
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PJR_BLOCK) k_fin(PjrArgs A)
+{
+    const long s = (long)blockIdx.x * PJR_BLOCK + threadIdx.x;
+    if (s >= A.n) return;
+    State L;
+    load_state(A, s, L);
+    const double T = L.T;
+    double cpavg = 0.0, dcpavg = 0.0, cpN = 0.0;
+    auto cp_of = [&](auto kc, double& dcp) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        const bool lo = T <= pjs::SP[k][2];
+        double a[5];
+        static_for<5>([&](auto cc) PJR_INL {
+            constexpr int c = decltype(cc)::value;
+            a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+        });
+        const double RW = RU_ * pjs::SP[k][0];
+        dcp = RW * (a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T)));
+        return RW * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+    };
+    static_for<NSP>([&](auto kc) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        double dcp;
+        const double cp = cp_of(kc, dcp);
+        cpavg += L.C[k] * cp;
+        dcpavg += L.C[k] * dcp;
+        if constexpr (k == LAST) cpN = cp;
+    });
+    const double* const scr = scr_of(A, s);
+    const double H = scr[(long)SUM_H * PJR_SSTRIDE(A)], SCP = scr[(long)SUM_SCP * PJR_SSTRIDE(A)],
+                 SJT = scr[(long)SUM_SJT * PJR_SSTRIDE(A)];
+    const double rho = L.rho, invrho = L.invrho, icp = 1.0 / cpavg;
+    double* const Jl = A.jac + s * A.j_ss;
+#define J_(e) Jl[(long)(e) * A.j_si]
+    J_(0) = -(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg);
+    static_for<LAST>([&](auto jc) PJR_INL {
+        constexpr int j = decltype(jc)::value;
+        double dcp;
+        const double cpj = cp_of(jc, dcp);
+        const double tot = J_(NSP * (j + 1));
+        J_(NSP * (j + 1)) = -tot * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
+    });
+#undef J_
+}
+
+constexpr int MAXPARTS = 512;
+pjr_launch_fn g_rates[MAXPARTS], g_rows[MAXPARTS];
+double* g_scr = nullptr;
+long g_scr_ld = 0;
+#endif
+
+}  // namespace
+
+#if PJR_PART == 0
+extern "C" {
+
+void pjr_register(int id, int kind, pjr_launch_fn fn)
+{
+    if (id < 0 || id >= MAXPARTS) return;
+    (kind == 1 ? g_rates : g_rows)[id] = fn;
+}
+
+unsigned long long pj_spec_hash(void) { return PJS_HASH; }
+int pj_spec_nsp(void) { return NSP; }
+int pj_spec_kind(void) { return 2; }   // 1: pj_lane.hip, 2: pj_rows.hip
+long pj_spec_scratch_doubles_per_state(void) { return pjs::NSCR + 3; }
+
+// layouts as in include/pyjac_amd.h: element (i, s) at base[i*si + s*ss].  One batch at a time
+// per library (the scratch array is shared): calls on different streams must not overlap.
+int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
+                     long j_si, long j_ss, int sum_last, void* stream)
+{
+    if (n <= 0) return 0;
+    long chunk = 262144;
+    if (const char* e = getenv("PJ_ROWS_CHUNK")) { const long v = atol(e); if (v >= 256) chunk = v; }
+    chunk = (chunk + PJR_TILE - 1) / PJR_TILE * PJR_TILE;
+    if (chunk > n) chunk = (n + PJR_TILE - 1) / PJR_TILE * PJR_TILE;
+    if (g_scr_ld < chunk) {
+        if (g_scr) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr); g_scr = nullptr; g_scr_ld = 0; }
+        if (hipMalloc((void**)&g_scr, sizeof(double) * (size_t)(pjs::NSCR + 3) * (size_t)chunk) != hipSuccess) return -4;
+        g_scr_ld = chunk;
+    }
+    for (long s0 = 0; s0 < n; s0 += chunk) {
+        const long m = s0 + chunk < n ? chunk : n - s0;
+        PjrArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, g_scr, g_scr_ld, sum_last};
+        for (int i = 0; i < MAXPARTS; ++i) if (g_rates[i]) g_rates[i](A, stream);
+        for (int i = 0; i < MAXPARTS; ++i) if (g_rows[i]) g_rows[i](A, stream);
+        hipLaunchKernelGGL(k_fin, dim3((unsigned)((m + PJR_BLOCK - 1) / PJR_BLOCK)), dim3(PJR_BLOCK), 0,
+                           (hipStream_t)stream, A);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // extern "C"
+#endif

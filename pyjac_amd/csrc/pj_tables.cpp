@@ -589,4 +589,114 @@ std::string emit_spec_header(const Programs& p)
     return o;
 }
 
+// Row-block partition for pj_rows.hip (state-per-lane kernels for mechanisms whose sparse
+// block does not fit the register file at once): species rows are grouped greedily so that a
+// group's accumulators (4 dense + its structurally non-zero S entries per row) fit `budget`
+// doubles, preferring rows that share reactions (each group visits every reaction that
+// touches one of its rows).  Also numbers the per-reaction values the rate kernel hands to
+// the row kernels through the HBM scratch array.
+std::string emit_rows_tables(const Programs& p, int budget)
+{
+    const int nsp = p.nsp, nrxn = p.nrxn;
+    std::string o;
+    auto arr_i = [&](const char* name, const std::vector<int32_t>& v, int width) {
+        const size_t rows = v.size() / width;
+        o += "constexpr int "; o += name; o += "[" + std::to_string(rows ? rows : 1) + "][" + std::to_string(width) + "] = {";
+        if (!rows) o += "{}";
+        for (size_t r = 0; r < rows; ++r) {
+            o += "{";
+            for (int c = 0; c < width; ++c) o += std::to_string(v[r * width + c]) + ",";
+            o += "},\n";
+        }
+        o += "};\n";
+    };
+    // structural pattern of S and the reactions touching each row
+    std::vector<int> nnz_row(nsp, 0);
+    for (int j = 0; j < nsp - 1; ++j)
+        for (int k = 0; k < nsp; ++k)
+            if (p.prog[p.p4en + k + nsp * j] & 255u) ++nnz_row[k];
+    std::vector<std::vector<int>> rx_of(nsp);
+    for (int i = 0; i < nrxn; ++i) {
+        const int32_t* ri = &p.ri[(size_t)i * RIW];
+        for (int q = 0; q < ri[RI_NET_CNT]; ++q) rx_of[p.net_sp[ri[RI_NET_PTR] + q]].push_back(i);
+    }
+    const int DENSE = 3;
+    std::vector<int> blk_of(nsp, -1);
+    std::vector<std::vector<int>> blocks;
+    std::vector<std::vector<char>> blk_rx;
+    int left = nsp;
+    while (left > 0) {
+        int seed = -1;
+        for (int k = 0; k < nsp; ++k)
+            if (blk_of[k] < 0 && (seed < 0 || rx_of[k].size() > rx_of[seed].size())) seed = k;
+        std::vector<int> blk{seed};
+        std::vector<char> rxs(nrxn, 0);
+        for (int i : rx_of[seed]) rxs[i] = 1;
+        blk_of[seed] = (int)blocks.size(); --left;
+        int cost = nnz_row[seed] + DENSE;
+        for (;;) {
+            int best = -1; double bscore = -1e300;
+            for (int k = 0; k < nsp; ++k) {
+                if (blk_of[k] >= 0 || cost + nnz_row[k] + DENSE > budget) continue;
+                int shared = 0;
+                for (int i : rx_of[k]) shared += rxs[i];
+                const double score = shared - 0.3 * ((int)rx_of[k].size() - shared);
+                if (score > bscore) { bscore = score; best = k; }
+            }
+            if (best < 0) break;
+            blk.push_back(best); blk_of[best] = (int)blocks.size(); --left;
+            cost += nnz_row[best] + DENSE;
+            for (int i : rx_of[best]) rxs[i] = 1;
+        }
+        std::sort(blk.begin(), blk.end());
+        blocks.push_back(blk);
+        blk_rx.push_back(rxs);
+    }
+    const int nblk = (int)blocks.size();
+    std::vector<int32_t> row_blk(nsp), rowloc(nsp), brow_ptr{0}, brows, brx_ptr{0}, brx, bnnz(nblk, 0);
+    std::vector<int32_t> sloc((size_t)nsp * nsp, -1);
+    int maxrows = 0, maxnnz = 1;
+    for (int b = 0; b < nblk; ++b) {
+        int loc = 0;
+        for (int k : blocks[b]) {
+            row_blk[k] = b; rowloc[k] = loc++;
+            brows.push_back(k);
+            for (int j = 0; j < nsp - 1; ++j)
+                if (p.prog[p.p4en + k + nsp * j] & 255u) sloc[(size_t)k * nsp + j] = bnnz[b]++;
+        }
+        brow_ptr.push_back((int32_t)brows.size());
+        for (int i = 0; i < nrxn; ++i) if (blk_rx[b][i]) brx.push_back(i);
+        brx_ptr.push_back((int32_t)brx.size());
+        maxrows = std::max(maxrows, loc);
+        maxnnz = std::max(maxnnz, (int)bnnz[b]);
+    }
+    // scratch slots per reaction: (theta: stays in the rate kernel), c*kf, c*kr, rp, bM, bcol
+    // (-1: not stored)
+    std::vector<int32_t> scr((size_t)nrxn * 6, -1);
+    int nscr = 0;
+    for (int i = 0; i < nrxn; ++i) {
+        const int fl = p.ri[(size_t)i * RIW + RI_FLAGS];
+        scr[(size_t)i * 6 + 1] = nscr++;
+        if (fl & F_REV) scr[(size_t)i * 6 + 2] = nscr++;
+        if (fl & (F_THD | F_PDEP)) scr[(size_t)i * 6 + 3] = nscr++;
+        if (fl & F_EFFTYPE) scr[(size_t)i * 6 + 4] = nscr++;
+        if (fl & F_COLLIDER) scr[(size_t)i * 6 + 5] = nscr++;
+    }
+    o += "namespace pjs {\n";
+    o += "constexpr int NBLK = " + std::to_string(nblk) + ", BLK_MAXROWS = " + std::to_string(maxrows) +
+         ", BLK_MAXNNZ = " + std::to_string(maxnnz) + ", NSCR = " + std::to_string(nscr) +
+         ", NVISIT = " + std::to_string(brx.size()) + ";\n";
+    arr_i("ROW_BLK", row_blk, 1);
+    arr_i("ROWLOC", rowloc, 1);
+    arr_i("BLK_ROW_PTR", brow_ptr, 1);
+    arr_i("BLK_ROWS", brows, 1);
+    arr_i("BLK_RX_PTR", brx_ptr, 1);
+    arr_i("BLK_RX", brx, 1);
+    arr_i("BLK_NNZ", bnnz, 1);
+    arr_i("SLOC", sloc, nsp);
+    arr_i("SCR", scr, 6);
+    o += "}  // namespace pjs\n";
+    return o;
+}
+
 }  // namespace pj

@@ -127,6 +127,8 @@ bool build_schedule(Programs& p, int NW, int IL, Schedule& out);
 uint64_t programs_hash(const Programs& p);
 // Mechanism constants as a C++ header (constexpr arrays) for pj_lane.hip.
 std::string emit_spec_header(const Programs& p);
+// Row-block partition + scratch numbering for pj_rows.hip, appended to that header.
+std::string emit_rows_tables(const Programs& p, int budget);
 
 // Returns false (and sets p.error) when the blob is malformed or uses a
 // feature outside the hot-path scope.

@@ -20,9 +20,10 @@ class Evaluator:
     """
 
     def __init__(self, mech, therm: str = None, last_spec: str = None, specialize: str = 'auto'):
-        """specialize: 'auto' attaches a prebuilt register-resident kernel for
-        this mechanism if pyjac_amd/spec/ holds one; 'build' also compiles it
-        when missing (hipcc, seconds; small mechanisms only); 'off' never."""
+        """specialize: 'auto' attaches the prebuilt mechanism-specific kernels if
+        pyjac_amd/spec/ holds them; 'build' also compiles them when missing (hipcc:
+        seconds for H2-size mechanisms, about a minute on 8 cores for GRI-size);
+        'off' never (table-driven kernel)."""
         if isinstance(mech, MechTables):
             self.tables = mech
             self.mechanism = None
@@ -46,35 +47,95 @@ class Evaluator:
         if specialize != 'off':
             self.specialize(build=(specialize == 'build'))
 
-    # ---- register-resident specialisation (csrc/pj_lane.hip) ----
+    # ---- mechanism-specific state-per-lane kernels ----
+    # csrc/pj_lane.hip: the whole Jacobian in one lane's registers (small mechanisms);
+    # csrc/pj_rows.hip: rate kernel + row-block kernels through an HBM scratch array (the rest)
     SPEC_MAX_NSP, SPEC_MAX_RXN = 16, 64
+    ROWS_BUDGET = 64          # accumulator doubles per row block (stays inside 256 VGPRs)
+    ROWS_FUSE = 16            # row blocks per kernel
+    ROWS_RATES_PER_PART = 128  # reactions per rate kernel (its coefficient tables sit in LDS)
 
     def spec_path(self) -> str:
         h = _lib.lib().pj_mech_spec_hash(self._h)
         return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'spec', 'libpj_spec_%016x.so' % h)
 
-    def specialize(self, build: bool = False) -> bool:
-        """Attach (and optionally build) the mechanism-specific lane kernel."""
+    def spec_kind(self) -> str:
+        """Which specialised kernel family specialize(build=True) compiles for this mechanism."""
+        return 'lane' if self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN else 'rows'
+
+    def specialize(self, build: bool = False, kind: str = None) -> bool:
+        """Attach (and optionally build) the mechanism-specific kernels."""
         L = _lib.lib()
         so = self.spec_path()
         if not os.path.exists(so):
-            if not build or self.nsp > self.SPEC_MAX_NSP or self.n_fwd > self.SPEC_MAX_RXN:
+            if not build:
                 return False
-            import subprocess
-            here = os.path.dirname(os.path.abspath(__file__))
-            os.makedirs(os.path.dirname(so), exist_ok=True)
-            hdr = so[:-3] + '.h'
-            check(L.pj_mech_emit_spec(self._h, hdr.encode()))
-            hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-            # -ffast-math: reciprocal instead of IEEE division sequences and reassociation of
-            # the long accumulation chains (+11 % on MI355X); parity stays ~1e-11 (DESIGN.md section 6)
-            flags = os.environ.get('PJ_LANE_FLAGS',
-                                   '-ffast-math -mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
-            subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
-                                  ['-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
-                                   '-o', so, os.path.join(here, 'csrc', 'pj_lane.hip')])
+            if (kind or self.spec_kind()) == 'lane':
+                self._build_lane(so)
+            else:
+                self._build_rows(so)
         check(L.pj_mech_attach_spec(self._h, so.encode()))
         return True
+
+    def _build_lane(self, so: str):
+        import subprocess
+        L = _lib.lib()
+        here = os.path.dirname(os.path.abspath(__file__))
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        hdr = so[:-3] + '.h'
+        check(L.pj_mech_emit_spec(self._h, hdr.encode()))
+        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        # -ffast-math: reciprocal instead of IEEE division sequences and reassociation of
+        # the long accumulation chains (+11 % on MI355X); parity stays ~1e-11 (DESIGN.md section 6)
+        flags = os.environ.get('PJ_LANE_FLAGS',
+                               '-ffast-math -mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
+                              ['-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
+                               '-o', so, os.path.join(here, 'csrc', 'pj_lane.hip')])
+
+    def _build_rows(self, so: str):
+        """One translation unit per kernel of csrc/pj_rows.hip, compiled in parallel."""
+        import re
+        import shutil
+        import subprocess
+        from concurrent.futures import ThreadPoolExecutor
+        L = _lib.lib()
+        here = os.path.dirname(os.path.abspath(__file__))
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        hdr = so[:-3] + '.h'
+        budget = int(os.environ.get('PJ_ROWS_BUDGET', self.ROWS_BUDGET))
+        fuse = int(os.environ.get('PJ_ROWS_FUSE', self.ROWS_FUSE))
+        rpp = int(os.environ.get('PJ_ROWS_RATES_PER_PART', self.ROWS_RATES_PER_PART))
+        check(L.pj_mech_emit_rows_spec(self._h, hdr.encode(), budget))
+        nblk = int(re.search(r'NBLK = (\d+)', open(hdr).read()).group(1))
+        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        work = so[:-3] + '.obj'
+        os.makedirs(work, exist_ok=True)
+        base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c',
+                '-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
+                os.path.join(here, 'csrc', 'pj_rows.hip')]
+        # rate kernels: fast-math as for the lane kernel.  Row kernels: no reassociation -- it
+        # makes the compiler keep every product of an accumulation chain live (AGPR traffic)
+        f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS', '-ffast-math').split()
+        f_rows = os.environ.get('PJ_ROWS_FLAGS',
+                                '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math').split()
+        jobs = [(f_rows + ['-DPJR_PART=0'], 'host.o')]
+        for i, r0 in enumerate(range(0, self.n_fwd, rpp)):
+            jobs.append((f_rates + ['-DPJR_PART=1', '-DPJR_ID=%d' % i, '-DPJR_R0=%d' % r0,
+                                    '-DPJR_R1=%d' % min(self.n_fwd, r0 + rpp)], 'rates%d.o' % i))
+        for i, b0 in enumerate(range(0, nblk, fuse)):
+            jobs.append((f_rows + ['-DPJR_PART=2', '-DPJR_ID=%d' % i, '-DPJR_B0=%d' % b0,
+                                   '-DPJR_B1=%d' % min(nblk, b0 + fuse)], 'rows%d.o' % i))
+        # longest first so the pool drains evenly
+        jobs.sort(key=lambda j: 0 if j[1].startswith('rates') else 1)
+
+        def run(job):
+            subprocess.check_call(base + job[0] + ['-o', os.path.join(work, job[1])])
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+            list(ex.map(run, jobs))
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] +
+                              [os.path.join(work, j[1]) for j in jobs])
+        shutil.rmtree(work, ignore_errors=True)
 
     @property
     def has_spec(self) -> bool:

@@ -1,0 +1,44 @@
+// hip_shim.h -- just enough of the HIP host/device surface to compile the state-per-lane
+// kernels (pj_lane.hip, pj_rows.hip) with g++ and run them one "thread" per workgroup on the
+// CPU.  Test infrastructure only: lets the CPU suite check the kernels' arithmetic and
+// indexing against the oracle without a GPU.  Build with -DPJR_BLOCK=1 / -DPJL_BLOCK=1.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#define __HIPCC__ 1
+#define __global__
+#define __device__
+#define __host__
+#define __constant__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+static thread_local dim3 threadIdx(0), blockIdx(0), blockDim(1), gridDim(1);
+inline void __syncthreads() {}
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipDeviceAttributeMultiprocessorCount = 0 };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 4; return hipSuccess; }
+template <class K>
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* v, K, int, int) { *v = 1; return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : 2; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+using std::exp; using std::log; using std::fmax;
+
+// one thread per workgroup: blocks run one after the other
+template <class K, class... Args>
+inline void hip_shim_launch(K kernel, dim3 grid, dim3 block, Args... args)
+{
+    if (block.x != 1) abort();
+    gridDim = grid; blockDim = block; threadIdx = dim3(0);
+    for (unsigned b = 0; b < grid.x; ++b) { blockIdx = dim3(b); kernel(args...); }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hip_shim_launch(kernel, grid, block, __VA_ARGS__)
