@@ -84,16 +84,39 @@ def cpu_baseline(w, tables, target_seconds=12.0):
                        'parallel-for over states (%d threads), %.1f s' % (passes, n, cores, dt))
 
 
+def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0):
+    """Evaluator with its mechanism-specific kernels attached.  Prebuilt libraries
+    (__graft_entry__.build()) are used as they are; a missing register-resident (pj_lane)
+    library is compiled here (seconds), by local rank 0 only.  The row-block (pj_rows) libraries
+    of the larger mechanisms take minutes to build and are never compiled inside the bench:
+    without one the table-driven kernel runs."""
+    ev = pyjac_amd.Evaluator(mech, specialize='auto')
+    if not ev.has_spec and ev.spec_kind() == 'lane':
+        if local_rank == 0:
+            ev.specialize(build=True)
+        if dist is not None and dist.is_initialized():
+            dist.barrier()
+        if not ev.has_spec:
+            ev.specialize(build=False)
+    return ev
+
+
+def kernel_label(ev):
+    return {'pj_lane': 'pj_lane (register-resident state-per-lane kernel)',
+            'pj_rows': 'pj_rows (state-per-lane rate + row-block kernels)'}.get(
+                ev.spec_kernel if ev.has_spec else '', 'k_eval (table-driven)')
+
+
 def also_workloads(primary, pyjac_amd, torch, np):
     """Short kernel-only measurements of the other BASELINE.json configurations on
     this GPU (reported next to the headline, never part of `value`)."""
     out = {}
-    for key, n in (('h2', 1_000_000), ('gri', 200_000), ('usc', 50_000)):
+    for key, n in (('h2', 1_000_000), ('gri', 1_000_000), ('usc', 200_000)):
         if key == primary or not os.path.exists(WORKLOADS[key]['mech']):
             continue
         try:
             w = WORKLOADS[key]
-            ev = pyjac_amd.Evaluator(w['mech'], specialize='build')
+            ev = open_mechanism(pyjac_amd, w['mech'])
             pres, y = make_states(w, ev.nsp, n, seed=20240901)
             soa = ev.has_spec or ev.get_launch()['tile_states'] >= 16
             L = pyjac_amd.LAYOUT_SOA if soa else pyjac_amd.LAYOUT_AOS
@@ -106,7 +129,7 @@ def also_workloads(primary, pyjac_amd, torch, np):
             out[key] = dict(workload=w['label'].replace('1e6', '%g' % n).replace('2e5', '%g' % n),
                             states=n, kernel_ms=ms, jacobians_per_s=n / ms * 1e3,
                             achieved_GBps=gbs, frac=gbs / HBM_PEAK_GBPS,
-                            kernel='pj_lane' if ev.has_spec else 'k_eval', launch=ev.get_launch())
+                            kernel=kernel_label(ev), layout='soa' if soa else 'aos')
             del jac, d_y, d_p, ev
             torch.cuda.empty_cache()
         except Exception as ex:
@@ -150,7 +173,7 @@ def main():
         # BASELINE.json configs[1]: the configuration its Target sentence is quoted on
         wl = 'h2'
     w = WORKLOADS[wl]
-    ev = pyjac_amd.Evaluator(w['mech'], specialize='build')
+    ev = open_mechanism(pyjac_amd, w['mech'], dist if world > 1 else None, local_rank)
     n = a.states or w['n']
     # every rank owns n states (weak scaling); global batch = world * n
     pres, y = make_states(w, ev.nsp, n, seed=20240901 + rank)
@@ -231,8 +254,7 @@ def main():
         }
         if validation:
             line['validation_allgather'] = validation
-        line['config']['kernel'] = ('pj_lane (register-resident specialisation)' if ev.has_spec
-                                    else 'k_eval (table-driven)')
+        line['config']['kernel'] = kernel_label(ev)
         if world == 1 and not a.no_also:
             line['also'] = also_workloads(wl, pyjac_amd, torch, np)
         if world == 1 and not a.no_cpu_baseline:

@@ -49,6 +49,9 @@ using namespace pj;
 #ifndef PJR_DEPTH
 #define PJR_DEPTH 16       // visits whose scratch values are in flight
 #endif
+#ifndef PJR_C_LDS
+#define PJR_C_LDS 0         // rate kernels: concentrations in LDS (set for large mechanisms)
+#endif
 #define PJR_TILE 256        // states per scratch tile
 #ifdef PJR_HOST_EMU
 #define PJR_SCHED_BARRIER()
@@ -186,17 +189,34 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
     __shared__ __attribute__((aligned(16))) double LT[(KC_N > 0 ? KC_N : 1) * 16];
     __shared__ __attribute__((aligned(16))) double RDL[R1_ - R0_][RDW];
     __shared__ __attribute__((aligned(16))) double EFL[NEFF];
+#if PJR_C_LDS
+    __shared__ double CLr[NSP][PJR_BLOCK];
+#endif
     for (int w = threadIdx.x; w < KC_N * 16; w += PJR_BLOCK) LT[w] = pjs::LTAB[pjs::LT_KC + KC_LO * 16 + w];
     for (int w = threadIdx.x; w < (R1_ - R0_) * RDW; w += PJR_BLOCK) (&RDL[0][0])[w] = (&pjs::RDT[R0_][0])[w];
     for (int w = threadIdx.x; w < NEFF; w += PJR_BLOCK) EFL[w] = pjs::EFFT[w][0];
     __syncthreads();
     for (long s = (long)blockIdx.x * PJR_BLOCK + threadIdx.x; s < A.n; s += (long)gridDim.x * PJR_BLOCK) {
+#if PJR_C_LDS
+        // large mechanisms: concentrations in LDS (one column per lane) instead of 2*NSP VGPRs
+        double T, p, invrho, Wbar, mconc;
+        {
+            State L;
+            load_state(A, s, L);
+            to_conc(L);
+            T = L.T; p = L.p; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
+            static_for<NSP>([&](auto kc) PJR_INL { CLr[decltype(kc)::value][threadIdx.x] = L.C[decltype(kc)::value]; });
+        }
+#define CC(idx) ((idx) == ONE ? 1.0 : CLr[(idx) == ONE ? 0 : (idx)][threadIdx.x])
+#else
         State L;
         load_state(A, s, L);
         to_conc(L);
-        const double T = L.T, p = L.p, logT = log(T), invT = 1.0 / T, logp = log(p);
+        const double T = L.T, p = L.p;
         const double invrho = L.invrho, Wbar = L.Wbar, mconc = L.mconc;
-        const double* C = L.C;
+#define CC(idx) L.C[idx]
+#endif
+        const double logT = log(T), invT = 1.0 / T, logp = log(p);
         double* const scr = scr_of(A, s);
 #define SCR_(slot) scr[(long)(slot) * PJR_SSTRIDE(A)]
         double* const Jl = A.jac + s * A.j_ss;
@@ -267,8 +287,8 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
                 TdlnKc = tdk[kcls];
             }
 
-            const double cr0 = C[pjs::RI[i][RI_R0]], cr1 = C[pjs::RI[i][RI_R1]], cr2 = C[pjs::RI[i][RI_R2]];
-            const double cp0 = C[pjs::RI[i][RI_P0]], cp1 = C[pjs::RI[i][RI_P1]], cp2 = C[pjs::RI[i][RI_P2]];
+            const double cr0 = CC(pjs::RI[i][RI_R0]), cr1 = CC(pjs::RI[i][RI_R1]), cr2 = CC(pjs::RI[i][RI_R2]);
+            const double cp0 = CC(pjs::RI[i][RI_P0]), cp1 = CC(pjs::RI[i][RI_P1]), cp2 = CC(pjs::RI[i][RI_P2]);
             const double Rf = kf * (cr0 * cr1 * cr2);
             const double Rr = kr * (cp0 * cp1 * cp2);
             const double R = Rf - Rr;
@@ -278,7 +298,7 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
                 double Mc = mconc;
                 static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
                     constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
-                    Mc += EFL[e] * C[pjs::EFF_SP[e][0]];
+                    Mc += EFL[e] * CC(pjs::EFF_SP[e][0]);
                 });
                 if constexpr ((fl & F_THD) != 0) {
                     c = Mc;
@@ -287,7 +307,7 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
                 } else {
                     constexpr int col = pjs::RI[i][RI_COLLIDER];
                     double conc_temp = Mc;
-                    if constexpr (col >= 0) conc_temp = C[col >= 0 ? col : 0];
+                    if constexpr (col >= 0) conc_temp = CC(col >= 0 ? col : 0);
                     const double e0T = rd[RD_E0] * invT;
                     const double k0kinf = exp(rd[RD_LNAR] + rd[RD_B0] * logT - e0T);
                     const double Pr = conc_temp * k0kinf;
@@ -375,6 +395,7 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
         if constexpr (R0_ == 0) SCR_(SUM_SJT) = sjt; else SCR_(SUM_SJT) += sjt;
 #undef J_
 #undef SCR_
+#undef CC
     }
 }
 

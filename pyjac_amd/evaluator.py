@@ -44,6 +44,7 @@ class Evaluator:
         self.n_fwd = L.pj_mech_fwd_rates(h)
         self.n_rev = L.pj_mech_rev_rates(h)
         self.n_pres_mod = L.pj_mech_pres_mod_rates(h)
+        self.attached_spec = None
         if specialize != 'off':
             self.specialize(build=(specialize == 'build'))
 
@@ -55,26 +56,31 @@ class Evaluator:
     ROWS_FUSE = 16            # row blocks per kernel
     ROWS_RATES_PER_PART = 128  # reactions per rate kernel (its coefficient tables sit in LDS)
 
-    def spec_path(self) -> str:
-        h = _lib.lib().pj_mech_spec_hash(self._h)
-        return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'spec', 'libpj_spec_%016x.so' % h)
-
     def spec_kind(self) -> str:
         """Which specialised kernel family specialize(build=True) compiles for this mechanism."""
         return 'lane' if self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN else 'rows'
 
-    def specialize(self, build: bool = False, kind: str = None) -> bool:
-        """Attach (and optionally build) the mechanism-specific kernels."""
+    def spec_path(self, kind: str = None) -> str:
+        h = _lib.lib().pj_mech_spec_hash(self._h)
+        stem = 'libpj_spec_%016x.so' if (kind or self.spec_kind()) == 'lane' else 'libpj_rows_%016x.so'
+        return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'spec', stem % h)
+
+    def specialize(self, build: bool = False, kind: str = None, **rows_opts) -> bool:
+        """Attach (and with build=True compile if missing) the mechanism-specific kernels.
+        kind: 'lane' | 'rows' | None (whatever is there, else the default for the size)."""
         L = _lib.lib()
-        so = self.spec_path()
-        if not os.path.exists(so):
+        kinds = [kind] if kind else [self.spec_kind()] + [k for k in ('lane', 'rows') if k != self.spec_kind()]
+        so = next((self.spec_path(k) for k in kinds if os.path.exists(self.spec_path(k))), None)
+        if so is None:
             if not build:
                 return False
-            if (kind or self.spec_kind()) == 'lane':
+            so = self.spec_path(kinds[0])
+            if kinds[0] == 'lane':
                 self._build_lane(so)
             else:
-                self._build_rows(so)
+                self._build_rows(so, **rows_opts)
         check(L.pj_mech_attach_spec(self._h, so.encode()))
+        self.attached_spec = so
         return True
 
     def _build_lane(self, so: str):
@@ -93,7 +99,7 @@ class Evaluator:
                               ['-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
                                '-o', so, os.path.join(here, 'csrc', 'pj_lane.hip')])
 
-    def _build_rows(self, so: str):
+    def _build_rows(self, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None):
         """One translation unit per kernel of csrc/pj_rows.hip, compiled in parallel."""
         import re
         import shutil
@@ -103,17 +109,19 @@ class Evaluator:
         here = os.path.dirname(os.path.abspath(__file__))
         os.makedirs(os.path.dirname(so), exist_ok=True)
         hdr = so[:-3] + '.h'
-        budget = int(os.environ.get('PJ_ROWS_BUDGET', self.ROWS_BUDGET))
-        fuse = int(os.environ.get('PJ_ROWS_FUSE', self.ROWS_FUSE))
-        rpp = int(os.environ.get('PJ_ROWS_RATES_PER_PART', self.ROWS_RATES_PER_PART))
+        budget = int(budget or os.environ.get('PJ_ROWS_BUDGET', self.ROWS_BUDGET))
+        fuse = int(fuse or os.environ.get('PJ_ROWS_FUSE', self.ROWS_FUSE))
+        rpp = int(rates_per_part or os.environ.get('PJ_ROWS_RATES_PER_PART', self.ROWS_RATES_PER_PART))
         check(L.pj_mech_emit_rows_spec(self._h, hdr.encode(), budget))
         nblk = int(re.search(r'NBLK = (\d+)', open(hdr).read()).group(1))
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
         work = so[:-3] + '.obj'
         os.makedirs(work, exist_ok=True)
+        # lanes per workgroup: the concentration columns (8 NSP bytes per lane) must fit the LDS
+        block = 256 if self.nsp * 256 * 8 <= 150 * 1024 else 128 if self.nsp * 128 * 8 <= 150 * 1024 else 64
         base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c',
-                '-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
-                os.path.join(here, 'csrc', 'pj_rows.hip')]
+                '-DPJS_HEADER="%s"' % hdr, '-DPJR_BLOCK=%d' % block, '-DPJR_C_LDS=%d' % int(self.nsp > 64),
+                '-I', os.path.join(here, 'csrc'), os.path.join(here, 'csrc', 'pj_rows.hip')]
         # rate kernels: fast-math as for the lane kernel.  Row kernels: no reassociation -- it
         # makes the compiler keep every product of an accumulation chain live (AGPR traffic)
         f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS', '-ffast-math').split()
@@ -136,6 +144,12 @@ class Evaluator:
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] +
                               [os.path.join(work, j[1]) for j in jobs])
         shutil.rmtree(work, ignore_errors=True)
+
+    @property
+    def spec_kernel(self) -> str:
+        """'pj_lane' / 'pj_rows' for the attached specialisation, '' if none."""
+        so = os.path.basename(self.attached_spec or '')
+        return 'pj_lane' if so.startswith('libpj_spec_') else 'pj_rows' if so.startswith('libpj_rows_') else ''
 
     @property
     def has_spec(self) -> bool:

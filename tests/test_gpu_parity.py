@@ -178,16 +178,23 @@ def test_empty_and_single_state(torch_cuda):
 
 @pytest.mark.parametrize('name,n', [('gri30_shaped', 300), ('usc2_shaped', 60)])
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
-def test_large_mechanisms_vs_oracle(name, n, layout, tables, torch_cuda):
+@pytest.mark.parametrize('kernel', ['pj_rows', 'k_eval'])
+def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda):
     """Configs 3-5 (GRI-3.0-shaped 53 sp / 325 rxn; USC-II-shaped 111 sp / 784 rxn
-    with PLOG; the species order is permuted so N2 ends up last)."""
+    with PLOG; the species order is permuted so N2 ends up last), through the state-per-lane
+    row-block kernels (csrc/pj_rows.hip, prebuilt by __graft_entry__.build()) and through the
+    table-driven kernel."""
     import pyjac_amd
     from oracle.oracle import Oracle
     from pyjac_amd import synth
     torch = torch_cuda
     ev = _ev(name)
-    if ev.get_launch()['lds_bytes'] > 160 * 1024:
-        pytest.skip('working set of one state exceeds LDS: %d B' % ev.get_launch()['lds_bytes'])
+    if kernel == 'pj_rows':
+        assert ev.has_spec and ev.spec_kernel == 'pj_rows', 'row-block library missing: run __graft_entry__.build()'
+    else:
+        ev.use_spec(False)
+        if ev.get_launch()['lds_bytes'] > 160 * 1024:
+            pytest.skip('working set of one state exceeds LDS: %d B' % ev.get_launch()['lds_bytes'])
     pres, y = synth.dist_b(n, ev.nsp, seed=21, Tlo=500, Thi=2600)
     d_p = torch.from_numpy(pres).cuda()
     if layout == 'soa':
@@ -234,6 +241,65 @@ def test_specialised_lane_kernel(name, layout, tables, torch_cuda):
     assert mx < RTOL and fro < 1e-9, ('spec vs table-driven', mx, fro)
 
 
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_row_block_kernels_all_reaction_types(layout, tables, torch_cuda):
+    """csrc/pj_rows.hip on the mechanism that holds every supported reaction type, built with a
+    deliberately fine partition (several rate kernels, several row kernels, multi-row blocks):
+    against the oracle, against the table-driven kernel, with and without the J_nplusone quirk,
+    on a batch that spans scratch tiles and ends mid-wavefront."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    name = 'synth_alltypes'
+    ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
+    assert ev.specialize(build=True, kind='rows', budget=16, fuse=3, rates_per_part=7)
+    assert ev.spec_kernel == 'pj_rows'
+    n = 4099
+    pres, y = synth.dist_b(n, ev.nsp, seed=31, Tlo=400, Thi=2800)
+    pres = 101325 * 10 ** np.random.default_rng(8).uniform(-1.5, 1.5, n)
+    d_p = torch.from_numpy(pres).cuda()
+    if layout == 'soa':
+        d_y, L = torch.from_numpy(y).cuda(), pyjac_amd.LAYOUT_SOA
+    else:
+        d_y, L = torch.from_numpy(np.ascontiguousarray(y.T)).cuda(), pyjac_amd.LAYOUT_AOS
+    o = Oracle(tables(name))
+    for sum_last in (0, 1):
+        ev.set_sum_last_species(bool(sum_last))
+        ev.use_spec(True)
+        spec = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+        ev.use_spec(False)
+        gen = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+        if layout == 'soa':
+            spec, gen = spec.T, gen.T
+        o.lib.pjo_set_sum_last_species(sum_last)
+        try:
+            ref = o.batch_jacob(pres, np.ascontiguousarray(y.T))
+        finally:
+            o.lib.pjo_set_sum_last_species(0)
+        mx, fro = thresholded_rel_err(spec, ref)
+        assert mx < RTOL and fro < 1e-9, (layout, sum_last, mx, fro)
+        mx, fro = thresholded_rel_err(spec, gen)
+        assert mx < RTOL and fro < 1e-9, ('rows vs table-driven', sum_last, mx, fro)
+
+
+def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
+    """A batch larger than the scratch chunk (PJ_ROWS_CHUNK) runs as several chunks through the
+    same scratch array; results must not depend on the chunking."""
+    import pyjac_amd
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev('gri30_shaped')
+    assert ev.spec_kernel == 'pj_rows'
+    n = 3000
+    pres, y = synth.dist_b(n, ev.nsp, seed=77)
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    whole = ev.jacobian(d_p, d_y).clone()
+    monkeypatch.setenv('PJ_ROWS_CHUNK', '1024')
+    parts = ev.jacobian(d_p, d_y)
+    assert torch.equal(whole, parts)
+
+
 def test_finite_difference_arm(tables, torch_cuda):
     """N3: the reference's FD Jacobian (fd_jacob.c) on the GPU dydt.  A forward difference
     amplifies the ~1e-16 differences between GPU and CPU dydt by 1/r ~ 1e8 / |y_j|, so the
@@ -268,9 +334,13 @@ def test_large_mechanisms_vs_reference_golden(name, golden, torch_cuda):
     ev = _ev(name)
     d_p = torch.from_numpy(g['pres'].copy()).cuda()
     d_y = torch.from_numpy(np.ascontiguousarray(g['y'])).cuda()
-    jac = ev.jacobian(d_p, d_y, y_layout=pyjac_amd.LAYOUT_AOS, jac_layout=pyjac_amd.LAYOUT_AOS).cpu().numpy()
-    mx, fro = thresholded_rel_err(jac, g['jac'])
-    assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0 and fro < 1e-9, (name, mx, fro)
+    for use in (True, False):       # row-block kernels, then the table-driven kernel
+        ev.use_spec(use)
+        if not use and ev.get_launch()['lds_bytes'] > 160 * 1024:
+            continue
+        jac = ev.jacobian(d_p, d_y, y_layout=pyjac_amd.LAYOUT_AOS, jac_layout=pyjac_amd.LAYOUT_AOS).cpu().numpy()
+        mx, fro = thresholded_rel_err(jac, g['jac'])
+        assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0 and fro < 1e-9, (name, use, mx, fro)
     r = ev.rates(d_p, d_y, y_layout=pyjac_amd.LAYOUT_AOS)
     for k, rows in (('conc', ev.nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
         mx, fro = thresholded_rel_err(r[k].cpu().numpy().T[:, :rows], g[k][:, :rows])
