@@ -53,6 +53,12 @@ using namespace pj;
 #define PJR_C_LDS 0         // rate kernels: concentrations in LDS (set for large mechanisms)
 #endif
 #define PJR_TILE 256        // states per scratch tile
+// Jacobian entries are written once and never read back by these kernels
+#if defined(PJR_NT_STORE) && PJR_NT_STORE && !defined(PJR_HOST_EMU)
+#define PJR_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define PJR_STORE(ptr, val) (*(ptr) = (val))
+#endif
 #ifdef PJR_HOST_EMU
 #define PJR_SCHED_BARRIER()
 #else
@@ -100,9 +106,6 @@ __device__ __forceinline__ void static_range(F&& f)
 // contiguous (NSCR + 3) * 2 KB region (DRAM-page and TLB locality), each wave access is 512 B
 #ifndef PJR_SCR_TILED
 #define PJR_SCR_TILED 1
-#endif
-#ifndef PJR_XPIPE
-#define PJR_XPIPE 0        // 1: issue the next block's first loads before this block's stores (measured: -7 %)
 #endif
 #if PJR_SCR_TILED
 #define PJR_SSTRIDE(A) PJR_TILE
@@ -233,144 +236,15 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
         static_for<NSP>([&](auto kc) PJR_INL { jt[decltype(kc)::value] = 0.0; });
         static_range<R0_, R1_>([&](auto ic) PJR_INL {
             constexpr int i = decltype(ic)::value;
-            constexpr int fl = pjs::RI[i][RI_FLAGS];
-            const double* rd = RDL[i - R0_];
-            double lnk, dlnk;
-            if constexpr ((fl & F_PLOG) != 0) {
-                constexpr int pp = pjs::RI[i][RI_PLOG_PTR], np = pjs::RI[i][RI_PLOG_CNT];
-                // interval select chain over the breakpoints (rate_subs.py:598-632)
-                lnk = pjs::PLOG[pp][2] + pjs::PLOG[pp][3] * logT - pjs::PLOG[pp][4] * invT;
-                dlnk = pjs::PLOG[pp][3] + pjs::PLOG[pp][4] * invT;
-                static_for<np - 1>([&](auto qc) PJR_INL {
-                    constexpr int q = decltype(qc)::value + 1;
-                    constexpr double P1 = pjs::PLOG[pp + q - 1][0], L1 = pjs::PLOG[pp + q - 1][1],
-                                     A1 = pjs::PLOG[pp + q - 1][2], B1 = pjs::PLOG[pp + q - 1][3],
-                                     E1 = pjs::PLOG[pp + q - 1][4];
-                    constexpr double P2 = pjs::PLOG[pp + q][0], L2 = pjs::PLOG[pp + q][1],
-                                     A2 = pjs::PLOG[pp + q][2], B2 = pjs::PLOG[pp + q][3],
-                                     E2 = pjs::PLOG[pp + q][4];
-                    const double k1 = A1 + B1 * logT - E1 * invT;
-                    const double k2 = A2 + B2 * logT - E2 * invT;
-                    const double f = (logp - L1) / (L2 - L1);
-                    const bool in = p > P1 && p <= P2;
-                    lnk = in ? k1 + (k2 - k1) * f : lnk;
-                    dlnk = in ? B1 + E1 * invT + ((B2 - B1) + (E2 - E1) * invT) * f : dlnk;
-                });
-                {
-                    constexpr double Pn = pjs::PLOG[pp + np - 1][0], An = pjs::PLOG[pp + np - 1][2],
-                                     Bn = pjs::PLOG[pp + np - 1][3], En = pjs::PLOG[pp + np - 1][4];
-                    const bool hi = p > Pn;
-                    lnk = hi ? An + Bn * logT - En * invT : lnk;
-                    dlnk = hi ? Bn + En * invT : dlnk;
-                }
-            } else {
-                lnk = rd[RD_LNA] + rd[RD_B] * logT - rd[RD_TA] * invT;
-                dlnk = rd[RD_B] + rd[RD_TA] * invT;
-            }
-            const double kf = (pjs::RD[i][RD_SGN] < 0.0) ? -exp(lnk) : exp(lnk);
-
-            double kr = 0.0, TdlnKc = 0.0;
-            if constexpr ((fl & F_REV) != 0) {
-                constexpr int kcls = pjs::KC_CLASS[i][0];
-                if constexpr (kc_first_in_range(i)) {
-                    double lnKc = rd[RD_LNPREF], td = 0.0;
-                    static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJR_INL {
-                        constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
-                        const double* a = LT + (g - KC_LO) * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
-                        lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
-                        td += a[1] + T * (a[2] + T * (2.0 * a[3] + T * (3.0 * a[4] + 4.0 * a[5] * T))) + a[6] * invT;
-                    });
-                    ekc[kcls] = exp(-lnKc);
-                    tdk[kcls] = td;
-                }
-                kr = kf * ekc[kcls];
-                TdlnKc = tdk[kcls];
-            }
-
-            const double cr0 = CC(pjs::RI[i][RI_R0]), cr1 = CC(pjs::RI[i][RI_R1]), cr2 = CC(pjs::RI[i][RI_R2]);
-            const double cp0 = CC(pjs::RI[i][RI_P0]), cp1 = CC(pjs::RI[i][RI_P1]), cp2 = CC(pjs::RI[i][RI_P2]);
-            const double Rf = kf * (cr0 * cr1 * cr2);
-            const double Rr = kr * (cp0 * cp1 * cp2);
-            const double R = Rf - Rr;
-
-            double c = 1.0, lead = 0.0, a_extra = 0.0, bM = 0.0, bcol = 0.0;
-            if constexpr ((fl & (F_THD | F_PDEP)) != 0) {
-                double Mc = mconc;
-                static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
-                    constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
-                    Mc += EFL[e] * CC(pjs::EFF_SP[e][0]);
-                });
-                if constexpr ((fl & F_THD) != 0) {
-                    c = Mc;
-                    lead = -c * R * invT;
-                    if constexpr ((fl & F_EFFTYPE) != 0) { bM = R; a_extra = c * R; }
-                } else {
-                    constexpr int col = pjs::RI[i][RI_COLLIDER];
-                    double conc_temp = Mc;
-                    if constexpr (col >= 0) conc_temp = CC(col >= 0 ? col : 0);
-                    const double e0T = rd[RD_E0] * invT;
-                    const double k0kinf = exp(rd[RD_LNAR] + rd[RD_B0] * logT - e0T);
-                    const double Pr = conc_temp * k0kinf;
-                    const double i1Pr = 1.0 / (1.0 + Pr);
-                    double F = 1.0, extra = 0.0, Xtroe = 0.0;
-                    if constexpr ((fl & F_TROE) != 0) {
-                        const double ta = rd[RD_TRA], T3 = rd[RD_T3], T1 = rd[RD_T1], T2 = rd[RD_T2];
-                        const double e3 = exp(-T / T3), e1 = exp(-T / T1);
-                        double Fcent = (1.0 - ta) * e3 + ta * e1;
-                        double dF = -((1.0 - ta) / T3) * e3 - (ta / T1) * e1;
-                        if constexpr ((fl & F_TROE4) != 0) {
-                            const double e2 = exp(-T2 * invT);
-                            Fcent += e2;
-                            dF += T2 * invT * invT * e2;
-                        }
-                        const double lF = log(fmax(Fcent, 1.0e-300));
-                        const double lgF = lF * INV_LN10;
-                        const double lgPr = log(fmax(Pr, 1.0e-300)) * INV_LN10;
-                        const double At = lgPr - 0.67 * lgF - 0.4;
-                        const double Bt = 0.806 - 1.1762 * lgF - 0.14 * lgPr;
-                        const double iB = 1.0 / Bt;
-                        const double iden = 1.0 / (1.0 + At * At * iB * iB);
-                        F = exp(lF * iden);
-                        const double lnF_AB = 2.0 * lF * At * iB * iB * iB * iden * iden;
-                        const double iFc = 1.0 / Fcent;
-                        Xtroe = lnF_AB * (INV_LN10 * Bt + (0.14 * INV_LN10) * At);
-                        extra = (iFc * iden - lnF_AB * (-(0.67 * INV_LN10) * Bt + (1.1762 * INV_LN10) * At) * iFc) * dF -
-                                Xtroe * (rd[RD_B0] + e0T - 1.0) * invT;
-                    }
-                    double dpr = (rd[RD_B04] + e0T - 1.0) * invT * i1Pr;
-                    double X;
-                    if constexpr ((fl & F_LOW) != 0) { c = F * Pr * i1Pr; X = i1Pr - Xtroe; }
-                    else { c = F * i1Pr; X = -Pr * i1Pr - Xtroe; dpr = -Pr * dpr; }
-                    lead = c * (dpr + extra) * R;
-                    if constexpr ((fl & (F_EFFTYPE | F_COLLIDER)) != 0) {
-                        const double pmt = X * R;
-                        a_extra = c * pmt;
-                        const double bb = pmt * k0kinf * F * i1Pr;
-                        if constexpr ((fl & F_COLLIDER) != 0) bcol = bb; else bM = bb;
-                    }
-                }
-            }
-
-            constexpr double nr = pjs::RD[i][RD_NR], np_ = pjs::RD[i][RD_NP];
-            if constexpr ((fl & F_NO_DT) == 0) {
-                double el = R * dlnk + Rf * (1.0 - nr);
-                if constexpr ((fl & F_REV) != 0) el -= Rr * ((1.0 - np_) - TdlnKc);
-                const double theta = (lead + c * invT * el) * invrho;
-                static_for<pjs::RI[i][RI_NET_CNT]>([&](auto qc) PJR_INL {
-                    constexpr int q = pjs::RI[i][RI_NET_PTR] + decltype(qc)::value;
-                    constexpr int k = pjs::NET_SP[q][0];
-                    jt[k] += pjs::NET_NU[q][0] * theta;
-                    if constexpr (k == LAST && i == pjs::LASTQ) jtq = pjs::NET_NU[q][0] * theta;
-                });
-            }
-            SCR_(pjs::SCR[i][S_KF]) = c * kf;
-            if constexpr (pjs::SCR[i][S_KR] >= 0) SCR_(pjs::SCR[i][S_KR]) = c * kr;
-            if constexpr (pjs::SCR[i][S_RP] >= 0) {
-                const double a = c * (nr * Rf - ((fl & F_REV) ? np_ * Rr : 0.0)) + a_extra;
-                SCR_(pjs::SCR[i][S_RP]) = (Wbar * invrho) * (c * R - a) + bM;
-            }
-            if constexpr (pjs::SCR[i][S_BM] >= 0) SCR_(pjs::SCR[i][S_BM]) = bM;
-            if constexpr (pjs::SCR[i][S_BC] >= 0) SCR_(pjs::SCR[i][S_BC]) = bcol;
+#define PJR_RD(i_) RDL[(i_) - R0_]
+#define PJR_KCROW(g_) (LT + ((g_) - KC_LO) * 16)
+#define PJR_EFL(e_) EFL[e_]
+#define PJR_KC_FIRST(i_) kc_first_in_range(i_)
+#include "pj_rows_rate.inc"
+#undef PJR_RD
+#undef PJR_KCROW
+#undef PJR_EFL
+#undef PJR_KC_FIRST
         });
         // reference quirk (create_jacobian.py:2786-2818): the last species keeps only the d/dT
         // term of one reaction unless sum_last is set (see pj_kernel.h)
@@ -473,135 +347,9 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
         constexpr int nv = pjs::BLK_RX_PTR[b + 1][0] - pjs::BLK_RX_PTR[b][0];
         static_for<(nv < PJR_DEPTH ? nv : PJR_DEPTH)>([&](auto vc) PJR_INL { issue_bv(bc, vc); });
     };
-    prologue(std::integral_constant<int, B0_>{});
-
     static_range<B0_, B1_>([&](auto bc) PJR_INL {
         constexpr int b = decltype(bc)::value;
-#if !PJR_XPIPE
-        if constexpr (b > B0_) prologue(bc);
-#endif
-        constexpr int r0 = pjs::BLK_ROW_PTR[b][0], nrows = pjs::BLK_ROW_PTR[b + 1][0] - r0;
-        constexpr int v0 = pjs::BLK_RX_PTR[b][0], nv = pjs::BLK_RX_PTR[b + 1][0] - v0;
-        double om[nrows], P[nrows], Q[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
-        static_for<nrows>([&](auto rc) PJR_INL {
-            constexpr int r = decltype(rc)::value;
-            om[r] = 0.0; P[r] = 0.0; Q[r] = 0.0;
-        });
-        static_for<pjs::BLK_NNZ[b][0]>([&](auto ec) PJR_INL { S[decltype(ec)::value] = 0.0; });
-
-        auto issue = [&](auto vc) PJR_INL { issue_bv(bc, vc); };
-        static_for<nv>([&](auto vc) PJR_INL {
-            constexpr int v = decltype(vc)::value;
-            constexpr int i = pjs::BLK_RX[v0 + v][0];
-            constexpr int fl = pjs::RI[i][RI_FLAGS];
-            double ckr = 0.0, bM = 0.0, bcol = 0.0, rp_ld = 0.0;
-            const double ckf = ring[v % PJR_DEPTH][S_KF];
-            if constexpr (pjs::SCR[i][S_KR] >= 0) ckr = ring[v % PJR_DEPTH][S_KR];
-            if constexpr (pjs::SCR[i][S_RP] >= 0) rp_ld = ring[v % PJR_DEPTH][S_RP];
-            if constexpr (pjs::SCR[i][S_BM] >= 0) bM = ring[v % PJR_DEPTH][S_BM];
-            if constexpr (pjs::SCR[i][S_BC] >= 0) bcol = ring[v % PJR_DEPTH][S_BC];
-            if constexpr (v + PJR_DEPTH < nv) issue(std::integral_constant<int, v + PJR_DEPTH>{});
-            const double cr0 = conc(std::integral_constant<int, pjs::RI[i][RI_R0]>{}),
-                         cr1 = conc(std::integral_constant<int, pjs::RI[i][RI_R1]>{}),
-                         cr2 = conc(std::integral_constant<int, pjs::RI[i][RI_R2]>{});
-            const double cp0 = conc(std::integral_constant<int, pjs::RI[i][RI_P0]>{}),
-                         cp1 = conc(std::integral_constant<int, pjs::RI[i][RI_P1]>{}),
-                         cp2 = conc(std::integral_constant<int, pjs::RI[i][RI_P2]>{});
-            const double Rf = ckf * (cr0 * cr1 * cr2);       // c * R_f
-            const double Rr = ckr * (cp0 * cp1 * cp2);       // c * R_r
-            const double q_ = Rf - Rr;
-            constexpr double nr = pjs::RD[i][RD_NR], np_ = pjs::RD[i][RD_NP];
-            double rp;
-            if constexpr (pjs::SCR[i][S_RP] >= 0) rp = rp_ld;
-            else rp = (Wbar * invrho) * ((1.0 - nr) * Rf - ((fl & F_REV) ? (1.0 - np_) * Rr : 0.0));
-
-            double gN = 0.0;
-            if constexpr (has_anm1<i>()) gN = bM * pjs::RD[i][RD_ANM1];
-            constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
-            auto slot = [&](auto spc, const double gv) PJR_INL {
-                constexpr int sp = decltype(spc)::value;
-                if constexpr (sp == LAST) gN += gv;
-                else if constexpr (sp != ONE) {
-                    static_for<ncnt>([&](auto qc) PJR_INL {
-                        constexpr int q = np0 + decltype(qc)::value;
-                        constexpr int k = pjs::NET_SP[q][0];
-                        if constexpr (pjs::ROW_BLK[k][0] == b) {
-                            constexpr int si = pjs::SLOC[k][sp];
-                            static_assert(si >= 0, "sparse pattern and program disagree");
-                            S[si] += pjs::NET_NU[q][0] * gv;
-                        }
-                    });
-                }
-            };
-            slot(std::integral_constant<int, pjs::RI[i][RI_R0]>{}, ckf * (cr1 * cr2));
-            slot(std::integral_constant<int, pjs::RI[i][RI_R1]>{}, ckf * (cr0 * cr2));
-            slot(std::integral_constant<int, pjs::RI[i][RI_R2]>{}, ckf * (cr0 * cr1));
-            if constexpr ((fl & F_REV) != 0) {
-                slot(std::integral_constant<int, pjs::RI[i][RI_P0]>{}, -ckr * (cp1 * cp2));
-                slot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -ckr * (cp0 * cp2));
-                slot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -ckr * (cp0 * cp1));
-            }
-            if constexpr ((fl & F_COLLIDER) != 0)
-                slot(std::integral_constant<int, (pjs::RI[i][RI_COLLIDER] >= 0 ? pjs::RI[i][RI_COLLIDER] : ONE)>{}, bcol);
-            if constexpr ((fl & F_EFFTYPE) != 0) {
-                static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
-                    constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
-                    constexpr int es = pjs::EFF_SP[e][0];
-                    // the last species' enhanced efficiency is already in gN (RD_ANM1)
-                    if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, pjs::EFF_AM1[e][0] * bM);
-                });
-            }
-            const double rq = rp + gN;
-            static_for<ncnt>([&](auto qc) PJR_INL {
-                constexpr int q = np0 + decltype(qc)::value;
-                constexpr int k = pjs::NET_SP[q][0];
-                if constexpr (pjs::ROW_BLK[k][0] == b) {
-                    constexpr int r = pjs::ROWLOC[k][0];
-                    constexpr double nu = pjs::NET_NU[q][0];
-                    om[r] += nu * q_;
-                    P[r] += nu * rp;
-                    Q[r] += nu * rq;
-                }
-            });
-            PJR_SCHED_BARRIER();
-        });
-#if PJR_XPIPE
-        if constexpr (b + 1 < B1_) prologue(std::integral_constant<int, b + 1>{});
-        PJR_SCHED_BARRIER();
-#endif
-
-        // rows of this block: NASA properties of its species, outputs, energy-row partials
-        double hW[nrows];
-        static_for<nrows>([&](auto rc) PJR_INL {
-            constexpr int r = decltype(rc)::value;
-            constexpr int k = pjs::BLK_ROWS[r0 + r][0];
-            const bool lo = T <= pjs::SP[k][2];
-            double a[6];
-            static_for<6>([&](auto cc) PJR_INL {
-                constexpr int c = decltype(cc)::value;
-                a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
-            });
-            hW[r] = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
-                           T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
-            const double cpk = (RU_ * pjs::SP[k][0]) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
-            H += hW[r] * om[r];
-            SCP += om[r] * pjs::SP[k][1] * cpk;
-        });
-        static_for<LAST>([&](auto jc) PJR_INL {
-            constexpr int j = decltype(jc)::value;
-            constexpr double wj = pjs::SP[j][3], iWj = pjs::SP[j][0];
-            double tot = 0.0;
-            static_for<nrows>([&](auto rc) PJR_INL {
-                constexpr int r = decltype(rc)::value;
-                constexpr int k = pjs::BLK_ROWS[r0 + r][0];
-                constexpr int si = pjs::SLOC[k][j];
-                double m = P[r] - wj * Q[r];
-                if constexpr (si >= 0) m += S[si];
-                tot += hW[r] * m;
-                if constexpr (k < LAST) J_(k + 1 + NSP * (j + 1)) = (pjs::SP[k][1] * iWj) * m;
-            });
-            E[j] += tot;
-        });
+#include "pj_rows_block.inc"
     });
 
     // hand the partial sums to k_fin through memory (kernels of one batch run in stream order)
