@@ -103,7 +103,8 @@ def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0):
 
 def kernel_label(ev):
     return {'pj_lane': 'pj_lane (register-resident state-per-lane kernel)',
-            'pj_rows': 'pj_rows (state-per-lane rate + row-block kernels)'}.get(
+            'pj_rows': 'pj_rows (state-per-lane rate + row-block kernels)',
+            'pj_fused': 'pj_rows fused (4 wavefronts per 64-state tile, one kernel)'}.get(
                 ev.spec_kernel if ev.has_spec else '', 'k_eval (table-driven)')
 
 

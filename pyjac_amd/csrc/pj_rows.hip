@@ -28,6 +28,7 @@
 //
 // PJR_PART = 0: host entry points + k_fin;  PJR_PART = 1: k_rates<PJR_R0,PJR_R1>;
 // PJR_PART = 2: k_rows<PJR_B0,PJR_B1>.  PJR_ID is the launch-order index of the part.
+// PJR_PART = 3: the fused single-kernel variant (k_fused, one translation unit, own host entry).
 #ifdef PJR_HOST_EMU
 #include "hip_shim.h"
 #else
@@ -52,6 +53,7 @@ using namespace pj;
 #ifndef PJR_C_LDS
 #define PJR_C_LDS 0         // rate kernels: concentrations in LDS (set for large mechanisms)
 #endif
+#define PJR_TICK_B(ph)      // phase timing hook of debug builds (fused kernel, -DPJR_TIMING)
 #define PJR_TILE 256        // states per scratch tile
 // Jacobian entries are written once and never read back by these kernels
 #if defined(PJR_NT_STORE) && PJR_NT_STORE && !defined(PJR_HOST_EMU)
@@ -347,6 +349,10 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
         constexpr int nv = pjs::BLK_RX_PTR[b + 1][0] - pjs::BLK_RX_PTR[b][0];
         static_for<(nv < PJR_DEPTH ? nv : PJR_DEPTH)>([&](auto vc) PJR_INL { issue_bv(bc, vc); });
     };
+#define PJR_SP(k_, c_) pjs::SP[k_][c_]
+#define PJR_EFF(e_) pjs::EFF_AM1[e_][0]
+#define PJR_NASA(k_, lo_, c_) ((lo_) ? pjs::SP[k_][4 + (c_)] : pjs::SP[k_][11 + (c_)])
+#define PJR_ANM1(i_) pjs::RD[i_][RD_ANM1]
     static_range<B0_, B1_>([&](auto bc) PJR_INL {
         constexpr int b = decltype(bc)::value;
 #include "pj_rows_block.inc"
@@ -371,6 +377,297 @@ void launch_part(const PjrArgs& A, void* stream)
 }
 struct Reg { Reg() { pjr_register(PJR_ID, 2, launch_part); } } reg_;
 #endif  // PJR_PART == 2
+
+#if PJR_PART == 3
+// ------------------------------------------------------------------------------------------
+// k_fused: the whole Jacobian of a 64-state tile by one workgroup of 4 wavefronts.
+//
+// The multi-kernel path above is HBM-bound on its scratch traffic (every c*k_f / c*k_r is written
+// once and re-read ~3.6 times, 2.8x the algorithmic bytes in total).  Here the four wavefronts of
+// a workgroup own the SAME 64 states and split the work instead of the states (reaction i ->
+// wavefront i % 4, row blocks dealt by estimated cost: pjs::ARM_BLKS), and resident workgroups walk the state tiles,
+// so the scratch array is one fixed (NSCR x 64 doubles) region per resident workgroup, ~100 MB for
+// the whole device: rewritten and re-read every tile, it stays in the 256 MB Infinity Cache while
+// the Jacobian streams out through nontemporal stores.  Cross-wavefront sums (d/dT column, energy
+// row, H / SCP / SJT) go through LDS atomics; nothing but T, p, Y is read from and nothing but the
+// Jacobian is written to memory outside that region.
+// ------------------------------------------------------------------------------------------
+#ifndef PJR_WLANES
+#define PJR_WLANES 64      // lanes per wavefront = states per tile
+#endif
+#ifndef PJR_NW
+#define PJR_NW 4           // wavefronts per workgroup; arm a runs on wavefront a % PJR_NW
+#endif
+constexpr int NARM = 4;
+constexpr int NKC = pjs::LT_SP / 16;
+constexpr int NEFF = (int)(sizeof(pjs::EFF_AM1) / sizeof(pjs::EFF_AM1[0]));
+template <int i>
+constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
+// first reaction of its arm that uses a K_c class evaluates it
+constexpr bool kc_first_arm(int i)
+{
+    for (int h = i % NARM; h < i; h += NARM)
+        if ((pjs::RI[h][RI_FLAGS] & F_REV) && pjs::KC_CLASS[h][0] == pjs::KC_CLASS[i][0]) return false;
+    return true;
+}
+#ifdef PJR_HOST_EMU
+#define PJR_LDS_ADD(ptr, val) (*(ptr) += (val))
+#define PJR_STORE_NT(ptr, val) (*(ptr) = (val))
+#else
+#define PJR_LDS_ADD(ptr, val) ((void)__hip_atomic_fetch_add((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#define PJR_STORE_NT(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+
+#ifdef PJR_TIMING
+// debug build: cycles per phase and wavefront, summed over the tiles of a workgroup
+__device__ long long g_tim[8][4][512];
+#define PJR_TICK(ph) { const long long tn_ = clock64(); tacc[ph] += tn_ - tprev; tprev = tn_; }
+#undef PJR_TICK_B
+#define PJR_TICK_B(ph) PJR_TICK(ph)
+#else
+#define PJR_TICK(ph)
+#endif
+
+__global__ void __launch_bounds__(PJR_WLANES * PJR_NW) k_fused(PjrArgs A)
+{
+    __shared__ __attribute__((aligned(16))) double LT[(NKC > 0 ? NKC : 1) * 16];
+    __shared__ __attribute__((aligned(16))) double RDL[NRXN][RDW];
+    __shared__ __attribute__((aligned(16))) double EFL[NEFF];
+    // species constants (1/W, W, T_mid, W/W_N, NASA rows) read with uniform ds_reads: as literals
+    // the persistent tile loop would hoist ~2000 64-bit constants out of the loop and spill them
+    __shared__ __attribute__((aligned(16))) double SPL[NSP][SPW];
+    __shared__ double CL[NSP][PJR_WLANES];     // concentrations of the tile
+    __shared__ double RED[NSP][PJR_WLANES];    // sum nu theta per species, later the energy-row sums
+    __shared__ double SUMS[5][PJR_WLANES];     // H, SCP, SJT, cp_avg, d(cp_avg)/dT
+    constexpr int NT = PJR_WLANES * PJR_NW;
+    for (int x = threadIdx.x; x < NKC * 16; x += NT) LT[x] = pjs::LTAB[pjs::LT_KC + x];
+    for (int x = threadIdx.x; x < NRXN * RDW; x += NT) (&RDL[0][0])[x] = (&pjs::RDT[0][0])[x];
+    for (int x = threadIdx.x; x < NEFF; x += NT) EFL[x] = pjs::EFFT[x][0];
+    for (int x = threadIdx.x; x < NSP * SPW; x += NT) (&SPL[0][0])[x] = (&pjs::SPF[0][0])[x];
+#define PJR_SP(k_, c_) SPL[k_][c_]
+#define PJR_EFF(e_) EFL[e_]
+#define PJR_NASA(k_, lo_, c_) SPL[k_][((lo_) ? 4 : 11) + (c_)]
+#define PJR_ANM1(i_) RDL[i_][RD_ANM1]
+    const int lane = threadIdx.x % PJR_WLANES;
+#ifdef PJR_HOST_EMU
+    const int w = threadIdx.x / PJR_WLANES;
+#else
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / PJR_WLANES);   // wavefront-uniform: scalar branches
+#endif
+    double* const scr0 = A.scr + (long)blockIdx.x * ((long)pjs::NSCR * PJR_WLANES) + lane;
+#define SCR_(slot) scr[(slot) * PJR_WLANES]
+#define LD_(slot) scr[(slot) * PJR_WLANES]
+#define CC(idx) ((idx) == ONE ? 1.0 : CL[(idx) == ONE ? 0 : (idx)][lane])
+    auto conc = [&](auto spc) PJR_INL {
+        constexpr int sp = decltype(spc)::value;
+        if constexpr (sp == ONE) return 1.0; else return CL[sp][lane];
+    };
+    const long ntiles = (A.n + PJR_WLANES - 1) / PJR_WLANES;
+#ifdef PJR_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // lanes past the end repeat the last state (same values to the same addresses)
+        long s = t * PJR_WLANES + lane;
+        if (s >= A.n) s = A.n - 1;
+        // The scratch region is the same every tile; hide that from the optimiser, which would
+        // otherwise hoist the 64-bit address of every scratch slot out of this loop (~NSCR live
+        // pointers per lane, all spilled).
+        double* scr = scr0;
+        long j_si = A.j_si;                 // same for the per-entry offsets e * j_si (SGPR pairs)
+#ifndef PJR_HOST_EMU
+        asm volatile("" : "+v"(scr));
+        asm volatile("" : "+s"(j_si));
+#endif
+        double T, p, rho, invrho, Wbar, mconc;
+        __syncthreads();                    // previous tile done with CL / RED / SUMS / scratch
+        {
+            // eval_conc (every wavefront needs the sums; each stores its share of C_k)
+            const double* y = A.y + s * A.y_ss;
+            T = y[0];
+            p = A.pres[s];
+            double Y[NSP], sumY = 0.0, sumYW = 0.0;
+            static_for<LAST>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                Y[k] = y[(k + 1) * A.y_si];
+                sumY += Y[k];
+                sumYW += Y[k] * PJR_SP(k, 0);
+            });
+            Y[LAST] = 1.0 - sumY;
+            sumYW += Y[LAST] * PJR_SP(LAST, 0);
+            Wbar = 1.0 / sumYW;
+            rho = p * Wbar / (RU_ * T);
+            invrho = 1.0 / rho;
+            mconc = p / (RU_ * T);
+            static_for<NSP>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                if (k % PJR_NW == w) { CL[k][lane] = rho * Y[k] * PJR_SP(k, 0); RED[k][lane] = 0.0; }
+            });
+            if (w == 0) static_for<5>([&](auto cc) PJR_INL { SUMS[decltype(cc)::value][lane] = 0.0; });
+        }
+        double* const Jl = A.jac + s * A.j_ss;
+#define J_(e) Jl[(long)(e) * j_si]
+        PJR_TICK(0)
+        __syncthreads();
+        PJR_TICK(2)
+
+        // ---- phase 1: rates of this wavefront's reactions -> scratch; d/dT partial sums ----
+        {
+            const double logT = log(T), invT = 1.0 / T, logp = log(p);
+#ifndef PJR_DBG_SKIP_P1
+            static_for<NARM>([&](auto ac) PJR_INL {
+                constexpr int arm = decltype(ac)::value;
+                if (arm % PJR_NW == w) {
+                    double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
+                    double jt[NSP], jtq = 0.0;
+                    static_for<NSP>([&](auto kc) PJR_INL { jt[decltype(kc)::value] = 0.0; });
+                    static_for<(NRXN - arm + NARM - 1) / NARM>([&](auto nc) PJR_INL {
+                        constexpr int i = arm + NARM * decltype(nc)::value;
+#define PJR_RD(i_) RDL[i_]
+#define PJR_KCROW(g_) (LT + (g_) * 16)
+#define PJR_EFL(e_) EFL[e_]
+#define PJR_KC_FIRST(i_) kc_first_arm(i_)
+#include "pj_rows_rate.inc"
+#undef PJR_RD
+#undef PJR_KCROW
+#undef PJR_EFL
+#undef PJR_KC_FIRST
+                    });
+                    // reference quirk (create_jacobian.py:2786-2818), see pj_kernel.h
+                    if (!A.sum_last) jt[LAST] = (pjs::LASTQ >= 0 && pjs::LASTQ % NARM == arm) ? jtq : 0.0;
+                    static_for<NSP>([&](auto kc) PJR_INL {
+                        constexpr int k = decltype(kc)::value;
+                        PJR_LDS_ADD(&RED[k][lane], jt[k]);
+                    });
+                }
+            });
+#endif
+        }
+        PJR_TICK(1)
+        __syncthreads();
+        PJR_TICK(2)
+
+        // ---- d/dT column out, SJT; RED is handed over (zeroed) to the energy row ----
+        {
+            double sjt = 0.0, cpa = 0.0, dcpa = 0.0;
+            static_for<NSP>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                if (k % PJR_NW == w) {
+                    const double jtk = RED[k][lane];
+                    RED[k][lane] = 0.0;
+                    const bool lo = T <= PJR_SP(k, 2);
+                    double a[6];
+                    static_for<6>([&](auto cc) PJR_INL {
+                        constexpr int c = decltype(cc)::value;
+                        a[c] = PJR_NASA(k, lo, c);
+                    });
+                    const double hW = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                                             T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+                    sjt += hW * jtk;
+                    if constexpr (k < LAST) PJR_STORE_NT(&J_(k + 1), PJR_SP(k, 1) * jtk);
+                    // mass-fraction weighted c_p sums from the concentrations: Y_k c_p,k = C_k R (a0 + ...) / rho
+                    const double Ck = CL[k][lane];
+                    cpa += Ck * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+                    dcpa += Ck * (a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T)));
+                }
+            });
+            PJR_LDS_ADD(&SUMS[2][lane], sjt);
+            PJR_LDS_ADD(&SUMS[3][lane], cpa * (RU_ * invrho));
+            PJR_LDS_ADD(&SUMS[4][lane], dcpa * (RU_ * invrho));
+        }
+        PJR_TICK(3)
+        __syncthreads();
+        PJR_TICK(2)
+
+        // ---- phase 2: this wavefront's row blocks ----
+        {
+            double E[LAST > 0 ? LAST : 1];
+            static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] = 0.0; });
+            double H = 0.0, SCP = 0.0;
+            double ring[PJR_DEPTH][6];
+            auto issue_bv = [&](auto bc, auto vc) PJR_INL {
+                constexpr int v = decltype(vc)::value;
+                constexpr int i = pjs::BLK_RX[pjs::BLK_RX_PTR[decltype(bc)::value][0] + v][0];
+                static_for<6>([&](auto cc) PJR_INL {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr (pjs::SCR[i][c] >= 0) ring[v % PJR_DEPTH][c] = LD_(pjs::SCR[i][c]);
+                });
+            };
+            auto prologue = [&](auto bc) PJR_INL {
+                constexpr int b = decltype(bc)::value;
+                constexpr int nv = pjs::BLK_RX_PTR[b + 1][0] - pjs::BLK_RX_PTR[b][0];
+                static_for<(nv < PJR_DEPTH ? nv : PJR_DEPTH)>([&](auto vc) PJR_INL { issue_bv(bc, vc); });
+            };
+#undef PJR_STORE
+#define PJR_STORE(ptr, val) PJR_STORE_NT(ptr, val)
+#ifndef PJR_DBG_SKIP_P2
+            static_for<NARM>([&](auto ac) PJR_INL {
+                constexpr int arm = decltype(ac)::value;
+                if (arm % PJR_NW == w) {
+                    static_for<pjs::ARM_BLK_PTR[arm + 1][0] - pjs::ARM_BLK_PTR[arm][0]>([&](auto nc) PJR_INL {
+                        constexpr int b = pjs::ARM_BLKS[pjs::ARM_BLK_PTR[arm][0] + decltype(nc)::value][0];
+                        const std::integral_constant<int, b> bc{};
+#include "pj_rows_block.inc"
+                    });
+                }
+            });
+#endif
+            static_for<LAST>([&](auto jc) PJR_INL {
+                constexpr int j = decltype(jc)::value;
+                PJR_LDS_ADD(&RED[j][lane], E[j]);
+            });
+            PJR_LDS_ADD(&SUMS[0][lane], H);
+            PJR_LDS_ADD(&SUMS[1][lane], SCP);
+        }
+        PJR_TICK(4)
+        __syncthreads();
+        PJR_TICK(2)
+
+        // ---- energy row ----
+        {
+            auto cp_of = [&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                const bool lo = T <= PJR_SP(k, 2);
+                double a[5];
+                static_for<5>([&](auto cc) PJR_INL {
+                    constexpr int c = decltype(cc)::value;
+                    a[c] = PJR_NASA(k, lo, c);
+                });
+                return (RU_ * PJR_SP(k, 0)) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+            };
+            const double cpavg = SUMS[3][lane], dcpavg = SUMS[4][lane];
+            const double cpN = cp_of(std::integral_constant<int, LAST>{});
+            const double H = SUMS[0][lane], SCP = SUMS[1][lane], SJT = SUMS[2][lane];
+            const double icp = 1.0 / cpavg;
+            if (w == 0) PJR_STORE_NT(&J_(0), -(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg));
+            static_for<LAST>([&](auto jc) PJR_INL {
+                constexpr int j = decltype(jc)::value;
+                if (j % PJR_NW == w) {
+                    const double cpj = cp_of(jc);
+                    PJR_STORE_NT(&J_(NSP * (j + 1)),
+                                 -RED[j][lane] * PJR_SP(j, 0) * icp + (cpj - cpN) * H * invrho * icp * icp);
+                }
+            });
+        }
+        PJR_TICK(5)
+#undef J_
+    }
+#ifdef PJR_TIMING
+    if (lane == 0 && blockIdx.x < 512)
+        for (int ph = 0; ph < 8; ++ph) g_tim[ph][w][blockIdx.x] = tacc[ph];
+#endif
+#undef SCR_
+#undef LD_
+#undef CC
+#undef PJR_SP
+#undef PJR_EFF
+#undef PJR_NASA
+#undef PJR_ANM1
+}
+
+double* g_scr = nullptr;
+long g_scr_wgs = 0;
+#endif  // PJR_PART == 3
 
 #if PJR_PART == 0
 // ------------------------------------------------------------------------------------------
@@ -466,6 +763,46 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         hipLaunchKernelGGL(k_fin, dim3((unsigned)((m + PJR_BLOCK - 1) / PJR_BLOCK)), dim3(PJR_BLOCK), 0,
                            (hipStream_t)stream, A);
     }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // extern "C"
+#endif
+
+#if PJR_PART == 3
+extern "C" {
+
+unsigned long long pj_spec_hash(void) { return PJS_HASH; }
+int pj_spec_nsp(void) { return NSP; }
+int pj_spec_kind(void) { return 3; }   // 1: pj_lane.hip, 2: pj_rows.hip kernels, 3: pj_rows.hip fused
+#ifdef PJR_TIMING
+int pj_spec_debug_timing(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tim), sizeof(g_tim)); }
+#endif
+
+// layouts as in include/pyjac_amd.h: element (i, s) at base[i*si + s*ss].  One batch at a time
+// per library (the per-workgroup scratch regions are shared): calls on different streams must
+// not overlap.
+int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
+                     long j_si, long j_ss, int sum_last, void* stream)
+{
+    if (n <= 0) return 0;
+    static long resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 256, per_cu = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused, PJR_WLANES * PJR_NW, 0);
+        resident = (long)cus * (per_cu > 0 ? per_cu : 1);
+    }
+    long wgs = (n + PJR_WLANES - 1) / PJR_WLANES;
+    if (wgs > resident) wgs = resident;
+    if (g_scr_wgs < wgs) {
+        if (g_scr) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr); g_scr = nullptr; g_scr_wgs = 0; }
+        if (hipMalloc((void**)&g_scr, sizeof(double) * (size_t)pjs::NSCR * PJR_WLANES * (size_t)wgs) != hipSuccess) return -4;
+        g_scr_wgs = wgs;
+    }
+    PjrArgs A{n, pres, y, y_si, y_ss, jac, j_si, j_ss, g_scr, 0, sum_last};
+    hipLaunchKernelGGL(k_fused, dim3((unsigned)wgs), dim3(PJR_WLANES * PJR_NW), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

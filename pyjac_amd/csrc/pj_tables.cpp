@@ -573,6 +573,7 @@ std::string emit_spec_header(const Programs& p)
         std::vector<double> spc;
         for (int k = 0; k < nsp; ++k) for (int c = 0; c < 4; ++c) spc.push_back(p.sp[(size_t)k * SPW + c]);
         dev_arr("SPT", spc, 4);
+        dev_arr("SPF", p.sp, SPW);      // full species records (pj_rows.hip fused kernel)
     }
     o += "#endif\n";
     o += "#ifdef __HIPCC__\n__device__ const double LTAB[LT_SIZE] = {\n";
@@ -682,6 +683,30 @@ std::string emit_rows_tables(const Programs& p, int budget)
         if (fl & F_EFFTYPE) scr[(size_t)i * 6 + 4] = nscr++;
         if (fl & F_COLLIDER) scr[(size_t)i * 6 + 5] = nscr++;
     }
+    // fused kernel: row blocks dealt to 4 wavefronts, longest-processing-time first, with the
+    // measured cost model (cycles): ~770 per reaction visit, ~14000 per row of Jacobian stores
+    const int NARM = 4;
+    std::vector<std::vector<int>> arm_blks(NARM);
+    {
+        std::vector<long> cost(nblk), load(NARM, 0);
+        std::vector<int> order(nblk);
+        for (int b = 0; b < nblk; ++b) {
+            cost[b] = 770L * (brx_ptr[b + 1] - brx_ptr[b]) + 14000L * (long)blocks[b].size() + 2000;
+            order[b] = b;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+        for (int b : order) {
+            const int a = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            arm_blks[a].push_back(b);
+            load[a] += cost[b];
+        }
+    }
+    std::vector<int32_t> arm_ptr{0}, arm_list;
+    for (int a = 0; a < NARM; ++a) {
+        std::sort(arm_blks[a].begin(), arm_blks[a].end());
+        for (int b : arm_blks[a]) arm_list.push_back(b);
+        arm_ptr.push_back((int32_t)arm_list.size());
+    }
     o += "namespace pjs {\n";
     o += "constexpr int NBLK = " + std::to_string(nblk) + ", BLK_MAXROWS = " + std::to_string(maxrows) +
          ", BLK_MAXNNZ = " + std::to_string(maxnnz) + ", NSCR = " + std::to_string(nscr) +
@@ -695,6 +720,8 @@ std::string emit_rows_tables(const Programs& p, int budget)
     arr_i("BLK_NNZ", bnnz, 1);
     arr_i("SLOC", sloc, nsp);
     arr_i("SCR", scr, 6);
+    arr_i("ARM_BLK_PTR", arm_ptr, 1);
+    arr_i("ARM_BLKS", arm_list, 1);
     o += "}  // namespace pjs\n";
     return o;
 }

@@ -60,16 +60,20 @@ class Evaluator:
         """Which specialised kernel family specialize(build=True) compiles for this mechanism."""
         return 'lane' if self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN else 'rows'
 
+    _SPEC_STEM = {'lane': 'libpj_spec_%016x.so', 'rows': 'libpj_rows_%016x.so', 'fused': 'libpj_fused_%016x.so'}
+
     def spec_path(self, kind: str = None) -> str:
         h = _lib.lib().pj_mech_spec_hash(self._h)
-        stem = 'libpj_spec_%016x.so' if (kind or self.spec_kind()) == 'lane' else 'libpj_rows_%016x.so'
-        return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'spec', stem % h)
+        return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'spec',
+                            self._SPEC_STEM[kind or self.spec_kind()] % h)
 
     def specialize(self, build: bool = False, kind: str = None, **rows_opts) -> bool:
         """Attach (and with build=True compile if missing) the mechanism-specific kernels.
-        kind: 'lane' | 'rows' | None (whatever is there, else the default for the size)."""
+        kind: 'lane' | 'rows' | 'fused' | None (whatever is there, else the default for the size).
+        'fused' is the single-kernel variant of pj_rows.hip (one translation unit: minutes to
+        compile for a 53-species mechanism; coefficient tables of all reactions must fit the LDS)."""
         L = _lib.lib()
-        kinds = [kind] if kind else [self.spec_kind()] + [k for k in ('lane', 'rows') if k != self.spec_kind()]
+        kinds = [kind] if kind else [self.spec_kind()] + [k for k in ('lane', 'fused', 'rows') if k != self.spec_kind()]
         so = next((self.spec_path(k) for k in kinds if os.path.exists(self.spec_path(k))), None)
         if so is None:
             if not build:
@@ -77,6 +81,8 @@ class Evaluator:
             so = self.spec_path(kinds[0])
             if kinds[0] == 'lane':
                 self._build_lane(so)
+            elif kinds[0] == 'fused':
+                self._build_fused(so, **rows_opts)
             else:
                 self._build_rows(so, **rows_opts)
         check(L.pj_mech_attach_spec(self._h, so.encode()))
@@ -98,6 +104,22 @@ class Evaluator:
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
                               ['-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
                                '-o', so, os.path.join(here, 'csrc', 'pj_lane.hip')])
+
+    def _build_fused(self, so: str, budget: int = None, **_):
+        """csrc/pj_rows.hip as ONE kernel (PJR_PART=3): a workgroup of 4 wavefronts per 64-state
+        tile, scratch region per resident workgroup."""
+        import subprocess
+        L = _lib.lib()
+        here = os.path.dirname(os.path.abspath(__file__))
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        hdr = so[:-3] + '.h'
+        check(L.pj_mech_emit_rows_spec(self._h, hdr.encode(), int(budget or os.environ.get('PJ_ROWS_BUDGET', self.ROWS_BUDGET))))
+        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        flags = os.environ.get('PJ_ROWS_FLAGS',
+                               '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math').split()
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
+                              ['-DPJR_PART=3', '-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
+                               '-o', so, os.path.join(here, 'csrc', 'pj_rows.hip')])
 
     def _build_rows(self, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None):
         """One translation unit per kernel of csrc/pj_rows.hip, compiled in parallel."""
@@ -149,7 +171,8 @@ class Evaluator:
     def spec_kernel(self) -> str:
         """'pj_lane' / 'pj_rows' for the attached specialisation, '' if none."""
         so = os.path.basename(self.attached_spec or '')
-        return 'pj_lane' if so.startswith('libpj_spec_') else 'pj_rows' if so.startswith('libpj_rows_') else ''
+        return ('pj_lane' if so.startswith('libpj_spec_') else 'pj_rows' if so.startswith('libpj_rows_')
+                else 'pj_fused' if so.startswith('libpj_fused_') else '')
 
     @property
     def has_spec(self) -> bool:

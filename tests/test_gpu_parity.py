@@ -283,6 +283,50 @@ def test_row_block_kernels_all_reaction_types(layout, tables, torch_cuda):
         assert mx < RTOL and fro < 1e-9, ('rows vs table-driven', sum_last, mx, fro)
 
 
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_fused_row_block_kernel(layout, tables, torch_cuda):
+    """The single-kernel variant of csrc/pj_rows.hip (4 wavefronts share a 64-state tile and split
+    reactions and row blocks; cross-wavefront sums through LDS atomics; per-workgroup scratch
+    region reused every tile) against the oracle and the table-driven kernel; the batch is not a
+    multiple of the tile and is larger than the resident workgroups cover in one pass."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    name = 'synth_alltypes'
+    ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
+    assert ev.specialize(build=True, kind='fused', budget=16)
+    assert ev.spec_kernel == 'pj_fused'
+    n = 64 * 700 + 11
+    pres, y = synth.dist_b(n, ev.nsp, seed=31, Tlo=400, Thi=2800)
+    pres = 101325 * 10 ** np.random.default_rng(8).uniform(-1.5, 1.5, n)
+    d_p = torch.from_numpy(pres).cuda()
+    if layout == 'soa':
+        d_y, L = torch.from_numpy(y).cuda(), pyjac_amd.LAYOUT_SOA
+    else:
+        d_y, L = torch.from_numpy(np.ascontiguousarray(y.T)).cuda(), pyjac_amd.LAYOUT_AOS
+    o = Oracle(tables(name))
+    for sum_last in (0, 1):
+        ev.set_sum_last_species(bool(sum_last))
+        ev.use_spec(True)
+        spec = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+        ev.use_spec(False)
+        gen = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+        if layout == 'soa':
+            spec, gen = spec.T, gen.T
+        assert np.isfinite(spec).all()
+        mx, fro = thresholded_rel_err(spec, gen)
+        assert mx < RTOL and fro < 1e-9, ('fused vs table-driven', sum_last, mx, fro)
+        ii = np.arange(0, n, 97)
+        o.lib.pjo_set_sum_last_species(sum_last)
+        try:
+            ref = o.batch_jacob(pres[ii], np.ascontiguousarray(y[:, ii].T))
+        finally:
+            o.lib.pjo_set_sum_last_species(0)
+        mx, fro = thresholded_rel_err(spec[ii], ref)
+        assert mx < RTOL and fro < 1e-9, (layout, sum_last, mx, fro)
+
+
 def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
     """A batch larger than the scratch chunk (PJ_ROWS_CHUNK) runs as several chunks through the
     same scratch array; results must not depend on the chunking."""

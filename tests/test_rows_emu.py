@@ -85,3 +85,40 @@ def test_rows_kernels_vs_reference_golden(tmp_path, golden):
     assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0
     fro = np.linalg.norm(jac - g['jac']) / np.linalg.norm(g['jac'])
     assert fro < 1e-9
+
+
+def _fused_emu_lib(name, budget, tmp):
+    """csrc/pj_rows.hip as the single fused kernel (PJR_PART=3) with one lane and one wavefront per
+    workgroup: the arms of the four wavefronts run one after the other."""
+    import subprocess
+    ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
+    hdr = os.path.join(tmp, '%s_f%d.h' % (name, budget))
+    _lib.check(_lib.lib().pj_mech_emit_rows_spec(ev._h, hdr.encode(), budget))
+    so = os.path.join(tmp, 'lib%s_fused.so' % name)
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-x', 'c++', '-DPJR_HOST_EMU',
+                           '-DPJR_PART=3', '-DPJR_WLANES=1', '-DPJR_NW=1', '-DPJS_HEADER="%s"' % hdr,
+                           '-I', build_rows_emu.HERE, '-I', build_rows_emu.CSRC,
+                           os.path.join(build_rows_emu.CSRC, 'pj_rows.hip'), '-o', so])
+    L = ctypes.CDLL(so)
+    L.pj_spec_jacobian.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp,
+                                   ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    return ev, L
+
+
+@pytest.mark.parametrize('name,budget', [('synth_alltypes', 16), ('h2o2', 24)])
+def test_fused_kernel_vs_oracle(name, budget, tmp_path, tables):
+    from oracle.oracle import Oracle
+    ev, L = _fused_emu_lib(name, budget, str(tmp_path))
+    orc = Oracle(tables(name))
+    n = 37
+    pres, y = synth.dist_b(n, ev.nsp)
+    for sum_last in (0, 1):
+        orc.lib.pjo_set_sum_last_species(sum_last)
+        try:
+            ref = orc.batch_jacob(pres, np.ascontiguousarray(y.T))
+        finally:
+            orc.lib.pjo_set_sum_last_species(0)
+        for aos in (False, True):
+            jac = _run(L, ev.nsp, pres, y, sum_last=sum_last, aos=aos)
+            assert not np.isnan(jac).any()
+            assert jac_scaled_err(jac, ref, ev.nsp) <= 1.0
