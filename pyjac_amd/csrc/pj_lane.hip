@@ -332,11 +332,18 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         sjt += hW[k] * jt[k];
     }
     double* const Jl = A.jac + (s - A.s0) * A.j_ss;
-#define J_(e) Jl[(long)(e) * A.j_si]
+#ifndef PJL_NT_STORE
+#define PJL_NT_STORE 1     // Jacobian entries are written once and not read back: nontemporal stores
+#endif
+#if PJL_NT_STORE
+#define JST(e, val) __builtin_nontemporal_store((val), &Jl[(long)(e) * A.j_si])
+#else
+#define JST(e, val) (Jl[(long)(e) * A.j_si] = (val))
+#endif
     const double icp = 1.0 / cpavg;
-    J_(0) = -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg);
+    JST(0, -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg));
 #pragma unroll
-    for (int k = 0; k < LAST; ++k) J_(k + 1) = SPT[k][1] * jt[k];
+    for (int k = 0; k < LAST; ++k) JST(k + 1, SPT[k][1] * jt[k]);
     static_for<LAST>([&](auto jc) PJL_INL {
         constexpr int j = decltype(jc)::value;
         const double wj = SPT[j][3], iWj = SPT[j][0];
@@ -347,9 +354,9 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             double m = ANY_GN ? P[k] - wj * Q[k] : P[k] - wj * P[k];
             if constexpr (si >= 0) m += S[si];
             tot += hW[k] * m;
-            if constexpr (k < LAST) J_(k + 1 + NSP * (j + 1)) = (SPT[k][1] * iWj) * m;
+            if constexpr (k < LAST) JST(k + 1 + NSP * (j + 1), (SPT[k][1] * iWj) * m);
         });
-        J_(NSP * (j + 1)) = -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp;
+        JST(NSP * (j + 1), -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp);
     });
 #undef PJL_INL
   }
