@@ -97,10 +97,12 @@ class Evaluator:
         hdr = so[:-3] + '.h'
         check(L.pj_mech_emit_spec(self._h, hdr.encode()))
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        # -ffast-math: reciprocal instead of IEEE division sequences and reassociation of
-        # the long accumulation chains (+11 % on MI355X); parity stays ~1e-11
+        # reciprocal instead of IEEE division sequences, contraction, no NaN/Inf/-0 special-casing;
+        # NO reassociation (it keeps every product of an accumulation chain live: +40 AGPRs, -5 %);
+        # measured on MI355X against -ffast-math and plain -O3
         flags = os.environ.get('PJ_LANE_FLAGS',
-                               '-ffast-math -mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
+                               '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
+                               '-ffinite-math-only -mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
                               ['-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
                                '-o', so, os.path.join(here, 'csrc', 'pj_lane.hip')])
