@@ -73,11 +73,11 @@ struct Args {
 };
 
 #ifndef PJL_BLOCK
-#define PJL_BLOCK 64
+#define PJL_BLOCK 256    // one wavefront per SIMD; measured 64 / 128 / 256 x PJL_PERSIST 1 / 2 / 4
 #endif
 
 #ifndef PJL_PERSIST
-#define PJL_PERSIST 2      // resident workgroups per slot; states are walked grid-stride
+#define PJL_PERSIST 1      // workgroups per resident slot; states are walked grid-stride
 #endif
 
 __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
