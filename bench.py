@@ -141,8 +141,10 @@ def also_workloads(primary, pyjac_amd, torch, np):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # defaults sized so that launch ramp-up (clocks, first-touch) and the final synchronisation are
+    # amortised: 200 steps are 45 ms (H2), 3.5 s (GRI-shaped), 4 s (USC-shaped) of GPU time
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default=os.environ.get('PJ_WORKLOAD', 'auto'))
     ap.add_argument('--states', type=int, default=0, help='states per GPU (default: workload size)')
     ap.add_argument('--layout', default='auto', choices=['auto', 'soa', 'aos'])
@@ -210,7 +212,7 @@ def main():
         elapsed = float(t.item())
 
     # kernel-only duration, HIP events on the launch stream (roofline.achieved)
-    ms_kernel = ev.time_jacobian(d_p, d_y, jac, max(a.steps, 5), L, L)
+    ms_kernel = ev.time_jacobian(d_p, d_y, jac, min(max(a.steps, 5), 100), L, L)
 
     finite = bool(torch.isfinite(jac[:, ::997] if L == pyjac_amd.LAYOUT_SOA else jac[::997]).all())
     validation = None
@@ -258,6 +260,29 @@ def main():
         line['config']['kernel'] = kernel_label(ev)
         if world == 1 and not a.no_also:
             line['also'] = also_workloads(wl, pyjac_amd, torch, np)
+            if ev.spec_kernel == 'pj_lane' and L == pyjac_amd.LAYOUT_SOA:
+                # the Jacobian consumed in registers (w = J v), nothing but T, p, Y, v read
+                # and w written -- reported next to the headline, never part of `value`
+                try:
+                    d_v = torch.randn_like(d_y)
+                    d_w = torch.empty_like(d_y)
+                    for _ in range(3):
+                        ev.jacobian_vec(d_p, d_y, d_v, out=d_w)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        ev.jacobian_vec(d_p, d_y, d_v, out=d_w)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / 20
+                    bjv = 8 * (2 * ev.nsp + 1) + 8 * ev.nsp
+                    line['also']['fused_jacobian_vector_product'] = dict(
+                        states=n, kernel_ms=ms, products_per_s=n / ms * 1e3, bytes_per_state=bjv,
+                        achieved_GBps=n * bjv / ms / 1e6, finite=bool(torch.isfinite(d_w[:, ::997]).all()),
+                        note='same kernel with the stores replaced by w[row] += J(row,col) v[col]: no longer '
+                             'HBM-bound (bytes/state 256 instead of 888)')
+                except Exception as ex:
+                    line['also']['fused_jacobian_vector_product'] = {'error': repr(ex)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(w, ev.tables)

@@ -42,6 +42,8 @@ SIGNATURES = {
     'pj_mech_use_spec': (ctypes.c_int, [_vp, ctypes.c_int]),
     'pj_eval_jacobian_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_int, _vp,
                                             ctypes.c_int, _vp]),
+    'pj_eval_jacobian_vec_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_int, _vp, _vp,
+                                                ctypes.c_int, _vp]),
     'pj_eval_rates_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_int,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pj_eval_fd_jacobian_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, _vp, ctypes.c_int, _vp]),

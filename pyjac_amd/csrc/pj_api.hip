@@ -240,6 +240,10 @@ struct pj_mech {
     // attached register-resident specialisation (pj_lane.hip)
     void* spec_lib = nullptr;
     int (*spec_jac)(long, const double*, const double*, long, long, double*, long, long, int, void*) = nullptr;
+    int (*spec_jv)(long, const double*, const double*, long, long, const double*, long, long, double*, long, long,
+                   int, void*) = nullptr;   // fused J*v (pj_lane.hip), optional
+    double* jv_tmp = nullptr;    // Jacobian chunk of the unfused J*v path
+    size_t jv_tmp_doubles = 0;
     bool use_spec = true;
 };
 
@@ -375,6 +379,22 @@ int launch(pj_mech* m, const Batch& B, int mode, const double* cin, const double
     return fail(PJ_EINVAL, "tile_states must be a power of two <= 64");
 }
 
+// w_s = A_s v_s for a chunk of stored Jacobians (SoA, leading dimension ld): the unfused consumer,
+// pyJac's sparse_multiplier (create_jacobian.py:3301-3404) applied to every state of the chunk
+__global__ void k_matvec(int nsp, long n, const double* A, long ld, const double* v, long v_si, long v_ss,
+                         double* w, long w_si, long w_ss)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const double* vs = v + s * v_ss;
+    double* ws = w + s * w_ss;
+    for (int i = 0; i < nsp; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < nsp; ++j) acc += A[(long)(i + nsp * j) * ld + s] * vs[j * v_si];
+        ws[i * w_si] = acc;
+    }
+}
+
 void set_layout(long n, int rows, int layout, long* si, long* ss)
 {
     if (layout == PJ_LAYOUT_AOS) { *si = 1; *ss = rows; }
@@ -443,6 +463,7 @@ int pj_mech_load(const char* path, pj_mech** out)
 
 void pj_mech_destroy(pj_mech* m)
 {
+    if (m && m->jv_tmp) { (void)hipFree(m->jv_tmp); m->jv_tmp = nullptr; }
     if (!m) return;
     if (m->on_device) {
         m->sp.release(); m->rd.release(); m->rtd.release(); m->rti.release();
@@ -500,6 +521,7 @@ int pj_mech_attach_spec(pj_mech* m, const char* library_path)
     if (m->spec_lib) dlclose(m->spec_lib);
     m->spec_lib = lib;
     m->spec_jac = jac;
+    m->spec_jv = (decltype(m->spec_jv))dlsym(lib, "pj_spec_jacvec");
     return PJ_OK;
 }
 
@@ -547,6 +569,54 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
     }
     static const int abl = getenv("PJ_ABLATE") ? atoi(getenv("PJ_ABLATE")) : 0;
     return launch(m, B, MODE_JAC | abl, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int pj_eval_jacobian_vec_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
+                             const double* d_v, double* d_w, int vw_layout, void* stream)
+{
+    if (!m || n < 0) return fail(PJ_EINVAL, "bad argument");
+    if (n == 0) return PJ_OK;
+    if (!d_pres || !d_y || !d_v || !d_w) return fail(PJ_EINVAL, "null device pointer");
+    const int nsp = m->P.nsp;
+    long y_si, y_ss, v_si, v_ss;
+    set_layout(n, nsp, y_layout, &y_si, &y_ss);
+    set_layout(n, nsp, vw_layout, &v_si, &v_ss);
+    int rc = ensure_device(m);
+    if (rc) return rc;
+    if (m->spec_jv && m->use_spec) {
+        if (m->spec_jv(n, d_pres, d_y, y_si, y_ss, d_v, v_si, v_ss, d_w, v_si, v_ss, m->M.sum_last, stream))
+            return fail(PJ_EHIP, "specialised kernel launch failed");
+        return PJ_OK;
+    }
+    // unfused: Jacobians of a chunk into a temporary SoA block, then the mat-vec kernel
+    long chunk = (long)((512UL << 20) / (8UL * nsp * nsp));
+    chunk = chunk / 256 * 256;
+    if (chunk < 256) chunk = 256;
+    if (chunk > n) chunk = n;
+    const size_t need = (size_t)chunk * nsp * nsp;
+    if (m->jv_tmp_doubles < need) {
+        if (m->jv_tmp) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(m->jv_tmp); m->jv_tmp = nullptr; m->jv_tmp_doubles = 0; }
+        HIPCHK(hipMalloc((void**)&m->jv_tmp, sizeof(double) * need));
+        m->jv_tmp_doubles = need;
+    }
+    for (long s0 = 0; s0 < n; s0 += chunk) {
+        const long c = s0 + chunk < n ? chunk : n - s0;
+        if (m->spec_jac && m->use_spec) {
+            if (m->spec_jac(c, d_pres + s0, d_y + s0 * y_ss, y_si, y_ss, m->jv_tmp, c, 1, m->M.sum_last, stream))
+                return fail(PJ_EHIP, "specialised kernel launch failed");
+        } else {
+            Batch B;
+            memset(&B, 0, sizeof(B));
+            B.n = c; B.pres = d_pres + s0; B.y = d_y + s0 * y_ss; B.jac = m->jv_tmp; B.o_ld = c;
+            B.y_si = y_si; B.y_ss = y_ss; B.j_si = c; B.j_ss = 1;
+            rc = launch(m, B, MODE_JAC, nullptr, nullptr, nullptr, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_matvec, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nsp, c,
+                           m->jv_tmp, c, d_v + s0 * v_ss, v_si, v_ss, d_w + s0 * v_ss, v_si, v_ss);
+    }
+    HIPCHK(hipGetLastError());
+    return PJ_OK;
 }
 
 int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,

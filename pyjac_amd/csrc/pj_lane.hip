@@ -70,6 +70,9 @@ struct Args {
     double* jac; long j_si, j_ss;      // jac already points at state s0's block
     long s0;                           // first state of this launch chunk
     int sum_last;
+    // fused Jacobian-vector product (k_lane<true>): w_s = J(Phi_s) v_s, J never leaves the registers
+    const double* v; long v_si, v_ss;
+    double* w; long w_si, w_ss;
 };
 
 #ifndef PJL_BLOCK
@@ -80,6 +83,7 @@ struct Args {
 #define PJL_PERSIST 1      // workgroups per resident slot; states are walked grid-stride
 #endif
 
+template <bool JV>
 __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 {
     // NASA lo/hi coefficient rows live in LDS: one ds_read per coefficient pair at an
@@ -100,6 +104,12 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     const double (*RDT)[RDW] = RDL;
     const double (*EFFT)[1] = EFL;
     const double (*SPT)[4] = SPL;
+    if constexpr (JV) {
+        // Without global stores in the loop body the optimiser treats the LDS tables as loop
+        // invariant and hoists hundreds of coefficient reads out of the persistent loop (spills);
+        // hide the table addresses from it once per state.
+        asm volatile("" : "+v"(RDT), "+v"(EFFT), "+v"(SPT));
+    }
     const double* y = A.y + s * A.y_ss;
     const double T = y[0];
     const double p = A.pres[s];
@@ -331,19 +341,30 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         scp += om[k] * SPT[k][1] * cpk[k];
         sjt += hW[k] * jt[k];
     }
-    double* const Jl = A.jac + (s - A.s0) * A.j_ss;
+    double* const Jl = JV ? nullptr : A.jac + (s - A.s0) * A.j_ss;
+    // JV: every Jacobian entry goes into w[row] += J(row, col) * v[col] instead of memory
+    double vv[NSP], ww[NSP];
+    if constexpr (JV) {
+        const double* vs = A.v + s * A.v_ss;
+#pragma unroll
+        for (int k = 0; k < NSP; ++k) { vv[k] = vs[k * A.v_si]; ww[k] = 0.0; }
+    }
 #ifndef PJL_NT_STORE
 #define PJL_NT_STORE 1     // Jacobian entries are written once and not read back: nontemporal stores
 #endif
 #if PJL_NT_STORE
-#define JST(e, val) __builtin_nontemporal_store((val), &Jl[(long)(e) * A.j_si])
+#define JMEM(e, val) __builtin_nontemporal_store((val), &Jl[(long)(e) * A.j_si])
 #else
-#define JST(e, val) (Jl[(long)(e) * A.j_si] = (val))
+#define JMEM(e, val) (Jl[(long)(e) * A.j_si] = (val))
 #endif
+// e = row + NSP * col, compile-time wherever this is used
+#define JST(e, val) do { if constexpr (JV) ww[(e) % NSP] += (val) * vv[(e) / NSP]; else JMEM(e, val); } while (0)
     const double icp = 1.0 / cpavg;
     JST(0, -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg));
-#pragma unroll
-    for (int k = 0; k < LAST; ++k) JST(k + 1, SPT[k][1] * jt[k]);
+    static_for<LAST>([&](auto kc) PJL_INL {
+        constexpr int k = decltype(kc)::value;
+        JST(k + 1, SPT[k][1] * jt[k]);
+    });
     static_for<LAST>([&](auto jc) PJL_INL {
         constexpr int j = decltype(jc)::value;
         const double wj = SPT[j][3], iWj = SPT[j][0];
@@ -358,6 +379,13 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         });
         JST(NSP * (j + 1), -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp);
     });
+#undef JST
+#undef JMEM
+    if constexpr (JV) {
+        double* ws = A.w + s * A.w_ss;
+#pragma unroll
+        for (int k = 0; k < NSP; ++k) ws[k * A.w_si] = ww[k];
+    }
 #undef PJL_INL
   }
 }
@@ -379,7 +407,7 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane, PJL_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<false>, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
     // launch in chunks whose per-lane byte offset into the Jacobian fits 32 bits
@@ -388,11 +416,33 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
     if (chunk > n) chunk = n;
     for (long s0 = 0; s0 < n; s0 += chunk) {
         const long s1 = s0 + chunk < n ? s0 + chunk : n;
-        Args A{s1, pres, y, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, s0, sum_last};
+        Args A{s1, pres, y, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, s0, sum_last, nullptr, 0, 0, nullptr, 0, 0};
         long blocks = (s1 - s0 + PJL_BLOCK - 1) / PJL_BLOCK;
         if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-        hipLaunchKernelGGL(k_lane, dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        hipLaunchKernelGGL(k_lane<false>, dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Fused Jacobian-vector product w_s = J(Phi_s) v_s (the consumer of pyJac's sparse_multiplier,
+// create_jacobian.py:3301-3404, applied while the entries are still in registers): reads T, p, Y and v,
+// writes NSP doubles per state.  Layouts as above.
+int pj_spec_jacvec(long n, const double* pres, const double* y, long y_si, long y_ss, const double* v,
+                   long v_si, long v_ss, double* w, long w_si, long w_ss, int sum_last, void* stream)
+{
+    if (n <= 0) return 0;
+    static long resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 256, per_cu = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<true>, PJL_BLOCK, 0);
+        resident = (long)cus * (per_cu > 0 ? per_cu : 1);
+    }
+    Args A{n, pres, y, y_si, y_ss, nullptr, 0, 0, 0, sum_last, v, v_si, v_ss, w, w_si, w_ss};
+    long blocks = (n + PJL_BLOCK - 1) / PJL_BLOCK;
+    if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
+    hipLaunchKernelGGL(k_lane<true>, dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -235,6 +235,19 @@ class Evaluator:
                                               out.data_ptr(), jac_layout, self._stream()))
         return out
 
+    def jacobian_vec(self, pres, y, v, layout=LAYOUT_SOA, out=None):
+        """w_s = J(Phi_s) v_s per state (the consumer of pyJac's sparse_multiplier fused into the
+        Jacobian kernel when a pj_lane library is attached).  y, v, w: SoA (NSP, n) or AoS (n, NSP)."""
+        import torch
+        n = pres.numel()
+        assert pres.is_cuda and y.is_cuda and v.is_cuda and y.dtype == v.dtype == torch.float64
+        assert y.is_contiguous() and v.is_contiguous() and y.numel() == v.numel() == n * self.nsp
+        if out is None:
+            out = torch.empty_like(v)
+        check(_lib.lib().pj_eval_jacobian_vec_dev(self._h, n, pres.data_ptr(), y.data_ptr(), layout,
+                                                  v.data_ptr(), out.data_ptr(), layout, self._stream()))
+        return out
+
     def rates(self, pres, y, y_layout=LAYOUT_SOA, want=('conc', 'fwd', 'rev', 'pres_mod',
                                                           'spec_rates', 'dydt')):
         """All SoA outputs of pyjacob.cu's k_dydt pass as a dict of (rows, n) tensors."""

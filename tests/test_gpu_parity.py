@@ -344,6 +344,40 @@ def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
     assert torch.equal(whole, parts)
 
 
+@pytest.mark.parametrize('name,fused', [('h2o2_n2', True), ('synth_alltypes', True), ('h2o2_n2', False),
+                                        ('gri30_shaped', False)])
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_jacobian_vector_product(name, fused, layout, tables, torch_cuda):
+    """N2: w = J v per state (pyJac's sparse_multiplier consumer, create_jacobian.py:3301-3404), fused
+    into the register-resident kernel (no Jacobian in memory) and through the unfused chunked path,
+    against the oracle's Jacobian times the same vectors."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev(name)
+    if fused:
+        assert ev.spec_kernel == 'pj_lane'
+    elif ev.spec_kernel == 'pj_lane':
+        ev.use_spec(False)
+    n = 1500
+    pres, y = synth.dist_b(n, ev.nsp, seed=12, Tlo=700, Thi=2500)
+    v = np.random.default_rng(3).standard_normal((ev.nsp, n))
+    v[0] *= 100.0                                   # temperature component on its own scale
+    d_p = torch.from_numpy(pres).cuda()
+    if layout == 'soa':
+        w = ev.jacobian_vec(d_p, torch.from_numpy(y).cuda(), torch.from_numpy(v).cuda()).cpu().numpy().T
+    else:
+        w = ev.jacobian_vec(d_p, torch.from_numpy(np.ascontiguousarray(y.T)).cuda(),
+                            torch.from_numpy(np.ascontiguousarray(v.T)).cuda(),
+                            layout=pyjac_amd.LAYOUT_AOS).cpu().numpy()
+    J = Oracle(tables(name)).batch_jacob(pres, np.ascontiguousarray(y.T)).reshape(n, ev.nsp, ev.nsp)  # [s][col][row]
+    ref = np.einsum('scr,cs->sr', J, v)
+    scale = np.einsum('scr,cs->sr', np.abs(J), np.abs(v)) + 1e-300     # sum of |terms| per entry
+    assert np.isfinite(w).all()
+    assert (np.abs(w - ref) / scale).max() < 1e-9, (name, fused, layout)
+
+
 def test_finite_difference_arm(tables, torch_cuda):
     """N3: the reference's FD Jacobian (fd_jacob.c) on the GPU dydt.  A forward difference
     amplifies the ~1e-16 differences between GPU and CPU dydt by 1/r ~ 1e8 / |y_j|, so the
