@@ -279,8 +279,8 @@ def main():
                     line['also']['fused_jacobian_vector_product'] = dict(
                         states=n, kernel_ms=ms, products_per_s=n / ms * 1e3, bytes_per_state=bjv,
                         achieved_GBps=n * bjv / ms / 1e6, finite=bool(torch.isfinite(d_w[:, ::997]).all()),
-                        note='same kernel with the stores replaced by w[row] += J(row,col) v[col]: no longer '
-                             'HBM-bound (bytes/state 256 instead of 888)')
+                        note='same kernel with the stores replaced by w[row] += J(row,col) v[col]: %d instead of '
+                             '%d bytes per state' % (bjv, bj))
                 except Exception as ex:
                     line['also']['fused_jacobian_vector_product'] = {'error': repr(ex)}
         if world == 1 and not a.no_cpu_baseline:
