@@ -244,7 +244,7 @@ struct pj_mech {
                    int, void*) = nullptr;   // fused J*v (pj_lane.hip), optional
     double* jv_tmp = nullptr;    // Jacobian chunk of the unfused J*v path
     size_t jv_tmp_doubles = 0;
-    bool use_spec = true;
+    int use_spec = 1;          // 0: never, 1: SoA Jacobians (default), 2: every layout
 };
 
 namespace {
@@ -526,7 +526,12 @@ int pj_mech_attach_spec(pj_mech* m, const char* library_path)
 }
 
 int pj_mech_has_spec(const pj_mech* m) { return m->spec_jac != nullptr; }
-int pj_mech_use_spec(pj_mech* m, int on) { m->use_spec = on != 0; return PJ_OK; }
+int pj_mech_use_spec(pj_mech* m, int on)
+{
+    if (on < 0 || on > 2) return fail(PJ_EINVAL, "use_spec: 0, 1 or 2");
+    m->use_spec = on;
+    return PJ_OK;
+}
 
 int pj_mech_set_launch(pj_mech* m, int tile_states, int threads)
 {
@@ -560,7 +565,9 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
     B.n = n; B.pres = d_pres; B.y = d_y; B.jac = d_jac; B.o_ld = n;
     set_layout(n, m->P.nsp, y_layout, &B.y_si, &B.y_ss);
     set_layout(n, m->P.nsp * m->P.nsp, jac_layout, &B.j_si, &B.j_ss);
-    if (m->spec_jac && m->use_spec) {
+    // the state-per-lane kernels write lane-contiguous (SoA) blocks; an AoS Jacobian is the
+    // cooperative kernel's native output (measured 3x faster there), unless forced (use_spec == 2)
+    if (m->spec_jac && (m->use_spec == 2 || (m->use_spec == 1 && jac_layout == PJ_LAYOUT_SOA))) {
         int rc = ensure_device(m);
         if (rc) return rc;
         if (m->spec_jac(n, d_pres, d_y, B.y_si, B.y_ss, d_jac, B.j_si, B.j_ss, m->M.sum_last, stream))

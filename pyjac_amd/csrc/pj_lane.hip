@@ -70,7 +70,7 @@ struct Args {
     double* jac; long j_si, j_ss;      // jac already points at state s0's block
     long s0;                           // first state of this launch chunk
     int sum_last;
-    // fused Jacobian-vector product (k_lane<true>): w_s = J(Phi_s) v_s, J never leaves the registers
+    // fused Jacobian-vector product (k_lane<true, false>): w_s = J(Phi_s) v_s, J never leaves the registers
     const double* v; long v_si, v_ss;
     double* w; long w_si, w_ss;
 };
@@ -83,7 +83,7 @@ struct Args {
 #define PJL_PERSIST 1      // workgroups per resident slot; states are walked grid-stride
 #endif
 
-template <bool JV>
+template <bool JV, bool NT>
 __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 {
     // NASA lo/hi coefficient rows live in LDS: one ds_read per coefficient pair at an
@@ -349,14 +349,11 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 #pragma unroll
         for (int k = 0; k < NSP; ++k) { vv[k] = vs[k * A.v_si]; ww[k] = 0.0; }
     }
-#ifndef PJL_NT_STORE
-#define PJL_NT_STORE 1     // Jacobian entries are written once and not read back: nontemporal stores
-#endif
-#if PJL_NT_STORE
-#define JMEM(e, val) __builtin_nontemporal_store((val), &Jl[(long)(e) * A.j_si])
-#else
-#define JMEM(e, val) (Jl[(long)(e) * A.j_si] = (val))
-#endif
+// Jacobian entries are written once and not read back: nontemporal stores when a wavefront's
+// store is one contiguous line (SoA, NT = true); with a state stride between lanes (AoS) they are
+// partial-line writes and nontemporal is 7x slower than write-back caching
+#define JMEM(e, val) do { if constexpr (NT) __builtin_nontemporal_store((val), &Jl[(long)(e) * A.j_si]); \
+                          else Jl[(long)(e) * A.j_si] = (val); } while (0)
 // e = row + NSP * col, compile-time wherever this is used
 #define JST(e, val) do { if constexpr (JV) ww[(e) % NSP] += (val) * vv[(e) / NSP]; else JMEM(e, val); } while (0)
     const double icp = 1.0 / cpavg;
@@ -407,7 +404,7 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<false>, PJL_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<false, true>, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
     // launch in chunks whose per-lane byte offset into the Jacobian fits 32 bits
@@ -419,7 +416,8 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         Args A{s1, pres, y, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, s0, sum_last, nullptr, 0, 0, nullptr, 0, 0};
         long blocks = (s1 - s0 + PJL_BLOCK - 1) / PJL_BLOCK;
         if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-        hipLaunchKernelGGL(k_lane<false>, dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        if (j_ss == 1) hipLaunchKernelGGL((k_lane<false, true>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        else hipLaunchKernelGGL((k_lane<false, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -436,13 +434,13 @@ int pj_spec_jacvec(long n, const double* pres, const double* y, long y_si, long 
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<true>, PJL_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<true, false>, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
     Args A{n, pres, y, y_si, y_ss, nullptr, 0, 0, 0, sum_last, v, v_si, v_ss, w, w_si, w_ss};
     long blocks = (n + PJL_BLOCK - 1) / PJL_BLOCK;
     if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-    hipLaunchKernelGGL(k_lane<true>, dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL((k_lane<true, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

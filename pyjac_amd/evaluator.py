@@ -180,7 +180,9 @@ class Evaluator:
     def has_spec(self) -> bool:
         return bool(_lib.lib().pj_mech_has_spec(self._h))
 
-    def use_spec(self, on: bool):
+    def use_spec(self, on):
+        """False/0: table-driven kernel; True/1: attached kernels for SoA Jacobians (default);
+        2: attached kernels for every layout."""
         check(_lib.lib().pj_mech_use_spec(self._h, int(on)))
 
     def close(self):

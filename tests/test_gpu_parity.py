@@ -191,6 +191,7 @@ def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda)
     ev = _ev(name)
     if kernel == 'pj_rows':
         assert ev.has_spec and ev.spec_kernel == 'pj_rows', 'row-block library missing: run __graft_entry__.build()'
+        ev.use_spec(2)
     else:
         ev.use_spec(False)
         if ev.get_launch()['lds_bytes'] > 160 * 1024:
@@ -229,6 +230,7 @@ def test_specialised_lane_kernel(name, layout, tables, torch_cuda):
         d_y, L = torch.from_numpy(y).cuda(), pyjac_amd.LAYOUT_SOA
     else:
         d_y, L = torch.from_numpy(np.ascontiguousarray(y.T)).cuda(), pyjac_amd.LAYOUT_AOS
+    ev.use_spec(2)              # also for the AoS layout (default: AoS goes to the table-driven kernel)
     spec = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
     ev.use_spec(False)
     gen = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
@@ -266,7 +268,7 @@ def test_row_block_kernels_all_reaction_types(layout, tables, torch_cuda):
     o = Oracle(tables(name))
     for sum_last in (0, 1):
         ev.set_sum_last_species(bool(sum_last))
-        ev.use_spec(True)
+        ev.use_spec(2)
         spec = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
         ev.use_spec(False)
         gen = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
@@ -308,7 +310,7 @@ def test_fused_row_block_kernel(layout, tables, torch_cuda):
     o = Oracle(tables(name))
     for sum_last in (0, 1):
         ev.set_sum_last_species(bool(sum_last))
-        ev.use_spec(True)
+        ev.use_spec(2)
         spec = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
         ev.use_spec(False)
         gen = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
@@ -412,7 +414,7 @@ def test_large_mechanisms_vs_reference_golden(name, golden, torch_cuda):
     ev = _ev(name)
     d_p = torch.from_numpy(g['pres'].copy()).cuda()
     d_y = torch.from_numpy(np.ascontiguousarray(g['y'])).cuda()
-    for use in (True, False):       # row-block kernels, then the table-driven kernel
+    for use in (2, 0):              # row-block kernels (forced: AoS), then the table-driven kernel
         ev.use_spec(use)
         if not use and ev.get_launch()['lds_bytes'] > 160 * 1024:
             continue
