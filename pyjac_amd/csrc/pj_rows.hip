@@ -514,7 +514,6 @@ __global__ void __launch_bounds__(PJR_WLANES * PJR_NW) k_fused(PjrArgs A)
         // ---- phase 1: rates of this wavefront's reactions -> scratch; d/dT partial sums ----
         {
             const double logT = log(T), invT = 1.0 / T, logp = log(p);
-#ifndef PJR_DBG_SKIP_P1
             static_for<NARM>([&](auto ac) PJR_INL {
                 constexpr int arm = decltype(ac)::value;
                 if (arm % PJR_NW == w) {
@@ -541,7 +540,6 @@ __global__ void __launch_bounds__(PJR_WLANES * PJR_NW) k_fused(PjrArgs A)
                     });
                 }
             });
-#endif
         }
         PJR_TICK(1)
         __syncthreads();
@@ -600,7 +598,6 @@ __global__ void __launch_bounds__(PJR_WLANES * PJR_NW) k_fused(PjrArgs A)
             };
 #undef PJR_STORE
 #define PJR_STORE(ptr, val) PJR_STORE_NT(ptr, val)
-#ifndef PJR_DBG_SKIP_P2
             static_for<NARM>([&](auto ac) PJR_INL {
                 constexpr int arm = decltype(ac)::value;
                 if (arm % PJR_NW == w) {
@@ -611,7 +608,6 @@ __global__ void __launch_bounds__(PJR_WLANES * PJR_NW) k_fused(PjrArgs A)
                     });
                 }
             });
-#endif
             static_for<LAST>([&](auto jc) PJR_INL {
                 constexpr int j = decltype(jc)::value;
                 PJR_LDS_ADD(&RED[j][lane], E[j]);
