@@ -15,6 +15,7 @@ MECHS = {
     'synth_alltypes': os.path.join(GOLDEN, 'synth_alltypes.inp'),
     'gri30_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'gri30_shaped.inp'),
     'usc2_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'),
+    'synth_mid24': os.path.join(GOLDEN, 'synth_mid24.inp'),     # 24 sp / 96 rxn incl. Troe, PLOG
 }
 
 

@@ -27,6 +27,7 @@ CASES = {
     'synth_alltypes': os.path.join(HERE, 'synth_alltypes.inp'),
     'gri30_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'gri30_shaped.inp'),
     'usc2_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'),
+    'synth_mid24': os.path.join(HERE, 'synth_mid24.inp'),
 }
 
 
@@ -40,8 +41,8 @@ def states_for(name, nsp):
         sel = slice(3, None, 17)
         P, T = P[sel], T[sel]
         Y = Y[sel, :9] / Y[sel, :9].sum(axis=1, keepdims=True)
-    elif name in ('gri30_shaped', 'usc2_shaped'):
-        n = 12 if name == 'gri30_shaped' else 4
+    elif name in ('gri30_shaped', 'usc2_shaped', 'synth_mid24'):
+        n = {'gri30_shaped': 12, 'usc2_shaped': 4, 'synth_mid24': 40}[name]
         P, ysoa = synth.dist_b(n, nsp, seed=77, Tlo=600, Thi=2500)
         return P, np.ascontiguousarray(ysoa.T)
     else:
@@ -56,7 +57,10 @@ def states_for(name, nsp):
 
 
 def main():
+    only = sys.argv[1:]
     for name, mech in CASES.items():
+        if only and name not in only:
+            continue
         build_ref(mech, name)
         r = Reference(name)
         P, y = states_for(name, r.nsp)

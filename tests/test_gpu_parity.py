@@ -329,6 +329,24 @@ def test_fused_row_block_kernel(layout, tables, torch_cuda):
         assert mx < RTOL and fro < 1e-9, (layout, sum_last, mx, fro)
 
 
+def test_row_block_kernels_mid_size(golden, torch_cuda):
+    """24 species / 96 reactions (Troe, PLOG, third bodies): the default row-block build (prebuilt by
+    __graft_entry__.build()) against vectors from pyJac's generated C, both layouts."""
+    import pyjac_amd
+    torch = torch_cuda
+    g = golden('synth_mid24')
+    ev = _ev('synth_mid24')
+    assert ev.spec_kernel == 'pj_rows'
+    ev.use_spec(2)
+    d_p = torch.from_numpy(g['pres'].copy()).cuda()
+    soa = ev.jacobian(d_p, torch.from_numpy(np.ascontiguousarray(g['y'].T)).cuda()).cpu().numpy().T
+    aos = ev.jacobian(d_p, torch.from_numpy(np.ascontiguousarray(g['y'])).cuda(),
+                      y_layout=pyjac_amd.LAYOUT_AOS, jac_layout=pyjac_amd.LAYOUT_AOS).cpu().numpy()
+    for jac in (soa, aos):
+        mx, fro = thresholded_rel_err(jac, g['jac'])
+        assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0 and fro < 1e-9, (mx, fro)
+
+
 def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
     """A batch larger than the scratch chunk (PJ_ROWS_CHUNK) runs as several chunks through the
     same scratch array; results must not depend on the chunking."""

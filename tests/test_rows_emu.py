@@ -55,6 +55,7 @@ def _run(L, nsp, pres, y_soa, sum_last=0, aos=False):
     ('synth_alltypes', 200, dict(blocks_per_part=1, rates_per_part=1000)),
     ('h2o2', 24, dict(blocks_per_part=3, rates_per_part=10)),
     ('h2o2_n2', 12, dict(blocks_per_part=100, rates_per_part=5)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
 ])
 def test_rows_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     from oracle.oracle import Oracle
