@@ -716,8 +716,11 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_fin(PjrArgs A)
 
 constexpr int MAXPARTS = 512;
 pjr_launch_fn g_rates[MAXPARTS], g_rows[MAXPARTS];
-double* g_scr = nullptr;
-long g_scr_ld = 0;
+double* g_scr[2] = {nullptr, nullptr};
+long g_scr_ld[2] = {0, 0};
+hipStream_t g_streams[2] = {nullptr, nullptr};
+enum { EV_START, EV_RATES0, EV_RATES1, EV_ROWS0, EV_ROWS1, EV_COUNT };
+hipEvent_t g_events[EV_COUNT];
 #endif
 
 }  // namespace
@@ -737,27 +740,65 @@ int pj_spec_kind(void) { return 2; }   // 1: pj_lane.hip, 2: pj_rows.hip
 long pj_spec_scratch_doubles_per_state(void) { return pjs::NSCR + 3; }
 
 // layouts as in include/pyjac_amd.h: element (i, s) at base[i*si + s*ss].  One batch at a time
-// per library (the scratch array is shared): calls on different streams must not overlap.
+// per library (the scratch arrays are shared): calls on different streams must not overlap.
+//
+// The batch runs in chunks through two scratch arrays on two internal streams: the rate kernels
+// of chunk c+1 (compute-bound) overlap the row kernels of chunk c (HBM-bound); both are forked
+// from and joined to the caller's stream with events, so the call is asynchronous and ordered
+// like a single kernel launch on `stream`.  PJ_ROWS_OVERLAP=0: everything on the caller's stream.
 int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
                      long j_si, long j_ss, int sum_last, void* stream)
 {
     if (n <= 0) return 0;
+    static int overlap = -1;
+    if (overlap < 0) { const char* e = getenv("PJ_ROWS_OVERLAP"); overlap = (e && atoi(e) == 0) ? 0 : 1; }
     long chunk = 262144;
     if (const char* e = getenv("PJ_ROWS_CHUNK")) { const long v = atol(e); if (v >= 256) chunk = v; }
+    // at least two chunks when the batch is big enough to fill the device twice
+    if (overlap && n > 2 * 65536 && n < 2 * chunk) chunk = (n + 1) / 2;
     chunk = (chunk + PJR_TILE - 1) / PJR_TILE * PJR_TILE;
     if (chunk > n) chunk = (n + PJR_TILE - 1) / PJR_TILE * PJR_TILE;
-    if (g_scr_ld < chunk) {
-        if (g_scr) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr); g_scr = nullptr; g_scr_ld = 0; }
-        if (hipMalloc((void**)&g_scr, sizeof(double) * (size_t)(pjs::NSCR + 3) * (size_t)chunk) != hipSuccess) return -4;
-        g_scr_ld = chunk;
+    const int nbuf = (overlap && n > chunk) ? 2 : 1;
+    for (int b = 0; b < nbuf; ++b) {
+        if (g_scr_ld[b] >= chunk) continue;
+        if (g_scr[b]) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr[b]); g_scr[b] = nullptr; g_scr_ld[b] = 0; }
+        if (hipMalloc((void**)&g_scr[b], sizeof(double) * (size_t)(pjs::NSCR + 3) * (size_t)chunk) != hipSuccess) return -4;
+        g_scr_ld[b] = chunk;
     }
-    for (long s0 = 0; s0 < n; s0 += chunk) {
+    hipStream_t user = (hipStream_t)stream, s_rates = user, s_rows = user;
+    if (nbuf == 2) {
+        if (!g_streams[0]) {
+            if (hipStreamCreateWithFlags(&g_streams[0], hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&g_streams[1], hipStreamNonBlocking) != hipSuccess) return -3;
+            for (auto& e : g_events)
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -3;
+        }
+        s_rates = g_streams[0]; s_rows = g_streams[1];
+        // fork
+        (void)hipEventRecord(g_events[EV_START], user);
+        (void)hipStreamWaitEvent(s_rates, g_events[EV_START], 0);
+        (void)hipStreamWaitEvent(s_rows, g_events[EV_START], 0);
+    }
+    long c = 0;
+    for (long s0 = 0; s0 < n; s0 += chunk, ++c) {
         const long m = s0 + chunk < n ? chunk : n - s0;
-        PjrArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, g_scr, g_scr_ld, sum_last};
-        for (int i = 0; i < MAXPARTS; ++i) if (g_rates[i]) g_rates[i](A, stream);
-        for (int i = 0; i < MAXPARTS; ++i) if (g_rows[i]) g_rows[i](A, stream);
-        hipLaunchKernelGGL(k_fin, dim3((unsigned)((m + PJR_BLOCK - 1) / PJR_BLOCK)), dim3(PJR_BLOCK), 0,
-                           (hipStream_t)stream, A);
+        const int b = (int)(c % nbuf);
+        PjrArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, g_scr[b], g_scr_ld[b], sum_last};
+        // scratch buffer b is free again once the row kernels of chunk c-2 are done
+        if (nbuf == 2 && c >= 2) (void)hipStreamWaitEvent(s_rates, g_events[EV_ROWS0 + b], 0);
+        for (int i = 0; i < MAXPARTS; ++i) if (g_rates[i]) g_rates[i](A, s_rates);
+        if (nbuf == 2) {
+            (void)hipEventRecord(g_events[EV_RATES0 + b], s_rates);
+            (void)hipStreamWaitEvent(s_rows, g_events[EV_RATES0 + b], 0);
+        }
+        for (int i = 0; i < MAXPARTS; ++i) if (g_rows[i]) g_rows[i](A, s_rows);
+        hipLaunchKernelGGL(k_fin, dim3((unsigned)((m + PJR_BLOCK - 1) / PJR_BLOCK)), dim3(PJR_BLOCK), 0, s_rows, A);
+        if (nbuf == 2) (void)hipEventRecord(g_events[EV_ROWS0 + b], s_rows);
+    }
+    if (nbuf == 2) {
+        // join: the last event recorded on s_rows covers every chunk (one stream, in order); the rate
+        // stream finished before it by construction
+        (void)hipStreamWaitEvent(user, g_events[EV_ROWS0 + (int)((c - 1) % 2)], 0);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

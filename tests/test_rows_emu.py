@@ -77,6 +77,19 @@ def test_rows_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     assert jac_scaled_err(_run(L, ev.nsp, pres, y, sum_last=1), ref1, ev.nsp) <= 1.0
 
 
+def test_rows_kernels_chunked_double_buffered(tmp_path, tables, monkeypatch):
+    """Batches larger than the scratch chunk alternate between two scratch arrays (on the GPU:
+    two streams, rate kernels of chunk c+1 next to the row kernels of chunk c)."""
+    from oracle.oracle import Oracle
+    monkeypatch.setenv('PJ_ROWS_CHUNK', '256')
+    ev, L = _emu_lib('h2o2', 24, str(tmp_path), blocks_per_part=2, rates_per_part=10)
+    n = 256 * 3 + 17
+    pres, y = synth.dist_b(n, ev.nsp, seed=5)
+    ref = Oracle(tables('h2o2')).batch_jacob(pres, np.ascontiguousarray(y.T))
+    jac = _run(L, ev.nsp, pres, y)
+    assert not np.isnan(jac).any() and jac_scaled_err(jac, ref, ev.nsp) <= 1.0
+
+
 def test_rows_kernels_vs_reference_golden(tmp_path, golden):
     """53-species mechanism at the shipping budget against vectors from pyJac's generated C."""
     ev, L = _emu_lib('gri30_shaped', 64, str(tmp_path), blocks_per_part=8)
