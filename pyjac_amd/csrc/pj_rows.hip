@@ -754,8 +754,9 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
     if (overlap < 0) { const char* e = getenv("PJ_ROWS_OVERLAP"); overlap = (e && atoi(e) == 0) ? 0 : 1; }
     long chunk = 262144;
     if (const char* e = getenv("PJ_ROWS_CHUNK")) { const long v = atol(e); if (v >= 256) chunk = v; }
-    // at least two chunks when the batch is big enough to fill the device twice
-    if (overlap && n > 2 * 65536 && n < 2 * chunk) chunk = (n + 1) / 2;
+    // at least two chunks when the batch fills the device several times over (measured: splitting a
+    // 2e5-state batch of the 111-species mechanism costs 10 %, splitting 1e6 states gains 3 %)
+    if (overlap && n > 2 * 131072 && n < 2 * chunk) chunk = (n + 1) / 2;
     chunk = (chunk + PJR_TILE - 1) / PJR_TILE * PJR_TILE;
     if (chunk > n) chunk = (n + PJR_TILE - 1) / PJR_TILE * PJR_TILE;
     const int nbuf = (overlap && n > chunk) ? 2 : 1;
