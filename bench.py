@@ -16,6 +16,7 @@ Workloads (BASELINE.json configs):
     usc  USC-II-shaped synthetic, 111 sp / 784 rxn w/ PLOG, 2e5 states     (config 5)
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -288,6 +289,38 @@ def main():
                              '%d bytes per state' % (bjv, bj))
                 except Exception as ex:
                     line['also']['fused_jacobian_vector_product'] = {'error': repr(ex)}
+                # configs[1] "spec_rates + Jacobian": the rate pass (pyjacob.cu k_dydt) on the same batch,
+                # with every intermediate array written (conc, fwd, rev, pres_mod, spec_rates, dy) and
+                # with dy only
+                try:
+                    from pyjac_amd import _lib
+                    rows = dict(conc=ev.nsp, fwd=ev.n_fwd, rev=max(ev.n_rev, 1), pres_mod=max(ev.n_pres_mod, 1),
+                                spec_rates=ev.nsp, dy=ev.nsp)
+                    bufs = {k: torch.empty((r, n), dtype=torch.float64, device='cuda') for k, r in rows.items()}
+                    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+                    def rates(which):
+                        p = lambda k: bufs[k].data_ptr() if k in which else None
+                        _lib.check(_lib.lib().pj_eval_rates_dev(ev._h, n, d_p.data_ptr(), d_y.data_ptr(), L, p('conc'),
+                                                                p('fwd'), p('rev'), p('pres_mod'), p('spec_rates'),
+                                                                p('dy'), stream))
+                    res = {}
+                    for label, which in (('all_arrays', tuple(rows)), ('dydt_only', ('dy',))):
+                        for _ in range(3):
+                            rates(which)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(20):
+                            rates(which)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ms = e0.elapsed_time(e1) / 20
+                        by = 8 * (ev.nsp + 1) + 8 * sum(rows[k] for k in which)
+                        res[label] = dict(kernel_ms=ms, states_per_s=n / ms * 1e3, bytes_per_state=by,
+                                          achieved_GBps=n * by / ms / 1e6, frac=n * by / ms / 1e6 / HBM_PEAK_GBPS)
+                    line['also']['rate_pass'] = res
+                except Exception as ex:
+                    line['also']['rate_pass'] = {'error': repr(ex)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(w, ev.tables)

@@ -242,6 +242,8 @@ struct pj_mech {
     int (*spec_jac)(long, const double*, const double*, long, long, double*, long, long, int, void*) = nullptr;
     int (*spec_jv)(long, const double*, const double*, long, long, const double*, long, long, double*, long, long,
                    int, void*) = nullptr;   // fused J*v (pj_lane.hip), optional
+    int (*spec_rates)(long, const double*, const double*, long, long, double*, double*, double*, double*, double*,
+                      double*, void*) = nullptr;   // rate outputs (pj_lane.hip), optional
     double* jv_tmp = nullptr;    // Jacobian chunk of the unfused J*v path
     size_t jv_tmp_doubles = 0;
     int use_spec = 1;          // 0: never, 1: SoA Jacobians (default), 2: every layout
@@ -522,6 +524,7 @@ int pj_mech_attach_spec(pj_mech* m, const char* library_path)
     m->spec_lib = lib;
     m->spec_jac = jac;
     m->spec_jv = (decltype(m->spec_jv))dlsym(lib, "pj_spec_jacvec");
+    m->spec_rates = (decltype(m->spec_rates))dlsym(lib, "pj_spec_rates");
     return PJ_OK;
 }
 
@@ -639,6 +642,13 @@ int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_
     set_layout(n, m->P.nsp, y_layout, &B.y_si, &B.y_ss);
     B.conc = d_conc; B.fwd = d_fwd; B.rev = d_rev; B.pres_mod = d_pres_mod;
     B.spec_rates = d_spec_rates; B.dy = d_dy;
+    if (m->spec_rates && m->use_spec) {
+        int rc = ensure_device(m);
+        if (rc) return rc;
+        if (m->spec_rates(n, d_pres, d_y, B.y_si, B.y_ss, d_conc, d_fwd, d_rev, d_pres_mod, d_spec_rates, d_dy, stream))
+            return fail(PJ_EHIP, "specialised kernel launch failed");
+        return PJ_OK;
+    }
     return launch(m, B, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -745,7 +755,13 @@ static int run_ws(pj_mech* m, Workspace& w, int num, const double* pres, const d
     B.jac = w.jac; B.j_si = num; B.j_ss = 1;
     B.conc = w.conc; B.fwd = w.fwd; B.rev = w.rev; B.pres_mod = w.pm; B.spec_rates = w.sr; B.dy = w.dy;
     const bool spec = jac && m->spec_jac && m->use_spec;
-    int rc = launch(m, B, (jac && !spec) ? MODE_JAC : 0, nullptr, nullptr, aux ? w.aux : nullptr, 0);
+    int rc = PJ_OK;
+    if (!aux && m->spec_rates && m->use_spec && (spec || !jac)) {
+        if (m->spec_rates(num, w.pres, w.y, B.y_si, B.y_ss, w.conc, w.fwd, w.rev, w.pm, w.sr, w.dy, nullptr))
+            return fail(PJ_EHIP, "specialised kernel launch failed");
+    } else {
+        rc = launch(m, B, (jac && !spec) ? MODE_JAC : 0, nullptr, nullptr, aux ? w.aux : nullptr, 0);
+    }
     if (rc) return rc;
     if (spec && m->spec_jac(num, w.pres, w.y, B.y_si, B.y_ss, w.jac, B.j_si, B.j_ss, m->M.sum_last, nullptr))
         return fail(PJ_EHIP, "specialised kernel launch failed");

@@ -70,9 +70,11 @@ struct Args {
     double* jac; long j_si, j_ss;      // jac already points at state s0's block
     long s0;                           // first state of this launch chunk
     int sum_last;
-    // fused Jacobian-vector product (k_lane<true, false>): w_s = J(Phi_s) v_s, J never leaves the registers
+    // fused Jacobian-vector product (k_lane<1, false>): w_s = J(Phi_s) v_s, J never leaves the registers
     const double* v; long v_si, v_ss;
     double* w; long w_si, w_ss;
+    // rate outputs (k_lane<2, .>), SoA with leading dimension o_ld, any may be null
+    double *conc, *fwd, *rev, *pres_mod, *spec_rates, *dy; long o_ld;
 };
 
 #ifndef PJL_BLOCK
@@ -83,9 +85,13 @@ struct Args {
 #define PJL_PERSIST 1      // workgroups per resident slot; states are walked grid-stride
 #endif
 
-template <bool JV, bool NT>
+// MODE 0: Jacobian blocks to memory; 1: fused Jacobian-vector product; 2: rate outputs only
+// (conc, fwd, rev, pres_mod, spec_rates, dy of pyjacob.cu's k_dydt pass -- the Jacobian
+// accumulations are dead code there and the compiler drops them)
+template <int MODE, bool NT>
 __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 {
+    constexpr bool JV = MODE == 1;
     // NASA lo/hi coefficient rows live in LDS: one ds_read per coefficient pair at an
     // address picked by the range test, instead of a v_cndmask per 32-bit half
     // plus the real-valued coefficient tables (Arrhenius / falloff / Troe parameters,
@@ -104,7 +110,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     const double (*RDT)[RDW] = RDL;
     const double (*EFFT)[1] = EFL;
     const double (*SPT)[4] = SPL;
-    if constexpr (JV) {
+    if constexpr (MODE != 0) {
         // Without global stores in the loop body the optimiser treats the LDS tables as loop
         // invariant and hoists hundreds of coefficient reads out of the persistent loop (spills);
         // hide the table addresses from it once per state.
@@ -317,6 +323,14 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         }
 
         const double q_ = c * R;
+        if constexpr (MODE == 2) {
+            // rate_subs.py:634-658, 811-840, 1076-1283: indices are positions in the mechanism file
+            if (A.fwd) A.fwd[pjs::RI[i][RI_ORIG] * A.o_ld + s] = Rf;
+            if constexpr (pjs::RI[i][RI_REV_IDX] >= 0) { if (A.rev) A.rev[pjs::RI[i][RI_REV_IDX] * A.o_ld + s] = Rr; }
+            if constexpr (pjs::RI[i][RI_PRES_IDX] >= 0) {
+                if (A.pres_mod) A.pres_mod[pjs::RI[i][RI_PRES_IDX] * A.o_ld + s] = c;
+            }
+        }
         const double rp = (Wbar * invrho) * (q_ - a) + bM;
         const double rq = rp + gN;
         static_for<ncnt>([&](auto qc) PJL_INL {
@@ -330,6 +344,19 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             if constexpr (k == LAST && i == pjs::LASTQ) jtq = nu * theta;
         });
     });
+    if constexpr (MODE == 2) {
+        // eval_spec_rates / dydt (rate_subs.py:1297-1542, 2171-2335)
+        double Hs = 0.0;
+#pragma unroll
+        for (int k = 0; k < NSP; ++k) {
+            Hs += hW[k] * om[k];
+            if (A.conc) A.conc[k * A.o_ld + s] = C[k];
+            if (A.spec_rates) A.spec_rates[k * A.o_ld + s] = om[k];
+            if (A.dy && k < LAST) A.dy[(k + 1) * A.o_ld + s] = om[k] * SPT[k][1] * invrho;
+        }
+        if (A.dy) A.dy[s] = -Hs / (rho * cpavg);
+        continue;
+    }
     // reference quirk (create_jacobian.py:2786-2818), see pj_kernel.h phase 3
     if (!A.sum_last) jt[LAST] = jtq;
 
@@ -404,7 +431,7 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<false, true>, PJL_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<0, true>, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
     // launch in chunks whose per-lane byte offset into the Jacobian fits 32 bits
@@ -413,11 +440,12 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
     if (chunk > n) chunk = n;
     for (long s0 = 0; s0 < n; s0 += chunk) {
         const long s1 = s0 + chunk < n ? s0 + chunk : n;
-        Args A{s1, pres, y, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, s0, sum_last, nullptr, 0, 0, nullptr, 0, 0};
+        Args A{s1, pres, y, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, s0, sum_last, nullptr, 0, 0, nullptr, 0, 0,
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         long blocks = (s1 - s0 + PJL_BLOCK - 1) / PJL_BLOCK;
         if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-        if (j_ss == 1) hipLaunchKernelGGL((k_lane<false, true>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
-        else hipLaunchKernelGGL((k_lane<false, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        if (j_ss == 1) hipLaunchKernelGGL((k_lane<0, true>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        else hipLaunchKernelGGL((k_lane<0, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -434,13 +462,35 @@ int pj_spec_jacvec(long n, const double* pres, const double* y, long y_si, long 
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<true, false>, PJL_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<1, false>, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
-    Args A{n, pres, y, y_si, y_ss, nullptr, 0, 0, 0, sum_last, v, v_si, v_ss, w, w_si, w_ss};
+    Args A{n, pres, y, y_si, y_ss, nullptr, 0, 0, 0, sum_last, v, v_si, v_ss, w, w_si, w_ss,
+           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     long blocks = (n + PJL_BLOCK - 1) / PJL_BLOCK;
     if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-    hipLaunchKernelGGL((k_lane<true, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL((k_lane<1, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Rate outputs of one pass (pyjacob.cu:18-35 k_dydt): any pointer may be null; SoA, leading dimension n.
+int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y_ss, double* conc, double* fwd,
+                  double* rev, double* pres_mod, double* spec_rates, double* dy, void* stream)
+{
+    if (n <= 0) return 0;
+    static long resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 256, per_cu = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<2, false>, PJL_BLOCK, 0);
+        resident = (long)cus * (per_cu > 0 ? per_cu : 1);
+    }
+    Args A{n, pres, y, y_si, y_ss, nullptr, 0, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0,
+           conc, fwd, rev, pres_mod, spec_rates, dy, n};
+    long blocks = (n + PJL_BLOCK - 1) / PJL_BLOCK;
+    if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
+    hipLaunchKernelGGL((k_lane<2, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -285,6 +285,36 @@ def test_row_block_kernels_all_reaction_types(layout, tables, torch_cuda):
         assert mx < RTOL and fro < 1e-9, ('rows vs table-driven', sum_last, mx, fro)
 
 
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_lane_rate_kernel(name, layout, golden, tables, torch_cuda):
+    """k_lane<2> (rate outputs of one pass: conc, fwd, rev, pres_mod, spec_rates, dydt) against the
+    reference's golden vectors and against the table-driven kernel on the same states."""
+    import pyjac_amd
+    torch = torch_cuda
+    g = golden(name)
+    ev = _ev(name)
+    assert ev.spec_kernel == 'pj_lane'
+    d_p = torch.from_numpy(g['pres'].copy()).cuda()
+    if layout == 'soa':
+        d_y, L = torch.from_numpy(np.ascontiguousarray(g['y'].T)).cuda(), pyjac_amd.LAYOUT_SOA
+    else:
+        d_y, L = torch.from_numpy(np.ascontiguousarray(g['y'])).cuda(), pyjac_amd.LAYOUT_AOS
+    lane = {k: v.cpu().numpy().T for k, v in ev.rates(d_p, d_y, y_layout=L).items()}
+    ev.use_spec(False)
+    gen = {k: v.cpu().numpy().T for k, v in ev.rates(d_p, d_y, y_layout=L).items()}
+    gross, sdy = rate_scales(tables(name), g['pres'], g['y'], g['conc'], g['fwd'], g['rev'], g['pres_mod'])
+    for k, cols in (('conc', ev.nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
+        if cols == 0:
+            continue
+        mx, _ = thresholded_rel_err(lane[k][:, :cols], g[k][:, :cols])
+        assert mx < RTOL, (name, k, mx)
+        mx, _ = thresholded_rel_err(lane[k][:, :cols], gen[k][:, :cols])
+        assert mx < RTOL, (name, k, 'vs table-driven', mx)
+    assert mixed_err(lane['spec_rates'], g['spec_rates'], gross[:, None]) <= 1.0
+    assert mixed_err(lane['dydt'], g['dydt'], sdy) <= 1.0
+
+
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
 def test_fused_row_block_kernel(layout, tables, torch_cuda):
     """The single-kernel variant of csrc/pj_rows.hip (4 wavefronts share a 64-state tile and split
