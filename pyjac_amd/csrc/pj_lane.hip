@@ -325,10 +325,10 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         const double q_ = c * R;
         if constexpr (MODE == 2) {
             // rate_subs.py:634-658, 811-840, 1076-1283: indices are positions in the mechanism file
-            if (A.fwd) A.fwd[pjs::RI[i][RI_ORIG] * A.o_ld + s] = Rf;
-            if constexpr (pjs::RI[i][RI_REV_IDX] >= 0) { if (A.rev) A.rev[pjs::RI[i][RI_REV_IDX] * A.o_ld + s] = Rr; }
+            if (A.fwd) __builtin_nontemporal_store(Rf, &A.fwd[pjs::RI[i][RI_ORIG] * A.o_ld + s]);
+            if constexpr (pjs::RI[i][RI_REV_IDX] >= 0) { if (A.rev) __builtin_nontemporal_store(Rr, &A.rev[pjs::RI[i][RI_REV_IDX] * A.o_ld + s]); }
             if constexpr (pjs::RI[i][RI_PRES_IDX] >= 0) {
-                if (A.pres_mod) A.pres_mod[pjs::RI[i][RI_PRES_IDX] * A.o_ld + s] = c;
+                if (A.pres_mod) __builtin_nontemporal_store(c, &A.pres_mod[pjs::RI[i][RI_PRES_IDX] * A.o_ld + s]);
             }
         }
         const double rp = (Wbar * invrho) * (q_ - a) + bM;
@@ -350,11 +350,11 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 #pragma unroll
         for (int k = 0; k < NSP; ++k) {
             Hs += hW[k] * om[k];
-            if (A.conc) A.conc[k * A.o_ld + s] = C[k];
-            if (A.spec_rates) A.spec_rates[k * A.o_ld + s] = om[k];
-            if (A.dy && k < LAST) A.dy[(k + 1) * A.o_ld + s] = om[k] * SPT[k][1] * invrho;
+            if (A.conc) __builtin_nontemporal_store(C[k], &A.conc[k * A.o_ld + s]);
+            if (A.spec_rates) __builtin_nontemporal_store(om[k], &A.spec_rates[k * A.o_ld + s]);
+            if (A.dy && k < LAST) __builtin_nontemporal_store(om[k] * SPT[k][1] * invrho, &A.dy[(k + 1) * A.o_ld + s]);
         }
-        if (A.dy) A.dy[s] = -Hs / (rho * cpavg);
+        if (A.dy) __builtin_nontemporal_store(-Hs / (rho * cpavg), &A.dy[s]);
         continue;
     }
     // reference quirk (create_jacobian.py:2786-2818), see pj_kernel.h phase 3
