@@ -85,8 +85,8 @@ int pj_mech_attach_spec(pj_mech* m, const char* library_path);
 /* 1 if a specialised kernel is attached */
 int pj_mech_has_spec(const pj_mech* m);
 /* 0: table-driven kernel even if a specialisation is attached; 1 (default): use it for SoA Jacobians
- * (its stores are lane-contiguous; AoS output is the cooperative kernel's native layout and goes
- * there); 2: use it for every layout */
+ * and, if it transposes through LDS (pj_lane.hip), for AoS ones (otherwise AoS output is the
+ * cooperative kernel's native layout and goes there); 2: use it for every layout */
 int pj_mech_use_spec(pj_mech* m, int on);
 
 /* ---- device-resident batch evaluation (pointers are device pointers on the

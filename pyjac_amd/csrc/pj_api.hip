@@ -244,6 +244,7 @@ struct pj_mech {
                    int, void*) = nullptr;   // fused J*v (pj_lane.hip), optional
     int (*spec_rates)(long, const double*, const double*, long, long, double*, double*, double*, double*, double*,
                       double*, void*) = nullptr;   // rate outputs (pj_lane.hip), optional
+    bool spec_aos = false;       // the attached library writes AoS Jacobians efficiently
     double* jv_tmp = nullptr;    // Jacobian chunk of the unfused J*v path
     size_t jv_tmp_doubles = 0;
     int use_spec = 1;          // 0: never, 1: SoA Jacobians (default), 2: every layout
@@ -525,6 +526,8 @@ int pj_mech_attach_spec(pj_mech* m, const char* library_path)
     m->spec_jac = jac;
     m->spec_jv = (decltype(m->spec_jv))dlsym(lib, "pj_spec_jacvec");
     m->spec_rates = (decltype(m->spec_rates))dlsym(lib, "pj_spec_rates");
+    auto fast_aos = (int (*)(void))dlsym(lib, "pj_spec_fast_aos");
+    m->spec_aos = fast_aos && fast_aos();
     return PJ_OK;
 }
 
@@ -568,9 +571,11 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
     B.n = n; B.pres = d_pres; B.y = d_y; B.jac = d_jac; B.o_ld = n;
     set_layout(n, m->P.nsp, y_layout, &B.y_si, &B.y_ss);
     set_layout(n, m->P.nsp * m->P.nsp, jac_layout, &B.j_si, &B.j_ss);
-    // the state-per-lane kernels write lane-contiguous (SoA) blocks; an AoS Jacobian is the
-    // cooperative kernel's native output (measured 3x faster there), unless forced (use_spec == 2)
-    if (m->spec_jac && (m->use_spec == 2 || (m->use_spec == 1 && jac_layout == PJ_LAYOUT_SOA))) {
+    // the state-per-lane kernels write lane-contiguous (SoA) blocks; AoS Jacobians go to them only
+    // if the library transposes through LDS (pj_lane.hip) -- otherwise that is the cooperative
+    // kernel's native output (measured 3x faster there) -- or when forced (use_spec == 2)
+    if (m->spec_jac && (m->use_spec == 2 ||
+                        (m->use_spec == 1 && (jac_layout == PJ_LAYOUT_SOA || m->spec_aos)))) {
         int rc = ensure_device(m);
         if (rc) return rc;
         if (m->spec_jac(n, d_pres, d_y, B.y_si, B.y_ss, d_jac, B.j_si, B.j_ss, m->M.sum_last, stream))

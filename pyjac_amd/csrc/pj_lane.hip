@@ -70,7 +70,7 @@ struct Args {
     double* jac; long j_si, j_ss;      // jac already points at state s0's block
     long s0;                           // first state of this launch chunk
     int sum_last;
-    // fused Jacobian-vector product (k_lane<1, false>): w_s = J(Phi_s) v_s, J never leaves the registers
+    // fused Jacobian-vector product (k_lane<1, 0>): w_s = J(Phi_s) v_s, J never leaves the registers
     const double* v; long v_si, v_ss;
     double* w; long w_si, w_ss;
     // rate outputs (k_lane<2, .>), SoA with leading dimension o_ld, any may be null
@@ -88,10 +88,18 @@ struct Args {
 // MODE 0: Jacobian blocks to memory; 1: fused Jacobian-vector product; 2: rate outputs only
 // (conc, fwd, rev, pres_mod, spec_rates, dy of pyjacob.cu's k_dydt pass -- the Jacobian
 // accumulations are dead code there and the compiler drops them)
-template <int MODE, bool NT>
+// ST (Jacobian store path, MODE 0): 0 strided plain stores, 1 lane-contiguous SoA (nontemporal),
+// 2 AoS (state-major NSP x NSP blocks, pyJac's per-state C layout) through a per-wavefront LDS
+// transpose: a wavefront's 64 blocks are one contiguous region of memory, written in runs of whole
+// columns instead of 8-byte stores that are NSP^2 doubles apart
+template <int MODE, int ST>
 __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 {
     constexpr bool JV = MODE == 1;
+    constexpr bool NT = ST == 1;
+    // AoS transpose tile: CC whole columns per flush, row stride padded to an odd number of doubles
+    constexpr int CC = (48 / NSP) > 0 ? (48 / NSP) : 1, TW = CC * NSP, TWP = TW | 1;
+    __shared__ double TL[ST == 2 ? PJL_BLOCK / 64 : 1][ST == 2 ? 64 : 1][ST == 2 ? TWP : 1];
     // NASA lo/hi coefficient rows live in LDS: one ds_read per coefficient pair at an
     // address picked by the range test, instead of a v_cndmask per 32-bit half
     // plus the real-valued coefficient tables (Arrhenius / falloff / Troe parameters,
@@ -106,15 +114,18 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     for (int w = threadIdx.x; w < (int)(sizeof(pjs::EFFT) / 8); w += PJL_BLOCK) EFL[w][0] = pjs::EFFT[w][0];
     for (int w = threadIdx.x; w < NSP * 4; w += PJL_BLOCK) (&SPL[0][0])[w] = (&pjs::SPT[0][0])[w];
     __syncthreads();
-  for (long s = A.s0 + (long)blockIdx.x * PJL_BLOCK + threadIdx.x; s < A.n; s += (long)gridDim.x * PJL_BLOCK) {
+  for (long tb = A.s0 + (long)blockIdx.x * PJL_BLOCK; tb < A.n; tb += (long)gridDim.x * PJL_BLOCK) {
+    long s = tb + threadIdx.x;
+    if constexpr (ST == 2) { if (s >= A.n) s = A.n - 1; }     // every lane takes part in the transpose
+    else { if (s >= A.n) continue; }
     const double (*RDT)[RDW] = RDL;
     const double (*EFFT)[1] = EFL;
     const double (*SPT)[4] = SPL;
-    if constexpr (MODE != 0) {
+    if constexpr (MODE != 0 || ST == 2) {
         // Without global stores in the loop body the optimiser treats the LDS tables as loop
         // invariant and hoists hundreds of coefficient reads out of the persistent loop (spills);
         // hide the table addresses from it once per state.
-        asm volatile("" : "+v"(RDT), "+v"(EFFT), "+v"(SPT));
+        asm volatile("" : "+s"(RDT), "+s"(EFFT), "+s"(SPT));
     }
     const double* y = A.y + s * A.y_ss;
     const double T = y[0];
@@ -379,8 +390,28 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 // Jacobian entries are written once and not read back: nontemporal stores when a wavefront's
 // store is one contiguous line (SoA, NT = true); with a state stride between lanes (AoS) they are
 // partial-line writes and nontemporal is 7x slower than write-back caching
-#define JMEM(e, val) do { if constexpr (NT) __builtin_nontemporal_store((val), &Jl[(long)(e) * A.j_si]); \
+#define JMEM(e, val) do { if constexpr (ST == 2) TL[threadIdx.x / 64][threadIdx.x % 64][(e) - ((e) / NSP / CC) * TW] = (val); \
+                          else if constexpr (NT) __builtin_nontemporal_store((val), &Jl[(long)(e) * A.j_si]); \
                           else Jl[(long)(e) * A.j_si] = (val); } while (0)
+    // after column `col` is complete: write the tile's columns [c0, col] of this wavefront's states
+    auto flush = [&](auto colc) PJL_INL {
+        constexpr int col = decltype(colc)::value;
+        if constexpr (ST == 2 && ((col + 1) % CC == 0 || col == NSP - 1)) {
+            constexpr int c0 = col / CC * CC, w = (col + 1 - c0) * NSP;     // doubles per state in this flush
+            const int wv = threadIdx.x / 64, ln = threadIdx.x % 64;
+            const long wbase = tb + wv * 64;                                   // first state of the wavefront
+            const long nvalid = A.n - wbase;                                   // states of it inside the batch
+            double* const Jw = A.jac + (wbase - A.s0) * (long)(NSP * NSP) + c0 * NSP;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < w; ++i) {
+                const int idx = i * 64 + ln, st = idx / w, en = idx - st * w;
+                if (st < nvalid) Jw[(long)st * (NSP * NSP) + en] = TL[wv][st][en];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
 // e = row + NSP * col, compile-time wherever this is used
 #define JST(e, val) do { if constexpr (JV) ww[(e) % NSP] += (val) * vv[(e) / NSP]; else JMEM(e, val); } while (0)
     const double icp = 1.0 / cpavg;
@@ -389,6 +420,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         constexpr int k = decltype(kc)::value;
         JST(k + 1, SPT[k][1] * jt[k]);
     });
+    flush(std::integral_constant<int, 0>{});
     static_for<LAST>([&](auto jc) PJL_INL {
         constexpr int j = decltype(jc)::value;
         const double wj = SPT[j][3], iWj = SPT[j][0];
@@ -402,6 +434,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             if constexpr (k < LAST) JST(k + 1 + NSP * (j + 1), (SPT[k][1] * iWj) * m);
         });
         JST(NSP * (j + 1), -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp);
+        flush(std::integral_constant<int, j + 1>{});
     });
 #undef JST
 #undef JMEM
@@ -420,6 +453,7 @@ extern "C" {
 
 unsigned long long pj_spec_hash(void) { return PJS_HASH; }
 int pj_spec_nsp(void) { return NSP; }
+int pj_spec_fast_aos(void) { return 1; }   // AoS Jacobians go through the LDS transpose (k_lane<0, 2>)
 
 // layouts as in include/pyjac_amd.h: element (i, s) at base[i*si + s*ss]
 int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
@@ -431,7 +465,7 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<0, true>, PJL_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<0, 1>, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
     // launch in chunks whose per-lane byte offset into the Jacobian fits 32 bits
@@ -444,8 +478,10 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         long blocks = (s1 - s0 + PJL_BLOCK - 1) / PJL_BLOCK;
         if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-        if (j_ss == 1) hipLaunchKernelGGL((k_lane<0, true>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
-        else hipLaunchKernelGGL((k_lane<0, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        if (j_ss == 1) hipLaunchKernelGGL((k_lane<0, 1>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        else if (j_si == 1 && j_ss == NSP * NSP)
+            hipLaunchKernelGGL((k_lane<0, 2>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        else hipLaunchKernelGGL((k_lane<0, 0>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -462,14 +498,14 @@ int pj_spec_jacvec(long n, const double* pres, const double* y, long y_si, long 
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<1, false>, PJL_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<1, 0>, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
     Args A{n, pres, y, y_si, y_ss, nullptr, 0, 0, 0, sum_last, v, v_si, v_ss, w, w_si, w_ss,
            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     long blocks = (n + PJL_BLOCK - 1) / PJL_BLOCK;
     if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-    hipLaunchKernelGGL((k_lane<1, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL((k_lane<1, 0>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -483,14 +519,14 @@ int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<2, false>, PJL_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lane<2, 0>, PJL_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
     Args A{n, pres, y, y_si, y_ss, nullptr, 0, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0,
            conc, fwd, rev, pres_mod, spec_rates, dy, n};
     long blocks = (n + PJL_BLOCK - 1) / PJL_BLOCK;
     if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-    hipLaunchKernelGGL((k_lane<2, false>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL((k_lane<2, 0>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
