@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     constexpr bool NT = ST == 1;
     // AoS transpose tile: CC whole columns per flush, row stride padded to an odd number of doubles
     constexpr int CC = (48 / NSP) > 0 ? (48 / NSP) : 1, TW = CC * NSP, TWP = TW | 1;
-    __shared__ double TL[ST == 2 ? PJL_BLOCK / 64 : 1][ST == 2 ? 64 : 1][ST == 2 ? TWP : 1];
+    __shared__ double TL[PJL_BLOCK / 64][ST == 2 ? 64 : 1][TWP];   // 1.3 KB placeholder when unused
     // NASA lo/hi coefficient rows live in LDS: one ds_read per coefficient pair at an
     // address picked by the range test, instead of a v_cndmask per 32-bit half
     // plus the real-valued coefficient tables (Arrhenius / falloff / Troe parameters,
