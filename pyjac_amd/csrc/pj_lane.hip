@@ -428,7 +428,8 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         static_for<NSP>([&](auto kc) PJL_INL {
             constexpr int k = decltype(kc)::value;
             constexpr int si = pjs::SIDX[k][j];
-            double m = ANY_GN ? P[k] - wj * Q[k] : P[k] - wj * P[k];
+            double m;
+            if constexpr (ANY_GN) m = P[k] - wj * Q[k]; else m = P[k] - wj * P[k];
             if constexpr (si >= 0) m += S[si];
             tot += hW[k] * m;
             if constexpr (k < LAST) JST(k + 1 + NSP * (j + 1), (SPT[k][1] * iWj) * m);
