@@ -114,10 +114,12 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     for (int w = threadIdx.x; w < (int)(sizeof(pjs::EFFT) / 8); w += PJL_BLOCK) EFL[w][0] = pjs::EFFT[w][0];
     for (int w = threadIdx.x; w < NSP * 4; w += PJL_BLOCK) (&SPL[0][0])[w] = (&pjs::SPT[0][0])[w];
     __syncthreads();
-  for (long tb = A.s0 + (long)blockIdx.x * PJL_BLOCK; tb < A.n; tb += (long)gridDim.x * PJL_BLOCK) {
-    long s = tb + threadIdx.x;
-    if constexpr (ST == 2) { if (s >= A.n) s = A.n - 1; }     // every lane takes part in the transpose
-    else { if (s >= A.n) continue; }
+  // ST == 2: the trip count is workgroup-uniform (every lane takes part in the transpose; lanes past
+  // the end repeat the last state); otherwise a lane simply stops at the end of the batch
+  for (long sl = A.s0 + (long)blockIdx.x * PJL_BLOCK + threadIdx.x; (ST == 2 ? sl - threadIdx.x : sl) < A.n;
+       sl += (long)gridDim.x * PJL_BLOCK) {
+    const long tb = sl - threadIdx.x;
+    const long s = (ST == 2 && sl >= A.n) ? A.n - 1 : sl;
     const double (*RDT)[RDW] = RDL;
     const double (*EFFT)[1] = EFL;
     const double (*SPT)[4] = SPL;
