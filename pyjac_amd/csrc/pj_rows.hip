@@ -224,6 +224,12 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
         const double logT = log(T), invT = 1.0 / T, logp = log(p);
         double* const scr = scr_of(A, s);
 #define SCR_(slot) scr[(long)(slot) * PJR_SSTRIDE(A)]
+// written once per state, read back by later kernels from HBM: nontemporal unless PJR_SCR_NT=0
+#if defined(PJR_HOST_EMU) || (defined(PJR_SCR_NT) && !PJR_SCR_NT)
+#define SCR_ST(slot, val) (SCR_(slot) = (val))
+#else
+#define SCR_ST(slot, val) __builtin_nontemporal_store((val), &SCR_(slot))
+#endif
         double* const Jl = A.jac + s * A.j_ss;
 #define J_(e) Jl[(long)(e) * A.j_si]
         if constexpr (R0_ == 0) {
@@ -271,6 +277,7 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
         if constexpr (R0_ == 0) SCR_(SUM_SJT) = sjt; else SCR_(SUM_SJT) += sjt;
 #undef J_
 #undef SCR_
+#undef SCR_ST
 #undef CC
     }
 }
@@ -326,7 +333,14 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
     // energy-row partial sums: rarely touched, so the register allocator parks them in AGPRs
     double E[LAST > 0 ? LAST : 1];
     const double* const scr = scr_of(A, s);
+#ifndef PJR_LD_NT
+#define PJR_LD_NT 1        // scratch values are streamed through once per kernel: nontemporal loads (+1.5 %)
+#endif
+#if !defined(PJR_HOST_EMU) && PJR_LD_NT
+#define LD_(slot) __builtin_nontemporal_load(&scr[(long)(slot) * PJR_SSTRIDE(A)])
+#else
 #define LD_(slot) scr[(long)(slot) * PJR_SSTRIDE(A)]
+#endif
     double* const Jl = A.jac + s * A.j_ss;
 #define J_(e) Jl[(long)(e) * A.j_si]
     static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] = 0.0; });
@@ -456,6 +470,7 @@ __global__ void __launch_bounds__(PJR_WLANES * PJR_NW) k_fused(PjrArgs A)
 #endif
     double* const scr0 = A.scr + (long)blockIdx.x * ((long)pjs::NSCR * PJR_WLANES) + lane;
 #define SCR_(slot) scr[(slot) * PJR_WLANES]
+#define SCR_ST(slot, val) (SCR_(slot) = (val))
 #define LD_(slot) scr[(slot) * PJR_WLANES]
 #define CC(idx) ((idx) == ONE ? 1.0 : CL[(idx) == ONE ? 0 : (idx)][lane])
     auto conc = [&](auto spc) PJR_INL {
@@ -653,6 +668,7 @@ __global__ void __launch_bounds__(PJR_WLANES * PJR_NW) k_fused(PjrArgs A)
         for (int ph = 0; ph < 8; ++ph) g_tim[ph][w][blockIdx.x] = tacc[ph];
 #endif
 #undef SCR_
+#undef SCR_ST
 #undef LD_
 #undef CC
 #undef PJR_SP
