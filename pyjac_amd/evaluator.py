@@ -143,6 +143,7 @@ class Evaluator:
         os.makedirs(work, exist_ok=True)
         # lanes per workgroup: the concentration columns (8 NSP bytes per lane) must fit the LDS
         block = 256 if self.nsp * 256 * 8 <= 150 * 1024 else 128 if self.nsp * 128 * 8 <= 150 * 1024 else 64
+        block = int(os.environ.get('PJ_ROWS_BLOCK', block))
         base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c',
                 '-DPJS_HEADER="%s"' % hdr, '-DPJR_BLOCK=%d' % block, '-DPJR_C_LDS=%d' % int(self.nsp > 64),
                 '-I', os.path.join(here, 'csrc'), os.path.join(here, 'csrc', 'pj_rows.hip')]
