@@ -53,6 +53,9 @@ using namespace pj;
 #ifndef PJR_C_LDS
 #define PJR_C_LDS 0         // rate kernels: concentrations in LDS (set for large mechanisms)
 #endif
+#ifndef PJR_RECOMPUTE_KR
+#define PJR_RECOMPUTE_KR 0   // 1: row kernels rebuild c*k_r = c*k_f * exp(-ln K_c(T)) instead of reading it back
+#endif
 #define PJR_TICK_B(ph)      // phase timing hook of debug builds (fused kernel, -DPJR_TIMING)
 #define PJR_TILE 256        // states per scratch tile
 // Jacobian entries are written once and never read back by these kernels
@@ -309,12 +312,33 @@ constexpr int B0_ = PJR_B0, B1_ = PJR_B1;
 template <int i>
 constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
 
+// ln K_c of reaction i from the pre-summed NASA polynomials of its groups (rate_subs.py:660-809)
+template <int i>
+__device__ __forceinline__ double kc_ln(const double* lt, double T, double logT, double invT)
+{
+    double lnKc = pjs::RD[i][RD_LNPREF];
+    static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJR_INL {
+        constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
+        const double* a = lt + g * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+        lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
+    });
+    return lnKc;
+}
+
 __global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
 {
     // Concentrations live in LDS, one column per lane (bank-conflict free): the registers they
     // would occupy are worth more as landing space for scratch loads in flight -- at one
     // wavefront per SIMD the bytes in flight per lane bound the achieved HBM bandwidth.
     __shared__ double CL[NSP][PJR_BLOCK];
+#if PJR_RECOMPUTE_KR
+    // NASA row pairs of every K_c group: c*k_r is rebuilt from c*k_f here (one exp and a 7-term
+    // polynomial per visit, in issue slots the memory-bound kernel leaves idle) instead of being
+    // written by the rate kernel and read back ~3.6 times
+    __shared__ __attribute__((aligned(16))) double LTK[(pjs::LT_SP / 16 > 0 ? pjs::LT_SP / 16 : 1) * 16];
+    for (int x = threadIdx.x; x < pjs::LT_SP; x += PJR_BLOCK) LTK[x] = pjs::LTAB[pjs::LT_KC + x];
+    __syncthreads();
+#endif
     const long s = (long)blockIdx.x * PJR_BLOCK + threadIdx.x;
     if (s >= A.n) return;
     const int tid = threadIdx.x;
@@ -326,6 +350,10 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
         T = L.T; invrho = L.invrho; Wbar = L.Wbar;
         static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
     }
+#if PJR_RECOMPUTE_KR
+    const double logT = log(T), invT = 1.0 / T;
+#define PJR_KR_FROM_KF(i_, ckf_) ((ckf_) * exp(-kc_ln<i_>(LTK, T, logT, invT)))
+#endif
     auto conc = [&](auto spc) PJR_INL {
         constexpr int sp = decltype(spc)::value;
         if constexpr (sp == ONE) return 1.0; else return CL[sp][tid];
@@ -355,7 +383,8 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
         constexpr int i = pjs::BLK_RX[pjs::BLK_RX_PTR[decltype(bc)::value][0] + v][0];
         static_for<6>([&](auto cc) PJR_INL {
             constexpr int c = decltype(cc)::value;
-            if constexpr (pjs::SCR[i][c] >= 0) ring[v % PJR_DEPTH][c] = LD_(pjs::SCR[i][c]);
+            if constexpr (pjs::SCR[i][c] >= 0 && !(PJR_RECOMPUTE_KR && c == S_KR))
+                ring[v % PJR_DEPTH][c] = LD_(pjs::SCR[i][c]);
         });
     };
     auto prologue = [&](auto bc) PJR_INL {
@@ -412,6 +441,7 @@ struct Reg { Reg() { pjr_register(PJR_ID, 2, launch_part); } } reg_;
 #ifndef PJR_NW
 #define PJR_NW 4           // wavefronts per workgroup; arm a runs on wavefront a % PJR_NW
 #endif
+static_assert(!PJR_RECOMPUTE_KR, "the fused kernel reads c*k_r back from its scratch region");
 constexpr int NARM = 4;
 constexpr int NKC = pjs::LT_SP / 16;
 constexpr int NEFF = (int)(sizeof(pjs::EFF_AM1) / sizeof(pjs::EFF_AM1[0]));

@@ -144,8 +144,14 @@ class Evaluator:
         # lanes per workgroup: the concentration columns (8 NSP bytes per lane) must fit the LDS
         block = 256 if self.nsp * 256 * 8 <= 150 * 1024 else 128 if self.nsp * 128 * 8 <= 150 * 1024 else 64
         block = int(os.environ.get('PJ_ROWS_BLOCK', block))
+        # Row kernels rebuild c*k_r from c*k_f and K_c(T) instead of reading it back from the scratch
+        # array (-17 % HBM bytes, +3..6 % on MI355X) when the K_c polynomial table fits the LDS next
+        # to the concentration columns
+        lt_sp = int(re.search(r'LT_SP = (\d+)', open(hdr).read()).group(1))
+        recompute = int(os.environ.get('PJ_ROWS_RECOMPUTE_KR', int(lt_sp * 8 + self.nsp * block * 8 <= 156 * 1024)))
         base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c',
                 '-DPJS_HEADER="%s"' % hdr, '-DPJR_BLOCK=%d' % block, '-DPJR_C_LDS=%d' % int(self.nsp > 64),
+                '-DPJR_RECOMPUTE_KR=%d' % recompute,
                 '-I', os.path.join(here, 'csrc'), os.path.join(here, 'csrc', 'pj_rows.hip')]
         # rate kernels: fast-math as for the lane kernel.  Row kernels: no reassociation -- it
         # makes the compiler keep every product of an accumulation chain live (AGPR traffic)

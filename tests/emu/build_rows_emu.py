@@ -12,14 +12,14 @@ CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
 
 
 def build(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int = 128, c_lds: int = 0,
-          opt: str = '-O1') -> str:
+          opt: str = '-O1', defines=()) -> str:
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
     t = open(hdr).read()
     nblk = int(re.search(r'NBLK = (\d+)', t).group(1))
     nrxn = int(re.search(r'NRXN = (\d+)', t).group(1))
     base = ['g++', opt, '-std=c++17', '-fPIC', '-c', '-x', 'c++', '-DPJR_HOST_EMU', '-DPJR_BLOCK=1',
-            '-DPJR_C_LDS=%d' % c_lds, '-DPJS_HEADER="%s"' % hdr, '-I', HERE, '-I', CSRC,
+            '-DPJR_C_LDS=%d' % c_lds, '-DPJS_HEADER="%s"' % hdr] + list(defines) + ['-I', HERE, '-I', CSRC,
             os.path.join(CSRC, 'pj_rows.hip')]
     jobs = [(['-DPJR_PART=0'], 'host.o')]
     for n, r0 in enumerate(range(0, nrxn, rates_per_part)):

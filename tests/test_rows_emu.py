@@ -24,7 +24,7 @@ def _emu_lib(name, budget, tmp, **kw):
     ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
     hdr = os.path.join(tmp, '%s_%d.h' % (name, budget))
     _lib.check(_lib.lib().pj_mech_emit_rows_spec(ev._h, hdr.encode(), budget))
-    so = build_rows_emu.build(hdr, os.path.join(tmp, 'lib%s_%d.so' % (name, budget)), **kw)
+    so = build_rows_emu.build(hdr, os.path.join(tmp, 'lib%s_%d_%d.so' % (name, budget, len(kw.get('defines', ())))), **kw)
     L = ctypes.CDLL(so)
     L.pj_spec_jacobian.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp,
                                    ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
@@ -56,6 +56,9 @@ def _run(L, nsp, pres, y_soa, sum_last=0, aos=False):
     ('h2o2', 24, dict(blocks_per_part=3, rates_per_part=10)),
     ('h2o2_n2', 12, dict(blocks_per_part=100, rates_per_part=5)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+    # row kernels rebuild c*k_r from c*k_f and K_c(T) instead of reading it from the scratch array
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, defines=('-DPJR_RECOMPUTE_KR=1',))),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJR_RECOMPUTE_KR=1',))),
 ])
 def test_rows_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     from oracle.oracle import Oracle
