@@ -56,6 +56,9 @@ using namespace pj;
 #ifndef PJR_RECOMPUTE_KR
 #define PJR_RECOMPUTE_KR 0   // 1: row kernels rebuild c*k_r = c*k_f * exp(-ln K_c(T)) instead of reading it back
 #endif
+#ifndef PJR_RECOMPUTE_KF
+#define PJR_RECOMPUTE_KF 0   // 1: ... and k_f of plain Arrhenius reactions (no third body / falloff / PLOG) as well
+#endif
 #define PJR_TICK_B(ph)      // phase timing hook of debug builds (fused kernel, -DPJR_TIMING)
 #define PJR_TILE 256        // states per scratch tile
 // Jacobian entries are written once and never read back by these kernels
@@ -88,6 +91,9 @@ constexpr double INV_LN10 = 0.434294481903251828;
 constexpr int NSP = pjs::NSP, NRXN = pjs::NRXN, LAST = pjs::NSP - 1, ONE = pjs::NSP;
 constexpr int S_TH = 0, S_KF = 1, S_KR = 2, S_RP = 3, S_BM = 4, S_BC = 5;
 constexpr int SUM_H = pjs::NSCR, SUM_SCP = pjs::NSCR + 1, SUM_SJT = pjs::NSCR + 2;
+
+// plain Arrhenius reaction: c = 1 and k_f = sgn * exp(ln A + b ln T - Ta / T) is a function of T alone
+constexpr bool kf_plain(int i) { return (pjs::RI[i][RI_FLAGS] & (F_THD | F_PDEP | F_PLOG)) == 0; }
 
 #define PJR_INL __attribute__((always_inline))
 // compile-time loop: f(std::integral_constant<int, I0 + i>) for i = 0..N-1 (flat fold, no recursion)
@@ -353,6 +359,10 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
 #if PJR_RECOMPUTE_KR
     const double logT = log(T), invT = 1.0 / T;
 #define PJR_KR_FROM_KF(i_, ckf_) ((ckf_) * exp(-kc_ln<i_>(LTK, T, logT, invT)))
+#if PJR_RECOMPUTE_KF
+#define PJR_KF_PLAIN(i_) ((pjs::RD[i_][RD_SGN] < 0.0 ? -1.0 : 1.0) * \
+                          exp(pjs::RD[i_][RD_LNA] + pjs::RD[i_][RD_B] * logT - pjs::RD[i_][RD_TA] * invT))
+#endif
 #endif
     auto conc = [&](auto spc) PJR_INL {
         constexpr int sp = decltype(spc)::value;
@@ -383,7 +393,8 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rows(PjrArgs A)
         constexpr int i = pjs::BLK_RX[pjs::BLK_RX_PTR[decltype(bc)::value][0] + v][0];
         static_for<6>([&](auto cc) PJR_INL {
             constexpr int c = decltype(cc)::value;
-            if constexpr (pjs::SCR[i][c] >= 0 && !(PJR_RECOMPUTE_KR && c == S_KR))
+            if constexpr (pjs::SCR[i][c] >= 0 && !(PJR_RECOMPUTE_KR && c == S_KR) &&
+                          !(PJR_RECOMPUTE_KF && c == S_KF && kf_plain(i)))
                 ring[v % PJR_DEPTH][c] = LD_(pjs::SCR[i][c]);
         });
     };

@@ -59,6 +59,8 @@ def _run(L, nsp, pres, y_soa, sum_last=0, aos=False):
     # row kernels rebuild c*k_r from c*k_f and K_c(T) instead of reading it from the scratch array
     ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, defines=('-DPJR_RECOMPUTE_KR=1',))),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJR_RECOMPUTE_KR=1',))),
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7,
+                                defines=('-DPJR_RECOMPUTE_KR=1', '-DPJR_RECOMPUTE_KF=1', '-DPJR_DUMMY=1'))),
 ])
 def test_rows_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     from oracle.oracle import Oracle
