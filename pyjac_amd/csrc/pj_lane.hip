@@ -16,7 +16,11 @@
 // emitters: pyjac/core/rate_subs.py:254-2335, pyjac/core/create_jacobian.py:2189-3298.
 //
 // Built per mechanism:  hipcc --offload-arch=gfx950 -O3 -DPJS_HEADER='"<hdr>"' -shared -fPIC pj_lane.hip
+#ifdef PJL_HOST_EMU
+#include "hip_shim.h"      // tests/emu: one lane per workgroup on the CPU (test infrastructure)
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <cstdint>
 #include <type_traits>
 
@@ -99,7 +103,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     constexpr bool NT = ST == 1;
     // AoS transpose tile: CC whole columns per flush, row stride padded to an odd number of doubles
     constexpr int CC = (48 / NSP) > 0 ? (48 / NSP) : 1, TW = CC * NSP, TWP = TW | 1;
-    __shared__ double TL[PJL_BLOCK / 64][ST == 2 ? 64 : 1][TWP];   // 1.3 KB placeholder when unused
+    __shared__ double TL[(PJL_BLOCK + 63) / 64][ST == 2 ? 64 : 1][TWP];   // 1.3 KB placeholder when unused
     // NASA lo/hi coefficient rows live in LDS: one ds_read per coefficient pair at an
     // address picked by the range test, instead of a v_cndmask per 32-bit half
     // plus the real-valued coefficient tables (Arrhenius / falloff / Troe parameters,
@@ -127,7 +131,9 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         // Without global stores in the loop body the optimiser treats the LDS tables as loop
         // invariant and hoists hundreds of coefficient reads out of the persistent loop (spills);
         // hide the table addresses from it once per state.
+#ifndef PJL_HOST_EMU
         asm volatile("" : "+s"(RDT), "+s"(EFFT), "+s"(SPT));
+#endif
     }
     const double* y = A.y + s * A.y_ss;
     const double T = y[0];
@@ -482,8 +488,10 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         long blocks = (s1 - s0 + PJL_BLOCK - 1) / PJL_BLOCK;
         if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
         if (j_ss == 1) hipLaunchKernelGGL((k_lane<0, 1>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+#ifndef PJL_HOST_EMU                  // the transpose needs whole wavefronts
         else if (j_si == 1 && j_ss == NSP * NSP)
             hipLaunchKernelGGL((k_lane<0, 2>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+#endif
         else hipLaunchKernelGGL((k_lane<0, 0>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;

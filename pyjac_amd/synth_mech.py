@@ -144,7 +144,7 @@ def generate(nsp: int = 53, nrxn: int = 325, n_falloff: int = 29, n_thd: int = 4
         return '%-48s %10.3E %8.3f %10.2f' % (eq, A, b, E)
 
     def effs():
-        k = int(rng.integers(4, min(7, len(colliders)) + 1))
+        k = int(rng.integers(min(4, len(colliders)), min(7, len(colliders)) + 1))
         ch = list(rng.choice(colliders, size=k, replace=False))
         return ' '.join('%s/%.2f/' % (c, 0.0 if rng.random() < 0.08 else rng.uniform(0.4, 6.0)) for c in ch)
 

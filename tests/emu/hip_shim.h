@@ -38,6 +38,12 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return hipSuccess; }
 using std::exp; using std::log; using std::fmax;
 
+// clang / AMDGPU builtins used by the kernels
+#define __builtin_nontemporal_store(val, ptr) (*(ptr) = (val))
+#define __builtin_nontemporal_load(ptr) (*(ptr))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+
 // one thread per workgroup: blocks run one after the other
 template <class K, class... Args>
 inline void hip_shim_launch(K kernel, dim3 grid, dim3 block, Args... args)
