@@ -124,17 +124,17 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
        sl += (long)gridDim.x * PJL_BLOCK) {
     const long tb = sl - threadIdx.x;
     const long s = (ST == 2 && sl >= A.n) ? A.n - 1 : sl;
-    const double (*RDT)[RDW] = RDL;
-    const double (*EFFT)[1] = EFL;
-    const double (*SPT)[4] = SPL;
-    if constexpr (MODE != 0 || ST == 2) {
-        // Without global stores in the loop body the optimiser treats the LDS tables as loop
-        // invariant and hoists hundreds of coefficient reads out of the persistent loop (spills);
-        // hide the table addresses from it once per state.
+    // Without global stores in the loop body the optimiser treats the LDS tables as loop invariant
+    // and hoists hundreds of coefficient reads out of the persistent loop (spills).  An opaque zero
+    // offset per state stops that and keeps the pointers recognisable as LDS addresses (laundering
+    // the pointers themselves turns every coefficient read into a flat_load).
+    unsigned zoff = 0;
 #ifndef PJL_HOST_EMU
-        asm volatile("" : "+s"(RDT), "+s"(EFFT), "+s"(SPT));
+    if constexpr (MODE != 0 || ST == 2) asm volatile("" : "+s"(zoff));
 #endif
-    }
+    const double (*RDT)[RDW] = (const double (*)[RDW])((const char*)RDL + zoff);
+    const double (*EFFT)[1] = (const double (*)[1])((const char*)EFL + zoff);
+    const double (*SPT)[4] = (const double (*)[4])((const char*)SPL + zoff);
     const double* y = A.y + s * A.y_ss;
     const double T = y[0];
     const double p = A.pres[s];

@@ -80,6 +80,8 @@ struct PjrArgs {
     double* jac; long j_si, j_ss;      // chunk base
     double* scr; long ld;              // scratch [ld / PJR_TILE][NSCR + 3][PJR_TILE]
     int sum_last;
+    // rate-output launches (k_rates<true>, k_dy): SoA, leading dimension o_ld; sr is never null
+    double *conc, *fwd, *rev, *pres_mod, *sr, *dy; long o_ld, sr_ld;   // sr has its own leading dimension
 };
 typedef void (*pjr_launch_fn)(const PjrArgs&, void* stream);
 extern "C" void pjr_register(int id, int kind, pjr_launch_fn fn);
@@ -196,7 +198,10 @@ constexpr bool kc_first_in_range(int i)
 }
 constexpr int NEFF = (int)(sizeof(pjs::EFF_AM1) / sizeof(pjs::EFF_AM1[0]));
 
-__global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
+// RATES_OUT = false: hand-over to the row kernels (scratch array, d/dT column);
+// RATES_OUT = true: conc, fwd, rev, pres_mod and this range's share of spec_rates (pj_eval_rates_dev)
+template <bool RATES_OUT>
+__global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A0)
 {
     // real-valued coefficient tables of this reaction range, staged once per workgroup and
     // read with uniform ds_reads (as 64-bit literals they would be hoisted and spilled)
@@ -210,7 +215,14 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
     for (int w = threadIdx.x; w < (R1_ - R0_) * RDW; w += PJR_BLOCK) (&RDL[0][0])[w] = (&pjs::RDT[R0_][0])[w];
     for (int w = threadIdx.x; w < NEFF; w += PJR_BLOCK) EFL[w] = pjs::EFFT[w][0];
     __syncthreads();
-    for (long s = (long)blockIdx.x * PJR_BLOCK + threadIdx.x; s < A.n; s += (long)gridDim.x * PJR_BLOCK) {
+    for (long s = (long)blockIdx.x * PJR_BLOCK + threadIdx.x; s < A0.n; s += (long)gridDim.x * PJR_BLOCK) {
+        // The strides are the same every iteration; hide that from the optimiser, which would otherwise
+        // hoist every entry offset e * j_si (and slot * ld ...) out of this loop as SGPR pairs and spill
+        // them (SGPR -> VGPR lanes -> scratch).
+        PjrArgs A = A0;
+#ifndef PJR_HOST_EMU
+        asm volatile("" : "+s"(A.j_si), "+s"(A.y_si), "+s"(A.o_ld), "+s"(A.sr_ld), "+s"(A.ld));
+#endif
 #if PJR_C_LDS
         // large mechanisms: concentrations in LDS (one column per lane) instead of 2*NSP VGPRs
         double T, p, invrho, Wbar, mconc;
@@ -235,17 +247,37 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
 #define SCR_(slot) scr[(long)(slot) * PJR_SSTRIDE(A)]
 // written once per state, read back by later kernels from HBM: nontemporal unless PJR_SCR_NT=0
 #if defined(PJR_HOST_EMU) || (defined(PJR_SCR_NT) && !PJR_SCR_NT)
-#define SCR_ST(slot, val) (SCR_(slot) = (val))
+#define SCR_ST(slot, val) do { if constexpr (!RATES_OUT) SCR_(slot) = (val); } while (0)
 #else
-#define SCR_ST(slot, val) __builtin_nontemporal_store((val), &SCR_(slot))
+#define SCR_ST(slot, val) do { if constexpr (!RATES_OUT) __builtin_nontemporal_store((val), &SCR_(slot)); } while (0)
 #endif
-        double* const Jl = A.jac + s * A.j_ss;
+        double* const Jl = RATES_OUT ? nullptr : A.jac + s * A.j_ss;
 #define J_(e) Jl[(long)(e) * A.j_si]
-        if constexpr (R0_ == 0) {
+        auto rate_out = [&](auto ic, const double Rf, const double Rr, const double c) PJR_INL {
+            constexpr int i = decltype(ic)::value;
+            // rate_subs.py:634-658, 811-840, 1076-1283: indices are positions in the mechanism file
+            if (A.fwd) PJR_STORE(&A.fwd[pjs::RI[i][RI_ORIG] * A.o_ld + s], Rf);
+            if constexpr (pjs::RI[i][RI_REV_IDX] >= 0) { if (A.rev) PJR_STORE(&A.rev[pjs::RI[i][RI_REV_IDX] * A.o_ld + s], Rr); }
+            if constexpr (pjs::RI[i][RI_PRES_IDX] >= 0) {
+                if (A.pres_mod) PJR_STORE(&A.pres_mod[pjs::RI[i][RI_PRES_IDX] * A.o_ld + s], c);
+            }
+        };
+        if constexpr (!RATES_OUT && R0_ == 0) {
             // this part also clears what the row kernels accumulate into
             SCR_(SUM_H) = 0.0; SCR_(SUM_SCP) = 0.0;
             static_for<LAST>([&](auto jc) PJR_INL { J_(NSP * (decltype(jc)::value + 1)) = 0.0; });
         }
+        // With few unconditional global stores in the loop body the optimiser treats the LDS tables as
+        // loop invariant and hoists hundreds of coefficient reads out of the persistent loop (spills).
+        // An opaque zero offset per iteration stops that and, unlike laundering the pointers
+        // themselves, keeps them recognisable as LDS addresses (ds_read, not flat_load).
+        unsigned zoff = 0;
+#ifndef PJR_HOST_EMU
+        if constexpr (RATES_OUT) asm volatile("" : "+s"(zoff));
+#endif
+        const double (*rdl)[RDW] = (const double (*)[RDW])((const char*)RDL + zoff);
+        const double* lt = (const double*)((const char*)LT + zoff);
+        const double* efl = (const double*)((const char*)EFL + zoff);
         double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
         // d/dT column: sum_q nu_kq theta_q needs nothing but theta, so it is finished here and
         // theta never goes through the scratch array
@@ -253,9 +285,9 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
         static_for<NSP>([&](auto kc) PJR_INL { jt[decltype(kc)::value] = 0.0; });
         static_range<R0_, R1_>([&](auto ic) PJR_INL {
             constexpr int i = decltype(ic)::value;
-#define PJR_RD(i_) RDL[(i_) - R0_]
-#define PJR_KCROW(g_) (LT + ((g_) - KC_LO) * 16)
-#define PJR_EFL(e_) EFL[e_]
+#define PJR_RD(i_) rdl[(i_) - R0_]
+#define PJR_KCROW(g_) (lt + ((g_) - KC_LO) * 16)
+#define PJR_EFL(e_) efl[e_]
 #define PJR_KC_FIRST(i_) kc_first_in_range(i_)
 #include "pj_rows_rate.inc"
 #undef PJR_RD
@@ -263,6 +295,16 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A)
 #undef PJR_EFL
 #undef PJR_KC_FIRST
         });
+        if constexpr (RATES_OUT) {
+            // eval_conc output and this range's share of omega_k (rate_subs.py:1297-1542)
+            static_for<NSP>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (R0_ == 0) { if (A.conc) PJR_STORE(&A.conc[k * A.o_ld + s], CC(k)); }
+                if constexpr (R0_ == 0) A.sr[k * A.sr_ld + s] = jt[k];
+                else A.sr[k * A.sr_ld + s] += jt[k];
+            });
+            continue;
+        }
         // reference quirk (create_jacobian.py:2786-2818): the last species keeps only the d/dT
         // term of one reaction unless sum_last is set (see pj_kernel.h)
         if (!A.sum_last) jt[LAST] = (pjs::LASTQ >= R0_ && pjs::LASTQ < R1_) ? jtq : 0.0;
@@ -298,14 +340,28 @@ void launch_part(const PjrArgs& A, void* stream)
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rates, PJR_BLOCK, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rates<false>, PJR_BLOCK, 0);
         resident = (long)cus * (per_cu > 0 ? per_cu : 1);
     }
     long blocks = (A.n + PJR_BLOCK - 1) / PJR_BLOCK;
     if (blocks > resident) blocks = resident;
-    hipLaunchKernelGGL(k_rates, dim3((unsigned)blocks), dim3(PJR_BLOCK), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_rates<false>, dim3((unsigned)blocks), dim3(PJR_BLOCK), 0, (hipStream_t)stream, A);
 }
-struct Reg { Reg() { pjr_register(PJR_ID, 1, launch_part); } } reg_;
+void launch_part_out(const PjrArgs& A, void* stream)
+{
+    static long resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 256, per_cu = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rates<true>, PJR_BLOCK, 0);
+        resident = (long)cus * (per_cu > 0 ? per_cu : 1);
+    }
+    long blocks = (A.n + PJR_BLOCK - 1) / PJR_BLOCK;
+    if (blocks > resident) blocks = resident;
+    hipLaunchKernelGGL(k_rates<true>, dim3((unsigned)blocks), dim3(PJR_BLOCK), 0, (hipStream_t)stream, A);
+}
+struct Reg { Reg() { pjr_register(PJR_ID, 1, launch_part); pjr_register(PJR_ID, 3, launch_part_out); } } reg_;
 #endif  // PJR_PART == 1
 
 #if PJR_PART == 2
@@ -575,6 +631,8 @@ __global__ void __launch_bounds__(PJR_WLANES * PJR_NW) k_fused(PjrArgs A)
                 if (arm % PJR_NW == w) {
                     double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
                     double jt[NSP], jtq = 0.0;
+                    constexpr bool RATES_OUT = false;
+                    auto rate_out = [](auto, double, double, double) {};
                     static_for<NSP>([&](auto kc) PJR_INL { jt[decltype(kc)::value] = 0.0; });
                     static_for<(NRXN - arm + NARM - 1) / NARM>([&](auto nc) PJR_INL {
                         constexpr int i = arm + NARM * decltype(nc)::value;
@@ -771,8 +829,36 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_fin(PjrArgs A)
 #undef J_
 }
 
+// dydt from the complete omega_k (rate_subs.py:2171-2335): dT/dt = -sum h_k W_k omega_k / (rho cp),
+// dY_k/dt = omega_k W_k / rho
+__global__ void __launch_bounds__(PJR_BLOCK) k_dy(PjrArgs A)
+{
+    const long s = (long)blockIdx.x * PJR_BLOCK + threadIdx.x;
+    if (s >= A.n) return;
+    State L;
+    load_state(A, s, L);
+    const double T = L.T;
+    double cpavg = 0.0, Hs = 0.0;
+    static_for<NSP>([&](auto kc) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        const bool lo = T <= pjs::SP[k][2];
+        double a[6];
+        static_for<6>([&](auto cc) PJR_INL {
+            constexpr int c = decltype(cc)::value;
+            a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+        });
+        cpavg += L.C[k] * (RU_ * pjs::SP[k][0]) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+        const double hW = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                                 T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+        const double om = A.sr[k * A.sr_ld + s];
+        Hs += hW * om;
+        if constexpr (k < LAST) A.dy[(k + 1) * A.o_ld + s] = om * pjs::SP[k][1] * L.invrho;
+    });
+    A.dy[s] = -Hs / (L.rho * cpavg);
+}
+
 constexpr int MAXPARTS = 512;
-pjr_launch_fn g_rates[MAXPARTS], g_rows[MAXPARTS];
+pjr_launch_fn g_rates[MAXPARTS], g_rows[MAXPARTS], g_rates_out[MAXPARTS];
 double* g_scr[2] = {nullptr, nullptr};
 long g_scr_ld[2] = {0, 0};
 hipStream_t g_streams[2] = {nullptr, nullptr};
@@ -788,7 +874,7 @@ extern "C" {
 void pjr_register(int id, int kind, pjr_launch_fn fn)
 {
     if (id < 0 || id >= MAXPARTS) return;
-    (kind == 1 ? g_rates : g_rows)[id] = fn;
+    (kind == 1 ? g_rates : kind == 3 ? g_rates_out : g_rows)[id] = fn;
 }
 
 unsigned long long pj_spec_hash(void) { return PJS_HASH; }
@@ -841,7 +927,8 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
     for (long s0 = 0; s0 < n; s0 += chunk, ++c) {
         const long m = s0 + chunk < n ? chunk : n - s0;
         const int b = (int)(c % nbuf);
-        PjrArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, g_scr[b], g_scr_ld[b], sum_last};
+        PjrArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, g_scr[b], g_scr_ld[b], sum_last,
+                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
         // scratch buffer b is free again once the row kernels of chunk c-2 are done
         if (nbuf == 2 && c >= 2) (void)hipStreamWaitEvent(s_rates, g_events[EV_ROWS0 + b], 0);
         for (int i = 0; i < MAXPARTS; ++i) if (g_rates[i]) g_rates[i](A, s_rates);
@@ -857,6 +944,37 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         // join: the last event recorded on s_rows covers every chunk (one stream, in order); the rate
         // stream finished before it by construction
         (void)hipStreamWaitEvent(user, g_events[EV_ROWS0 + (int)((c - 1) % 2)], 0);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Rate outputs of one pass (pyjacob.cu:18-35 k_dydt): any pointer may be null; SoA, leading dimension n.
+int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y_ss, double* conc, double* fwd,
+                  double* rev, double* pres_mod, double* spec_rates, double* dy, void* stream)
+{
+    if (n <= 0) return 0;
+    // omega_k is accumulated across the rate kernels in memory: the caller's spec_rates array, or a
+    // chunk of the scratch array when only dydt is wanted
+    long chunk = n;
+    if (!spec_rates) {
+        chunk = 262144;
+        if (chunk > n) chunk = (n + PJR_TILE - 1) / PJR_TILE * PJR_TILE;
+        if (g_scr_ld[0] < chunk) {
+            if (g_scr[0]) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr[0]); g_scr[0] = nullptr; g_scr_ld[0] = 0; }
+            if (hipMalloc((void**)&g_scr[0], sizeof(double) * (size_t)(pjs::NSCR + 3) * (size_t)chunk) != hipSuccess) return -4;
+            g_scr_ld[0] = chunk;
+        }
+    }
+    for (long s0 = 0; s0 < n; s0 += chunk) {
+        const long m = s0 + chunk < n ? chunk : n - s0;
+        PjrArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, nullptr, 0, 0, nullptr, 0, 0,
+                  conc ? conc + s0 : nullptr, fwd ? fwd + s0 : nullptr, rev ? rev + s0 : nullptr,
+                  pres_mod ? pres_mod + s0 : nullptr, spec_rates ? spec_rates + s0 : g_scr[0],
+                  dy ? dy + s0 : nullptr, n, spec_rates ? n : g_scr_ld[0]};
+        for (int i = 0; i < MAXPARTS; ++i) if (g_rates_out[i]) g_rates_out[i](A, stream);
+        if (dy)
+            hipLaunchKernelGGL(k_dy, dim3((unsigned)((m + PJR_BLOCK - 1) / PJR_BLOCK)), dim3(PJR_BLOCK), 0,
+                               (hipStream_t)stream, A);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -896,7 +1014,8 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         if (hipMalloc((void**)&g_scr, sizeof(double) * (size_t)pjs::NSCR * PJR_WLANES * (size_t)wgs) != hipSuccess) return -4;
         g_scr_wgs = wgs;
     }
-    PjrArgs A{n, pres, y, y_si, y_ss, jac, j_si, j_ss, g_scr, 0, sum_last};
+    PjrArgs A{n, pres, y, y_si, y_ss, jac, j_si, j_ss, g_scr, 0, sum_last,
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     hipLaunchKernelGGL(k_fused, dim3((unsigned)wgs), dim3(PJR_WLANES * PJR_NW), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -153,9 +153,11 @@ class Evaluator:
                 '-DPJS_HEADER="%s"' % hdr, '-DPJR_BLOCK=%d' % block, '-DPJR_C_LDS=%d' % int(self.nsp > 64),
                 '-DPJR_RECOMPUTE_KR=%d' % recompute,
                 '-I', os.path.join(here, 'csrc'), os.path.join(here, 'csrc', 'pj_rows.hip')]
-        # rate kernels: fast-math as for the lane kernel.  Row kernels: no reassociation -- it
-        # makes the compiler keep every product of an accumulation chain live (AGPR traffic)
-        f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS', '-ffast-math').split()
+        # no reassociation anywhere: it makes the compiler keep every product of an accumulation
+        # chain live (AGPR traffic in the row kernels, 0.6 KB of spills per lane in the rate kernels)
+        f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS',
+                                 '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
+                                 '-ffinite-math-only').split()
         f_rows = os.environ.get('PJ_ROWS_FLAGS',
                                 '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math').split()
         jobs = [(f_rows + ['-DPJR_PART=0'], 'host.o')]

@@ -315,6 +315,40 @@ def test_lane_rate_kernel(name, layout, golden, tables, torch_cuda):
     assert mixed_err(lane['dydt'], g['dydt'], sdy) <= 1.0
 
 
+@pytest.mark.parametrize('name,n', [('synth_mid24', 3000), ('gri30_shaped', 1500), ('usc2_shaped', 300)])
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_row_block_rate_outputs(name, n, layout, tables, torch_cuda):
+    """k_rates<true> + k_dy of the row-block libraries (pj_eval_rates_dev for the larger mechanisms):
+    every output against the table-driven kernel, dydt also alone (omega_k then accumulates in the
+    library's scratch array)."""
+    import ctypes
+    import pyjac_amd
+    from pyjac_amd import _lib, synth
+    torch = torch_cuda
+    ev = _ev(name)
+    assert ev.spec_kernel == 'pj_rows'
+    pres, y = synth.dist_b(n, ev.nsp, seed=4, Tlo=600, Thi=2600)
+    d_p = torch.from_numpy(pres).cuda()
+    if layout == 'soa':
+        d_y, L = torch.from_numpy(y).cuda(), pyjac_amd.LAYOUT_SOA
+    else:
+        d_y, L = torch.from_numpy(np.ascontiguousarray(y.T)).cuda(), pyjac_amd.LAYOUT_AOS
+    lane = {k: v.cpu().numpy() for k, v in ev.rates(d_p, d_y, y_layout=L).items()}
+    dy = torch.full((ev.nsp, n), float('nan'), dtype=torch.float64, device='cuda')
+    _lib.check(_lib.lib().pj_eval_rates_dev(ev._h, n, d_p.data_ptr(), d_y.data_ptr(), L, None, None, None, None, None,
+                                            dy.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert np.array_equal(dy.cpu().numpy(), lane['dydt'])
+    ev.use_spec(False)
+    gen = {k: v.cpu().numpy() for k, v in ev.rates(d_p, d_y, y_layout=L).items()}
+    for k in ('conc', 'fwd', 'rev', 'pres_mod'):
+        mx, _ = thresholded_rel_err(lane[k].T, gen[k].T)
+        assert mx < 1e-9, (name, k, mx)
+    gross = np.maximum(np.abs(gen['fwd']).max(axis=0), np.abs(gen['rev']).max(axis=0)) + 1e-300
+    assert (np.abs(lane['spec_rates'] - gen['spec_rates']) / (1e-6 * np.abs(gen['spec_rates']) + 1e-10 * gross)).max() <= 1.0
+    sc = np.abs(gen['dydt']).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(lane['dydt'] - gen['dydt']) / (1e-6 * np.abs(gen['dydt']) + 1e-9 * sc)).max() <= 1.0
+
+
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
 def test_fused_row_block_kernel(layout, tables, torch_cuda):
     """The single-kernel variant of csrc/pj_rows.hip (4 wavefronts share a 64-state tile and split

@@ -12,7 +12,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'emu'))
-from conftest import MECHS, jac_scaled_err  # noqa: E402
+from conftest import MECHS, jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err  # noqa: E402
 import build_rows_emu  # noqa: E402
 import pyjac_amd  # noqa: E402
 from pyjac_amd import _lib, synth  # noqa: E402
@@ -80,6 +80,41 @@ def test_rows_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     finally:
         orc.lib.pjo_set_sum_last_species(0)
     assert jac_scaled_err(_run(L, ev.nsp, pres, y, sum_last=1), ref1, ev.nsp) <= 1.0
+
+
+@pytest.mark.parametrize('name,budget,kw', [
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+])
+def test_rows_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
+    """k_rates<true> + k_dy (pj_spec_rates of the row-block library): conc, fwd, rev, pres_mod,
+    spec_rates summed over several rate kernels, dydt -- with every array requested and with dydt only
+    (omega_k then lives in the library's scratch array)."""
+    from oracle.oracle import Oracle
+    ev, L = _emu_lib(name, budget, str(tmp_path), **kw)
+    L.pj_spec_rates.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long] + [_dp] * 6 + [ctypes.c_void_p]
+    tab = tables(name)
+    orc = Oracle(tab)
+    n, nsp = 300, ev.nsp
+    pres, y = synth.dist_b(n, nsp, seed=9, Tlo=600, Thi=2600)
+    y = np.ascontiguousarray(y)
+    y_aos = np.ascontiguousarray(y.T)
+    o = [orc.eval_all(float(pres[s]), y_aos[s]) for s in range(n)]
+    g = {k: np.array([x[k] for x in o]) for k in ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt')}
+    rows = dict(conc=nsp, fwd=ev.n_fwd, rev=max(ev.n_rev, 1), pres_mod=max(ev.n_pres_mod, 1), spec_rates=nsp, dy=nsp)
+    bufs = {k: np.full((r, n), np.nan) for k, r in rows.items()}
+    P = lambda a: a.ctypes.data_as(_dp)
+    assert L.pj_spec_rates(n, P(pres), P(y), n, 1, *[P(bufs[k]) for k in rows], None) == 0
+    for k, cols in (('conc', nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
+        if cols:
+            mx, _ = thresholded_rel_err(bufs[k].T[:, :cols], g[k][:, :cols])
+            assert mx < 1e-9, (k, mx)
+    gross, sdy = rate_scales(tab, pres, y_aos, g['conc'], g['fwd'], g['rev'], g['pres_mod'])
+    assert mixed_err(bufs['spec_rates'].T, g['spec_rates'], gross[:, None]) <= 1.0
+    assert mixed_err(bufs['dy'].T, g['dydt'], sdy) <= 1.0
+    dy2 = np.full((nsp, n), np.nan)
+    assert L.pj_spec_rates(n, P(pres), P(y), n, 1, None, None, None, None, None, P(dy2), None) == 0
+    assert np.array_equal(dy2, bufs['dy'])
 
 
 def test_rows_kernels_chunked_double_buffered(tmp_path, tables, monkeypatch):
