@@ -411,6 +411,26 @@ def test_row_block_kernels_mid_size(golden, torch_cuda):
         assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0 and fro < 1e-9, (mx, fro)
 
 
+@pytest.mark.parametrize('n', [1, 63, 65, 257])
+def test_row_block_kernels_small_batches(n, torch_cuda):
+    """Batches smaller than a wavefront / a workgroup / a scratch tile, and one past each boundary."""
+    import pyjac_amd
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev('synth_mid24')
+    assert ev.spec_kernel == 'pj_rows'
+    pres, y = synth.dist_b(n, ev.nsp, seed=n)
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    a = ev.jacobian(d_p, d_y).cpu().numpy().T
+    ra = ev.rates(d_p, d_y)['dydt'].cpu().numpy()
+    ev.use_spec(False)
+    b = ev.jacobian(d_p, d_y).cpu().numpy().T
+    rb = ev.rates(d_p, d_y)['dydt'].cpu().numpy()
+    assert np.isfinite(a).all() and jac_scaled_err(a, b, ev.nsp) <= 1.0
+    sc = np.abs(rb).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(ra - rb) / (1e-6 * np.abs(rb) + 1e-9 * sc)).max() <= 1.0
+
+
 def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
     """A batch larger than the scratch chunk (PJ_ROWS_CHUNK) runs as several chunks through the
     same scratch array; results must not depend on the chunking."""
