@@ -1,0 +1,835 @@
+// pj_rblk.hip -- state-per-lane Jacobian kernels for MEDIUM / LARGE mechanisms, second generation:
+// row blocks that REBUILD the reaction rates they need instead of reading them back.
+//
+// pj_rows.hip evaluates every reaction once (k_rates), hands c*k_f (and more) to the row-block
+// kernels through an HBM scratch array and reads it back ~3.6 times: 2.2x the algorithmic bytes, a
+// load queue that sits behind the Jacobian stores of the previous block (vmcnt is one in-order
+// counter on gfx9), and a compute-bound rate kernel that cannot share a SIMD with the row kernels.
+// Measured (profiles/r02_*): the row kernels wait 55 % and issue 24 % of their wave-cycles, the
+// instruction cache hits 99.5 % -- arithmetic is the resource that is left over.  So here:
+//
+//   k_rblk<B0,B1>  row blocks [B0,B1) of the Jacobian, one thermochemical state per lane,
+//                  concentrations in LDS (one column per lane).  A visit of reaction i rebuilds
+//                  k_f = exp(ln A + b ln T - Ta/T), K_c (pre-summed NASA polynomials + one exp), the
+//                  third-body concentration, theta_i = dq_i/dT and the cheap concentration products
+//                  from T, p and the LDS columns, and accumulates omega_k, P_k, Q_k, sum nu theta
+//                  (the d/dT column, finished here too) and the structurally non-zero S_kj of the
+//                  block's rows in registers with compile-time indices.  No loads in the steady
+//                  state: the Jacobian stores of block b drain while block b+1 is being computed.
+//   k_pre          the few reactions whose rate factor is expensive (falloff: Lindemann / Troe,
+//                  PLOG) are evaluated once per state and handed over: theta, c*k_f, rp, b_M, b_col --
+//                  4-5 doubles for ~10 % of the reactions.  Their loads for block b+1 are issued
+//                  BEFORE the stores of block b.
+//   energy row     partial sums in registers (AGPRs), carried between the kernels of one library
+//                  through hand-over slots that the next kernel loads with its state; the last kernel
+//                  finishes the row and jac[0].
+//
+// The mechanism is injected as constexpr tables (pj::emit_spec_header + pj::emit_rows_tables ->
+// PJS_HEADER); every loop is a compile-time loop.  One translation unit per kernel (PJQ_PART).
+//
+// Same formulation as pj_lane.hip / pj_rows.hip / pj_kernel.h; reference emitters:
+// pyjac/core/rate_subs.py:254-2335, pyjac/core/create_jacobian.py:2189-3298.
+//
+// PJQ_PART = 0: host entry points;  1: k_pre;  2: k_rblk<PJQ_B0,PJQ_B1> (PJQ_FIRST / PJQ_LAST: first /
+// last row kernel of the library).  PJQ_ID is the launch-order index of a row kernel.
+#ifdef PJR_HOST_EMU
+#include "hip_shim.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "pj_tables.h"
+#include PJS_HEADER
+
+using namespace pj;
+
+#ifndef PJQ_BLOCK
+#define PJQ_BLOCK 256
+#endif
+#ifndef PJQ_SB_EVERY
+#define PJQ_SB_EVERY 1      // scheduling barrier after every n-th visit (0: none)
+#endif
+#ifndef PJQ_DEPTH
+#define PJQ_DEPTH 4         // falloff / PLOG visits whose hand-over values are in flight
+#endif
+#ifndef PJQ_CONC_OPAQUE
+#define PJQ_CONC_OPAQUE 0
+#endif
+#ifndef PJQ_SPLIT
+#define PJQ_SPLIT 0         // scheduling barrier between the two phases of a visit
+#endif
+#ifndef PJQ_STREAMS
+#define PJQ_STREAMS 1       // internal streams the chunks of a batch are dealt to
+#endif
+#ifndef PJQ_CHUNK
+#define PJQ_CHUNK (1L << 20) // states per chunk
+#endif
+#ifndef PJQ_C_LDS
+#define PJQ_C_LDS 0         // k_pre: concentrations in LDS (set for large mechanisms)
+#endif
+#define PJQ_TILE 256        // states per scratch tile
+#if defined(PJR_HOST_EMU)
+#define PJQ_STORE(ptr, val) (*(ptr) = (val))
+#define PJQ_LOAD_NT(ptr) (*(ptr))
+#define PJQ_SCHED_BARRIER()
+#else
+// Jacobian entries are written once and never read back by these kernels
+#ifndef PJQ_NT_STORE
+#define PJQ_NT_STORE 1
+#endif
+#if defined(PJQ_NO_STORE)
+// experiment: the arithmetic without the Jacobian stores (values folded into one sink per lane)
+#define PJQ_STORE(ptr, val) (pjq_sink += (val))
+#elif PJQ_NT_STORE
+#define PJQ_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define PJQ_STORE(ptr, val) (*(ptr) = (val))
+#endif
+#define PJQ_LOAD_NT(ptr) __builtin_nontemporal_load(ptr)
+#define PJQ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// debug builds (-DPJQ_TIMING): shader cycles per phase and wavefront, summed over a kernel
+// (0 prologue, 1 Arrhenius visits, 2 hand-over visits, 3 output phase, 4 energy-row epilogue)
+#ifdef PJQ_TIMING
+#define PJQ_TICK(ph) { const long long tn_ = clock64(); tacc[ph] += tn_ - tprev; tprev = tn_; }
+#else
+#define PJQ_TICK(ph) {}
+#endif
+
+struct PjqArgs {
+    long n;                            // states of this chunk
+    const double* pres;                // chunk base
+    const double* y; long y_si, y_ss;  // chunk base
+    double* jac; long j_si, j_ss;      // chunk base
+    double* scr;                       // hand-over array [tile][NSCQ + 3][PJQ_TILE]
+    int sum_last;
+};
+typedef void (*pjq_launch_fn)(const PjqArgs&, void* stream);
+extern "C" void pjq_register(int id, int kind, pjq_launch_fn fn);
+
+namespace {
+
+constexpr double RU_ = 8314.4621;
+constexpr double INV_LN10 = 0.434294481903251828;
+constexpr int NSP = pjs::NSP, NRXN = pjs::NRXN, LAST = pjs::NSP - 1, ONE = pjs::NSP;
+constexpr int S_TH = 0, S_KF = 1, S_KR = 2, S_RP = 3, S_BM = 4, S_BC = 5;
+constexpr int SUM_H = pjs::NSCQ, SUM_SCP = pjs::NSCQ + 1, SUM_SJT = pjs::NSCQ + 2;
+constexpr int SUM_E = pjs::NSCQ + 3;            // energy-row partial sums, LAST slots
+constexpr int NSLOTS = pjs::NSCQ + 3 + (pjs::NSP - 1);
+
+// reactions evaluated once per state by k_pre and handed over
+constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG)) != 0; }
+
+#define PJR_INL __attribute__((always_inline))
+template <int I0, class F, int... Is>
+__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, I0 + Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (N > 0) static_for_seq<0>(f, std::make_integer_sequence<int, N>{});
+}
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_range(F&& f)
+{
+    if constexpr (I1 > I0) static_for_seq<I0>(f, std::make_integer_sequence<int, I1 - I0>{});
+}
+
+// exp(x) with the arithmetic of the device library's double-precision exp (same reduction and
+// polynomial) minus its range selects: ldexp saturates to 0 / inf by itself.  Two arguments at once,
+// statement by statement: the two Horner chains are independent and a lane at one wavefront per
+// SIMD has nothing else to fill the fp64 pipeline latency with.
+__device__ __forceinline__ void exp_pair(const double x0, const double x1, double& y0, double& y1)
+{
+    constexpr double LOG2E = 0x1.71547652b82fep+0, NLN2H = -0x1.62e42fefa39efp-1, NLN2L = -0x1.abc9e3b39803fp-56;
+    constexpr double C[10] = {0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22, 0x1.71dee623fde64p-19, 0x1.a01997c89e6bp-16,
+                              0x1.a01a014761f6ep-13, 0x1.6c16c1852b7bp-10, 0x1.1111111122322p-7, 0x1.55555555502a1p-5,
+                              0x1.5555555555511p-3, 0x1.000000000000bp-1};
+    const double n0 = __builtin_rint(x0 * LOG2E), n1 = __builtin_rint(x1 * LOG2E);
+    double r0 = __builtin_fma(n0, NLN2H, x0), r1 = __builtin_fma(n1, NLN2H, x1);
+    r0 = __builtin_fma(n0, NLN2L, r0); r1 = __builtin_fma(n1, NLN2L, r1);
+    double p0 = __builtin_fma(C[0], r0, C[1]), p1 = __builtin_fma(C[0], r1, C[1]);
+    static_for<8>([&](auto cc) PJR_INL {
+        constexpr int c = decltype(cc)::value + 2;
+        p0 = __builtin_fma(p0, r0, C[c]); p1 = __builtin_fma(p1, r1, C[c]);
+    });
+    p0 = __builtin_fma(r0, p0, 1.0); p1 = __builtin_fma(r1, p1, 1.0);
+    p0 = __builtin_fma(r0, p0, 1.0); p1 = __builtin_fma(r1, p1, 1.0);
+    y0 = __builtin_ldexp(p0, (int)n0); y1 = __builtin_ldexp(p1, (int)n1);
+}
+__device__ __forceinline__ double exp_one(const double x)
+{
+    double y0, y1;
+    exp_pair(x, x, y0, y1);
+    (void)y1;
+    return y0;
+}
+
+// hand-over layout [state tile][slot][PJQ_TILE]: what one workgroup reads and writes is one
+// contiguous NSLOTS * 2 KB region, each wave access is 512 B
+__device__ __forceinline__ double* scr_of(const PjqArgs& A, long s)
+{
+    return A.scr + (s / PJQ_TILE) * ((long)NSLOTS * PJQ_TILE) + (s % PJQ_TILE);
+}
+
+struct State {
+    double T, p, Wbar, rho, invrho, mconc;
+    double C[NSP + 1];
+};
+__device__ __forceinline__ void load_state(const PjqArgs& A, long s, State& L)
+{
+    const double* y = A.y + s * A.y_ss;
+    L.T = y[0];
+    L.p = A.pres[s];
+    // all loads first: left to itself the scheduler keeps two of them in flight and pays the memory
+    // latency NSP / 2 times per kernel
+    static_for<LAST>([&](auto kc) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        L.C[k] = y[(k + 1) * A.y_si];
+    });
+    PJQ_SCHED_BARRIER();
+    double sumY = 0.0, sumYW = 0.0;
+    static_for<LAST>([&](auto kc) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        sumY += L.C[k];
+        sumYW += L.C[k] * pjs::SP[k][0];
+    });
+    const double yN = 1.0 - sumY;
+    L.C[LAST] = yN;
+    sumYW += yN * pjs::SP[LAST][0];
+    L.Wbar = 1.0 / sumYW;
+    L.rho = L.p * L.Wbar / (RU_ * L.T);
+    L.invrho = 1.0 / L.rho;
+    L.mconc = L.p / (RU_ * L.T);
+}
+__device__ __forceinline__ void to_conc(State& L)
+{
+    static_for<NSP>([&](auto kc) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        L.C[k] = L.rho * L.C[k] * pjs::SP[k][0];
+    });
+    L.C[ONE] = 1.0;
+}
+
+#if PJQ_PART == 1
+// ------------------------------------------------------------------------------------------
+// k_pre: falloff / PLOG reactions once per state -> hand-over array
+// ------------------------------------------------------------------------------------------
+#define PJR_RECOMPUTE_KF 0
+#define PJR_RECOMPUTE_KR 1          // c*k_r is rebuilt by the row kernels
+#define PJR_SLOT(i_, c_) pjs::SCQ[i_][c_]
+constexpr bool kf_plain(int) { return false; }
+constexpr int NEFF = (int)(sizeof(pjs::EFF_AM1) / sizeof(pjs::EFF_AM1[0]));
+constexpr int NKC = pjs::LT_SP / 16;
+
+__global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
+{
+    // NASA row pairs of the K_c groups: the range select is per lane, so the rows are read from LDS
+    __shared__ __attribute__((aligned(16))) double LT[(NKC > 0 ? NKC : 1) * 16];
+#if PJQ_C_LDS
+    __shared__ double CLr[NSP][PJQ_BLOCK];
+#endif
+    for (int x = threadIdx.x; x < NKC * 16; x += PJQ_BLOCK) LT[x] = pjs::LTAB[pjs::LT_KC + x];
+    __syncthreads();
+    const long s = (long)blockIdx.x * PJQ_BLOCK + threadIdx.x;
+    if (s >= A.n) return;
+#if PJQ_C_LDS
+    double T, p, invrho, Wbar, mconc;
+    {
+        State L;
+        load_state(A, s, L);
+        to_conc(L);
+        T = L.T; p = L.p; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
+        static_for<NSP>([&](auto kc) PJR_INL { CLr[decltype(kc)::value][threadIdx.x] = L.C[decltype(kc)::value]; });
+    }
+#define CC(idx) ((idx) == ONE ? 1.0 : CLr[(idx) == ONE ? 0 : (idx)][threadIdx.x])
+#else
+    State L;
+    load_state(A, s, L);
+    to_conc(L);
+    const double T = L.T, p = L.p;
+    const double invrho = L.invrho, Wbar = L.Wbar, mconc = L.mconc;
+#define CC(idx) L.C[idx]
+#endif
+    const double logT = log(T), invT = 1.0 / T, logp = log(p);
+    double* const scr = scr_of(A, s);
+    constexpr bool RATES_OUT = false;
+    auto rate_out = [](auto, double, double, double) {};
+#ifdef PJR_HOST_EMU
+#define SCR_ST(slot, val) (scr[(long)(slot) * PJQ_TILE] = (val))
+#else
+#define SCR_ST(slot, val) __builtin_nontemporal_store((val), &scr[(long)(slot) * PJQ_TILE])
+#endif
+    double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
+    double jt[NSP], jtq = 0.0;          // d/dT sums are taken by the row kernels: dead here
+    static_for<NRXN>([&](auto ic) PJR_INL {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (is_pre(i)) {
+#define PJR_RD(i_) pjs::RD[i_]
+#define PJR_KCROW(g_) (LT + (g_) * 16)
+#define PJR_EFL(e_) pjs::EFF_AM1[e_][0]
+#define PJR_KC_FIRST(i_) true
+#define PJR_SCHED_BARRIER() PJQ_SCHED_BARRIER()
+#include "pj_rows_rate.inc"
+#undef PJR_RD
+#undef PJR_KCROW
+#undef PJR_EFL
+#undef PJR_KC_FIRST
+            PJQ_SCHED_BARRIER();
+        }
+    });
+    (void)jt; (void)jtq;
+#undef SCR_ST
+#undef CC
+}
+
+void launch_pre(const PjqArgs& A, void* stream)
+{
+    const long blocks = (A.n + PJQ_BLOCK - 1) / PJQ_BLOCK;
+    hipLaunchKernelGGL(k_pre, dim3((unsigned)blocks), dim3(PJQ_BLOCK), 0, (hipStream_t)stream, A);
+}
+struct Reg { Reg() { pjq_register(0, 1, launch_pre); } } reg_;
+#endif  // PJQ_PART == 1
+
+#if PJQ_PART == 2
+// ------------------------------------------------------------------------------------------
+// k_rblk<B0,B1>
+// ------------------------------------------------------------------------------------------
+constexpr int B0_ = PJQ_B0, B1_ = PJQ_B1;
+constexpr bool FIRST_ = PJQ_FIRST != 0, LASTK_ = PJQ_LAST != 0;
+constexpr int NKC = pjs::LT_SP / 16;
+
+template <int i>
+constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
+
+// visits of block b that read hand-over values
+template <int b>
+constexpr int n_pre_visits()
+{
+    int c = 0;
+    for (int v = pjs::BLK_RX_PTR[b][0]; v < pjs::BLK_RX_PTR[b + 1][0]; ++v) c += is_pre(pjs::BLK_RX[v][0]) ? 1 : 0;
+    return c;
+}
+#ifdef PJQ_TIMING
+__device__ long long g_tim[5][1024][4];
+#endif
+
+__global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
+{
+    // Concentrations live in LDS, one column per lane (bank-conflict free)
+    __shared__ double CL[NSP][PJQ_BLOCK];
+    // NASA row pairs of every K_c group (the low / high range select is per lane)
+    __shared__ __attribute__((aligned(16))) double LTK[(NKC > 0 ? NKC : 1) * 16];
+#ifdef PJQ_TIMING
+    long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64();
+#endif
+    const int tid = threadIdx.x;
+    // lanes past the end repeat the last state (same values to the same addresses): no divergence
+    long s = (long)blockIdx.x * PJQ_BLOCK + tid;
+    if (s >= A.n) s = A.n - 1;
+#ifdef PJQ_NO_STORE
+    double pjq_sink = 0.0;
+#endif
+    double T, rho, invrho, Wbar, mconc;
+    {
+        // one round trip for everything the prologue reads: the state and this thread's share of the
+        // K_c table are requested before anything waits (a load behind other workgroups' Jacobian
+        // stores takes microseconds)
+        struct __attribute__((aligned(16))) d2 { double x, y; };
+        constexpr int NLT2 = NKC * 8, NQ = (NLT2 + PJQ_BLOCK - 1) / PJQ_BLOCK;     // 16-byte pieces
+        d2 lt[NQ > 0 ? NQ : 1];
+        static_for<NQ>([&](auto qc) PJR_INL {
+            constexpr int q = decltype(qc)::value;
+            const int x = tid + q * PJQ_BLOCK;
+            lt[q] = ((const d2*)(pjs::LTAB + pjs::LT_KC))[x < NLT2 ? x : 0];
+        });
+        State L;
+        load_state(A, s, L);        // all loads, scheduling barrier, sums
+        static_for<NQ>([&](auto qc) PJR_INL {
+            constexpr int q = decltype(qc)::value;
+            const int x = tid + q * PJQ_BLOCK;
+            if (x < NLT2) ((d2*)LTK)[x] = lt[q];
+        });
+        to_conc(L);
+        T = L.T; rho = L.rho; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
+        static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
+    }
+    __syncthreads();
+#if defined(PJQ_STAGGER) && !defined(PJR_HOST_EMU)
+    // experiment: shift the compute / store phases of neighbouring workgroups against each other
+    {
+        const int ph = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 3));
+        for (int q = 0; q < ph; ++q) __builtin_amdgcn_s_sleep(PJQ_STAGGER);
+    }
+#endif
+    const double logT = log(T), invT = 1.0 / T;
+    // powers of T for the K_c polynomials (sum-of-products form: no dependent Horner chain)
+    const double T2 = T * T, T3 = T2 * T, T4 = T2 * T2;
+    const double T2d = 2.0 * T2, T3d = 3.0 * T3, T4d = 4.0 * T4;
+    const double WR = Wbar * invrho;
+    // A DS instruction reaches 64 KB from its address register; the columns of a 53-species mechanism
+    // span 106 KB.  Left alone the compiler keeps one address VGPR per column beyond the first 64 KB;
+    // an opaque zero offset per 32-column group gives it one base per group instead.
+    constexpr int CGRP = 65536 / (8 * PJQ_BLOCK) > 0 ? 65536 / (8 * PJQ_BLOCK) : 1;
+    constexpr int NCG = (NSP + CGRP - 1) / CGRP;
+    const double* clb[NCG];
+    static_for<NCG>([&](auto gc) PJR_INL {
+        constexpr int g = decltype(gc)::value;
+        unsigned zo = 0;
+#ifndef PJR_HOST_EMU
+        if constexpr (g > 0) asm volatile("" : "+v"(zo));
+#endif
+        clb[g] = (const double*)((const char*)&CL[g * CGRP][tid] + zo);
+    });
+    unsigned vzo = 0;      // opaque zero, renewed per visit (PJQ_CONC_OPAQUE): see the visit loop
+    auto conc = [&](auto spc) PJR_INL {
+        constexpr int sp = decltype(spc)::value;
+        if constexpr (sp == ONE) return 1.0;
+        else return ((const double*)((const char*)clb[sp / CGRP] + vzo))[(sp % CGRP) * PJQ_BLOCK];
+    };
+    // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
+    double E[LAST > 0 ? LAST : 1];
+    double H = 0.0, SCP = 0.0, SJT = 0.0;
+    const double* const scr = scr_of(A, s);
+    if constexpr (FIRST_) {
+        static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] = 0.0; });
+    } else {
+        // partial sums of the previous row kernel: fetched here, next to the state loads, so that no
+        // kernel ever waits for a load behind its own Jacobian stores
+        static_for<LAST>([&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+            E[j] = scr[(long)(SUM_E + j) * PJQ_TILE];
+        });
+        H = scr[(long)SUM_H * PJQ_TILE];
+        SCP = scr[(long)SUM_SCP * PJQ_TILE];
+        SJT = scr[(long)SUM_SJT * PJQ_TILE];
+    }
+    // Jacobian entry e of this lane's state: wavefront-uniform 64-bit base (entry offset e * j_si and
+    // the wavefront's first state: scalar arithmetic) + a 32-bit per-lane byte offset, so that a store
+    // is one instruction with an SGPR base and no 64-bit vector address arithmetic
+#ifdef PJR_HOST_EMU
+    const long s_wave = s;
+#else
+    const long s_wave = ((long)__builtin_amdgcn_readfirstlane((int)((unsigned long)s >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s);
+#endif
+    double* const Jw = A.jac + s_wave * A.j_ss;
+    const unsigned jvo = (unsigned)((s - s_wave) * A.j_ss) * 8u;
+#define J_(e) (*(double*)((char*)(Jw + (long)(e) * A.j_si) + jvo))
+
+    // hand-over values of the falloff / PLOG visits: those visits come last in a block
+    // (pj::emit_rows_tables), their values are fetched PJQ_DEPTH visits ahead into a register ring.
+    // vmcnt counts loads and stores in order, so a load waits for every store issued before it: the
+    // first loads of a block go out right after the previous block's stores and are consumed after
+    // the block's Arrhenius visits, by which time those stores have drained.
+    double ring[PJQ_DEPTH][6];
+    auto issue_pre = [&](auto bc, auto pc) PJR_INL {
+        constexpr int b = decltype(bc)::value, pp = decltype(pc)::value;
+        constexpr int v1 = pjs::BLK_RX_PTR[b + 1][0];
+        constexpr int i = pjs::BLK_RX[v1 - n_pre_visits<b>() + pp][0];
+        static_assert(is_pre(i), "falloff / PLOG visits must come last in a block");
+        static_for<6>([&](auto cc) PJR_INL {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (pjs::SCQ[i][c] >= 0)
+                ring[pp % PJQ_DEPTH][c] = PJQ_LOAD_NT(&scr[(long)pjs::SCQ[i][c] * PJQ_TILE]);
+        });
+    };
+
+    static_range<B0_, B1_>([&](auto bc) PJR_INL {
+        constexpr int b = decltype(bc)::value;
+        constexpr int r0 = pjs::BLK_ROW_PTR[b][0], nrows = pjs::BLK_ROW_PTR[b + 1][0] - r0;
+        constexpr int v0 = pjs::BLK_RX_PTR[b][0], nv = pjs::BLK_RX_PTR[b + 1][0] - v0;
+        double om[nrows], P[nrows], Q[nrows], JT[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
+        double JTQ = 0.0;
+        static_for<nrows>([&](auto rc) PJR_INL {
+            constexpr int r = decltype(rc)::value;
+            om[r] = 0.0; P[r] = 0.0; Q[r] = 0.0; JT[r] = 0.0;
+        });
+        static_for<pjs::BLK_NNZ[b][0]>([&](auto ec) PJR_INL { S[decltype(ec)::value] = 0.0; });
+        constexpr int npre = n_pre_visits<b>();
+        static_for<(npre < PJQ_DEPTH ? npre : PJQ_DEPTH)>([&](auto pc) PJR_INL { issue_pre(bc, pc); });
+        PJQ_SCHED_BARRIER();
+        if constexpr (b == B0_) PJQ_TICK(0)
+
+        static_for<nv>([&](auto vc) PJR_INL {
+            constexpr int v = decltype(vc)::value;
+            constexpr int i = pjs::BLK_RX[v0 + v][0];
+            constexpr int fl = pjs::RI[i][RI_FLAGS];
+            constexpr double nr = pjs::RD[i][RD_NR], np_ = pjs::RD[i][RD_NP];
+#if PJQ_CONC_OPAQUE && !defined(PJR_HOST_EMU)
+            // the concentration columns never change, so the optimiser would merge all reads of a
+            // column into one load and keep the value live across the kernel (register pressure)
+            asm volatile("" : "+v"(vzo));
+#endif
+            const double cr0 = conc(std::integral_constant<int, pjs::RI[i][RI_R0]>{}),
+                         cr1 = conc(std::integral_constant<int, pjs::RI[i][RI_R1]>{}),
+                         cr2 = conc(std::integral_constant<int, pjs::RI[i][RI_R2]>{});
+            const double cp0 = conc(std::integral_constant<int, pjs::RI[i][RI_P0]>{}),
+                         cp1 = conc(std::integral_constant<int, pjs::RI[i][RI_P1]>{}),
+                         cp2 = conc(std::integral_constant<int, pjs::RI[i][RI_P2]>{});
+            // ---- phase A: everything that has to travel (LDS reads of the concentration columns and
+            //      of the K_c polynomial rows) next to arithmetic that needs none of it (k_f) ----
+            constexpr int KCNT = (fl & F_REV) ? pjs::RI[i][RI_KC_CNT] : 0;
+            double ka[KCNT > 0 ? KCNT : 1][7];
+            static_for<KCNT>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value, g = pjs::RI[i][RI_KC_PTR] + c;
+                const double* a = LTK + g * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                static_for<7>([&](auto ec) PJR_INL { ka[c][decltype(ec)::value] = a[decltype(ec)::value]; });
+            });
+#if PJQ_SPLIT
+            PJQ_SCHED_BARRIER();
+#endif
+            // ---- phase B ----
+            const double pr_ = cr0 * cr1 * cr2, pp_ = cp0 * cp1 * cp2;
+            // Arrhenius (rate_subs.py:113-147); exp(-ln K_c) and T dlnK_c/dT from the pre-summed NASA
+            // polynomials of the reaction's groups (rate_subs.py:660-809); the two exponentials of a
+            // reversible reaction are evaluated side by side
+            double kf = 0.0, ekc = 0.0, td = 0.0, lnk = 0.0, lnKc = 0.0;
+            if constexpr (!is_pre(i))
+                lnk = pjs::RD[i][RD_LNA] + pjs::RD[i][RD_B] * logT - pjs::RD[i][RD_TA] * invT;
+            if constexpr ((fl & F_REV) != 0) {
+                lnKc = pjs::RD[i][RD_LNPREF];
+                static_for<KCNT>([&](auto cc) PJR_INL {
+                    constexpr int c = decltype(cc)::value;
+                    const double* a = ka[c];
+                    lnKc += a[0] + a[1] * logT + a[2] * T + a[3] * T2 + a[4] * T3 + a[5] * T4 - a[6] * invT;
+                    if constexpr (!is_pre(i))
+                        td += a[1] + a[2] * T + a[3] * T2d + a[4] * T3d + a[5] * T4d + a[6] * invT;
+                });
+            }
+            if constexpr (!is_pre(i) && (fl & F_REV) != 0) exp_pair(lnk, -lnKc, kf, ekc);
+            else if constexpr (!is_pre(i)) kf = exp_one(lnk);
+            else if constexpr ((fl & F_REV) != 0) ekc = exp_one(-lnKc);
+            if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
+            double ckf, ckr = 0.0, theta = 0.0, rp, bM = 0.0, bcol = 0.0;
+            if constexpr (is_pre(i)) {
+                // falloff / PLOG: handed over by k_pre
+                constexpr int pp = v - (nv - npre);
+                static_assert(pp >= 0, "falloff / PLOG visits must come last in a block");
+                ckf = ring[pp % PJQ_DEPTH][S_KF];
+                theta = ring[pp % PJQ_DEPTH][S_TH];
+                double rp_ld = 0.0;
+                if constexpr (pjs::SCQ[i][S_BM] >= 0) bM = ring[pp % PJQ_DEPTH][S_BM];
+                if constexpr (pjs::SCQ[i][S_BC] >= 0) bcol = ring[pp % PJQ_DEPTH][S_BC];
+                if constexpr (pjs::SCQ[i][S_RP] >= 0) rp_ld = ring[pp % PJQ_DEPTH][S_RP];
+                if constexpr (pp + PJQ_DEPTH < npre) issue_pre(bc, std::integral_constant<int, pp + PJQ_DEPTH>{});
+                if constexpr ((fl & F_REV) != 0) ckr = ckf * ekc;
+                if constexpr (pjs::SCQ[i][S_RP] >= 0) rp = rp_ld;
+                else rp = WR * ((1.0 - nr) * (ckf * pr_) - ((fl & F_REV) ? (1.0 - np_) * (ckr * pp_) : 0.0));
+            } else {
+                // optional third body (rate_subs.py:1076-1130)
+                const double Rf = kf * pr_;
+                double Rr = 0.0;
+                if constexpr ((fl & F_REV) != 0) Rr = (kf * ekc) * pp_;
+                const double R = Rf - Rr;
+                double c = 1.0, lead = 0.0;
+                if constexpr ((fl & F_THD) != 0) {
+                    double Mc = mconc;
+                    static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
+                        constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                        Mc += pjs::EFF_AM1[e][0] * conc(std::integral_constant<int, pjs::EFF_SP[e][0]>{});
+                    });
+                    c = Mc;
+                    lead = -c * R * invT;
+                    if constexpr ((fl & F_EFFTYPE) != 0) bM = R;
+                }
+                if constexpr ((fl & F_NO_DT) == 0) {
+                    const double dlnk = pjs::RD[i][RD_B] + pjs::RD[i][RD_TA] * invT;
+                    double el = R * dlnk + Rf * (1.0 - nr);
+                    if constexpr ((fl & F_REV) != 0) el -= Rr * ((1.0 - np_) - td);
+                    theta = (lead + c * invT * el) * invrho;
+                }
+                ckf = c * kf;
+                if constexpr ((fl & F_REV) != 0) ckr = ckf * ekc;
+                if constexpr ((fl & F_THD) != 0) {
+                    // create_jacobian.py:341-489: a_i and the b_i * [M] term of a third-body reaction
+                    double a = c * (nr * Rf - ((fl & F_REV) ? np_ * Rr : 0.0));
+                    if constexpr ((fl & F_EFFTYPE) != 0) a += c * R;
+                    rp = WR * (c * R - a) + bM;
+                } else {
+                    rp = WR * ((1.0 - nr) * Rf - ((fl & F_REV) ? (1.0 - np_) * Rr : 0.0));
+                }
+            }
+            const double q_ = ckf * pr_ - ckr * pp_;
+
+            double gN = 0.0;
+            if constexpr (has_anm1<i>()) gN = bM * pjs::RD[i][RD_ANM1];
+            constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
+            auto slot = [&](auto spc, const double gv) PJR_INL {
+                constexpr int sp = decltype(spc)::value;
+                if constexpr (sp == LAST) gN += gv;
+                else if constexpr (sp != ONE) {
+                    static_for<ncnt>([&](auto qc) PJR_INL {
+                        constexpr int q = np0 + decltype(qc)::value;
+                        constexpr int k = pjs::NET_SP[q][0];
+                        if constexpr (pjs::ROW_BLK[k][0] == b) {
+                            constexpr int si = pjs::SLOC[k][sp];
+                            static_assert(si >= 0, "sparse pattern and program disagree");
+                            S[si] += pjs::NET_NU[q][0] * gv;
+                        }
+                    });
+                }
+            };
+            slot(std::integral_constant<int, pjs::RI[i][RI_R0]>{}, ckf * (cr1 * cr2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_R1]>{}, ckf * (cr0 * cr2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_R2]>{}, ckf * (cr0 * cr1));
+            if constexpr ((fl & F_REV) != 0) {
+                slot(std::integral_constant<int, pjs::RI[i][RI_P0]>{}, -ckr * (cp1 * cp2));
+                slot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -ckr * (cp0 * cp2));
+                slot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -ckr * (cp0 * cp1));
+            }
+            if constexpr ((fl & F_COLLIDER) != 0)
+                slot(std::integral_constant<int, (pjs::RI[i][RI_COLLIDER] >= 0 ? pjs::RI[i][RI_COLLIDER] : ONE)>{}, bcol);
+            if constexpr ((fl & F_EFFTYPE) != 0) {
+                static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
+                    constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                    constexpr int es = pjs::EFF_SP[e][0];
+                    // the last species' enhanced efficiency is already in gN (RD_ANM1)
+                    if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, pjs::EFF_AM1[e][0] * bM);
+                });
+            }
+            const double rq = rp + gN;
+            static_for<ncnt>([&](auto qc) PJR_INL {
+                constexpr int q = np0 + decltype(qc)::value;
+                constexpr int k = pjs::NET_SP[q][0];
+                if constexpr (pjs::ROW_BLK[k][0] == b) {
+                    constexpr int r = pjs::ROWLOC[k][0];
+                    constexpr double nu = pjs::NET_NU[q][0];
+                    om[r] += nu * q_;
+                    P[r] += nu * rp;
+                    Q[r] += nu * rq;
+                    JT[r] += nu * theta;
+                    // reference quirk (create_jacobian.py:2786-2818): J_nplusone is assigned, not
+                    // accumulated -- the last species keeps the d/dT term of one reaction only
+                    if constexpr (k == LAST && i == pjs::LASTQ) JTQ = nu * theta;
+                }
+            });
+#if PJQ_SB_EVERY
+            if constexpr ((v + 1) % PJQ_SB_EVERY == 0) PJQ_SCHED_BARRIER();
+#endif
+            if constexpr (v + 1 == nv - npre) PJQ_TICK(1)
+            if constexpr (v + 1 == nv && npre > 0) PJQ_TICK(2)
+        });
+        PJQ_SCHED_BARRIER();
+
+        // rows of this block: NASA properties of its species, outputs, energy-row partials
+        double hW[nrows];
+        static_for<nrows>([&](auto rc) PJR_INL {
+            constexpr int r = decltype(rc)::value;
+            constexpr int k = pjs::BLK_ROWS[r0 + r][0];
+            const bool lo = T <= pjs::SP[k][2];
+            double a[6];
+            static_for<6>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value;
+                a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+            });
+            hW[r] = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                           T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+            const double cpk = (RU_ * pjs::SP[k][0]) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+            H += hW[r] * om[r];
+            SCP += om[r] * pjs::SP[k][1] * cpk;
+            // d/dT column (create_jacobian.py:2786-2818)
+            if constexpr (k < LAST) PJQ_STORE(&J_(k + 1), pjs::SP[k][1] * JT[r]);
+            if constexpr (k == LAST) SJT += hW[r] * (A.sum_last ? JT[r] : JTQ);
+            else SJT += hW[r] * JT[r];
+        });
+        static_for<LAST>([&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+            constexpr double wj = pjs::SP[j][3], iWj = pjs::SP[j][0];
+            double tot = 0.0;
+            static_for<nrows>([&](auto rc) PJR_INL {
+                constexpr int r = decltype(rc)::value;
+                constexpr int k = pjs::BLK_ROWS[r0 + r][0];
+                constexpr int si = pjs::SLOC[k][j];
+                double m = P[r] - wj * Q[r];
+                if constexpr (si >= 0) m += S[si];
+                tot += hW[r] * m;
+                if constexpr (k < LAST) PJQ_STORE(&J_(k + 1 + NSP * (j + 1)), (pjs::SP[k][1] * iWj) * m);
+            });
+            E[j] += tot;
+        });
+        PJQ_SCHED_BARRIER();
+        PJQ_TICK(3)
+    });
+
+    // ---- energy row: partial sums travel from kernel to kernel through hand-over slots (stored here,
+    //      loaded in the next kernel's prologue); the last kernel turns them into d(dT/dt)/d. ----
+    double* const sw = scr_of(A, s);
+    if constexpr (!LASTK_) {
+        sw[(long)SUM_H * PJQ_TILE] = H;
+        sw[(long)SUM_SCP * PJQ_TILE] = SCP;
+        sw[(long)SUM_SJT * PJQ_TILE] = SJT;
+        static_for<LAST>([&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+            sw[(long)(SUM_E + j) * PJQ_TILE] = E[j];
+        });
+    } else {
+        // rate_subs.py:2171-2335 / create_jacobian.py:2940-3120: mass-fraction weighted c_p sums
+        // from the concentrations, Y_k c_p,k = C_k R (a0 + ...) / rho
+        double cpa = 0.0, dcpa = 0.0, cpN = 0.0;
+        auto cp_of = [&](auto kc, double& cpm, double& dcpm) PJR_INL {
+            constexpr int k = decltype(kc)::value;
+            const bool lo = T <= pjs::SP[k][2];
+            double a[5];
+            static_for<5>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value;
+                a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+            });
+            cpm = a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T)));
+            dcpm = a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T));
+        };
+        static_for<NSP>([&](auto kc) PJR_INL {
+            constexpr int k = decltype(kc)::value;
+            double cpm, dcpm;
+            cp_of(kc, cpm, dcpm);
+            const double Ck = conc(kc);
+            cpa += Ck * cpm;
+            dcpa += Ck * dcpm;
+            if constexpr (k == LAST) cpN = (RU_ * pjs::SP[k][0]) * cpm;
+        });
+        const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
+        const double icp = 1.0 / cpavg;
+        PJQ_STORE(&J_(0), -(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg));
+        static_for<LAST>([&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+            double cpm, dcpm;
+            cp_of(jc, cpm, dcpm);
+            const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
+            PJQ_STORE(&J_(NSP * (j + 1)), -E[j] * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp);
+        });
+    }
+#ifdef PJQ_NO_STORE
+    if (pjq_sink == 1.2345e-300) J_(0) = pjq_sink;
+#endif
+#ifdef PJQ_TIMING
+    PJQ_TICK(4)
+    if ((tid & 63) == 0 && blockIdx.x < 1024)
+        for (int ph = 0; ph < 5; ++ph) g_tim[ph][blockIdx.x][tid >> 6] = tacc[ph];
+#endif
+#undef J_
+}
+
+void launch_part(const PjqArgs& A, void* stream)
+{
+    const long blocks = (A.n + PJQ_BLOCK - 1) / PJQ_BLOCK;
+    hipLaunchKernelGGL(k_rblk, dim3((unsigned)blocks), dim3(PJQ_BLOCK), 0, (hipStream_t)stream, A);
+}
+#ifdef PJQ_TIMING
+void read_timing(const PjqArgs& A, void*)   // A.scr: host buffer of 5 * 1024 * 4 long long
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol((void*)A.scr, HIP_SYMBOL(g_tim), sizeof(g_tim));
+}
+struct Reg { Reg() { pjq_register(PJQ_ID, 2, launch_part); pjq_register(PJQ_ID, 5, read_timing); } } reg_;
+#else
+struct Reg { Reg() { pjq_register(PJQ_ID, 2, launch_part); } } reg_;
+#endif
+#endif  // PJQ_PART == 2
+
+#if PJQ_PART == 0
+constexpr int MAXPARTS = 256;
+pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_timing[MAXPARTS];
+constexpr int MAXSTREAMS = 8;
+double* g_scr[MAXSTREAMS] = {};
+long g_scr_ld[MAXSTREAMS] = {};
+hipStream_t g_streams[MAXSTREAMS] = {};
+hipEvent_t g_events[MAXSTREAMS + 1];
+#endif
+
+}  // namespace
+
+#if PJQ_PART == 0
+extern "C" {
+
+void pjq_register(int id, int kind, pjq_launch_fn fn)
+{
+    if (kind == 1) g_pre = fn;
+    else if (id >= 0 && id < MAXPARTS) (kind == 5 ? g_timing : g_rows)[id] = fn;
+}
+
+// debug builds (-DPJQ_TIMING): cycles per phase of row kernel `part`, [5][1024 workgroups][4 wavefronts]
+int pj_spec_debug_timing(int part, long long* out)
+{
+    if (part < 0 || part >= MAXPARTS || !g_timing[part]) return -1;
+    PjqArgs A{};
+    A.scr = (double*)out;
+    g_timing[part](A, nullptr);
+    return 0;
+}
+
+unsigned long long pj_spec_hash(void) { return PJS_HASH; }
+int pj_spec_nsp(void) { return NSP; }
+int pj_spec_kind(void) { return 4; }   // 1: pj_lane.hip, 2: pj_rows.hip, 3: pj_rows.hip fused, 4: pj_rblk.hip
+long pj_spec_scratch_doubles_per_state(void) { return NSLOTS; }
+
+// layouts as in include/pyjac_amd.h: element (i, s) at base[i*si + s*ss].  One batch at a time per
+// library (the hand-over arrays are shared): calls on different streams must not overlap.
+//
+// The batch runs in chunks, chunk c on internal stream c % S with its own hand-over array: all
+// wavefronts of one launch move through "compute a block / store its rows" in step, so a single
+// stream alternates between a busy memory system with idle SIMDs and the reverse; kernels of
+// different chunks are out of step with each other.  The internal streams are forked from and joined
+// to the caller's stream with events: the call is asynchronous and ordered like one kernel launch on
+// `stream`.  PJ_RBLK_STREAMS=1: everything on the caller's stream.
+int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
+                     long j_si, long j_ss, int sum_last, void* stream)
+{
+    if (n <= 0) return 0;
+    static int nstreams = 0;
+    static long chunk_env = 0;
+    if (!nstreams) {
+        const char* e = getenv("PJ_RBLK_STREAMS");
+        nstreams = e ? atoi(e) : PJQ_STREAMS;
+        if (nstreams < 1) nstreams = 1;
+        if (nstreams > MAXSTREAMS) nstreams = MAXSTREAMS;
+        if (const char* c = getenv("PJ_RBLK_CHUNK")) chunk_env = atol(c);
+    }
+    // chunks: a multiple of the tile, at least 2 per stream when the batch fills the device several times
+    long chunk = chunk_env >= 256 ? chunk_env : PJQ_CHUNK;
+    chunk = (chunk + PJQ_TILE - 1) / PJQ_TILE * PJQ_TILE;
+    if (chunk > n) chunk = (n + PJQ_TILE - 1) / PJQ_TILE * PJQ_TILE;
+    const long nchunks = (n + chunk - 1) / chunk;
+    const int S = (int)(nchunks < nstreams ? nchunks : nstreams);
+    for (int b = 0; b < S; ++b) {
+        if (g_scr_ld[b] >= chunk) continue;
+        if (g_scr[b]) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr[b]); g_scr[b] = nullptr; g_scr_ld[b] = 0; }
+        if (hipMalloc((void**)&g_scr[b], sizeof(double) * (size_t)NSLOTS * (size_t)chunk) != hipSuccess) return -4;
+        g_scr_ld[b] = chunk;
+    }
+    hipStream_t user = (hipStream_t)stream;
+    if (S > 1) {
+        if (!g_streams[0]) {
+            for (auto& st : g_streams)
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -3;
+            for (auto& e : g_events)
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -3;
+        }
+        (void)hipEventRecord(g_events[MAXSTREAMS], user);
+        for (int b = 0; b < S; ++b) (void)hipStreamWaitEvent(g_streams[b], g_events[MAXSTREAMS], 0);
+    }
+    long c = 0;
+    for (long s0 = 0; s0 < n; s0 += chunk, ++c) {
+        const long m = s0 + chunk < n ? chunk : n - s0;
+        const int b = (int)(c % S);
+        void* st = S > 1 ? (void*)g_streams[b] : stream;
+        PjqArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, g_scr[b], sum_last};
+        if (g_pre) g_pre(A, st);
+        for (int i = 0; i < MAXPARTS; ++i) if (g_rows[i]) g_rows[i](A, st);
+    }
+    if (S > 1)
+        for (int b = 0; b < S; ++b) {
+            (void)hipEventRecord(g_events[b], g_streams[b]);
+            (void)hipStreamWaitEvent(user, g_events[b], 0);
+        }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // extern "C"
+#endif

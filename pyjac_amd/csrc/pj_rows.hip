@@ -98,6 +98,7 @@ constexpr int SUM_H = pjs::NSCR, SUM_SCP = pjs::NSCR + 1, SUM_SJT = pjs::NSCR + 
 constexpr bool kf_plain(int i) { return (pjs::RI[i][RI_FLAGS] & (F_THD | F_PDEP | F_PLOG)) == 0; }
 
 #define PJR_INL __attribute__((always_inline))
+#define PJR_SLOT(i_, c_) pjs::SCR[i_][c_]      // hand-over slots of pj_rows_rate.inc
 // compile-time loop: f(std::integral_constant<int, I0 + i>) for i = 0..N-1 (flat fold, no recursion)
 template <int I0, class F, int... Is>
 __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, Is...>)
@@ -333,6 +334,7 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_rates(PjrArgs A0)
     }
 }
 
+#ifndef PJR_RATES_LIB
 void launch_part(const PjrArgs& A, void* stream)
 {
     static long resident = 0;
@@ -347,6 +349,7 @@ void launch_part(const PjrArgs& A, void* stream)
     if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL(k_rates<false>, dim3((unsigned)blocks), dim3(PJR_BLOCK), 0, (hipStream_t)stream, A);
 }
+#endif
 void launch_part_out(const PjrArgs& A, void* stream)
 {
     static long resident = 0;
@@ -361,7 +364,11 @@ void launch_part_out(const PjrArgs& A, void* stream)
     if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL(k_rates<true>, dim3((unsigned)blocks), dim3(PJR_BLOCK), 0, (hipStream_t)stream, A);
 }
+#ifdef PJR_RATES_LIB   // rate outputs only (the Jacobian kernels of the library are pj_rblk.hip's)
+struct Reg { Reg() { pjr_register(PJR_ID, 3, launch_part_out); } } reg_;
+#else
 struct Reg { Reg() { pjr_register(PJR_ID, 1, launch_part); pjr_register(PJR_ID, 3, launch_part_out); } } reg_;
+#endif
 #endif  // PJR_PART == 1
 
 #if PJR_PART == 2
@@ -858,6 +865,8 @@ __global__ void __launch_bounds__(PJR_BLOCK) k_dy(PjrArgs A)
 }
 
 constexpr int MAXPARTS = 512;
+// rows of a scratch array: the hand-over slots + 3 sums, or NSP rows when pj_spec_rates keeps omega_k there
+constexpr int SCR_ROWS = (pjs::NSCR + 3 > NSP) ? pjs::NSCR + 3 : NSP;
 pjr_launch_fn g_rates[MAXPARTS], g_rows[MAXPARTS], g_rates_out[MAXPARTS];
 double* g_scr[2] = {nullptr, nullptr};
 long g_scr_ld[2] = {0, 0};
@@ -877,6 +886,7 @@ void pjr_register(int id, int kind, pjr_launch_fn fn)
     (kind == 1 ? g_rates : kind == 3 ? g_rates_out : g_rows)[id] = fn;
 }
 
+#ifndef PJR_RATES_LIB
 unsigned long long pj_spec_hash(void) { return PJS_HASH; }
 int pj_spec_nsp(void) { return NSP; }
 int pj_spec_kind(void) { return 2; }   // 1: pj_lane.hip, 2: pj_rows.hip
@@ -906,7 +916,7 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
     for (int b = 0; b < nbuf; ++b) {
         if (g_scr_ld[b] >= chunk) continue;
         if (g_scr[b]) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr[b]); g_scr[b] = nullptr; g_scr_ld[b] = 0; }
-        if (hipMalloc((void**)&g_scr[b], sizeof(double) * (size_t)(pjs::NSCR + 3) * (size_t)chunk) != hipSuccess) return -4;
+        if (hipMalloc((void**)&g_scr[b], sizeof(double) * (size_t)SCR_ROWS * (size_t)chunk) != hipSuccess) return -4;
         g_scr_ld[b] = chunk;
     }
     hipStream_t user = (hipStream_t)stream, s_rates = user, s_rows = user;
@@ -948,6 +958,8 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+#endif  // !PJR_RATES_LIB
+
 // Rate outputs of one pass (pyjacob.cu:18-35 k_dydt): any pointer may be null; SoA, leading dimension n.
 int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y_ss, double* conc, double* fwd,
                   double* rev, double* pres_mod, double* spec_rates, double* dy, void* stream)
@@ -961,7 +973,7 @@ int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y
         if (chunk > n) chunk = (n + PJR_TILE - 1) / PJR_TILE * PJR_TILE;
         if (g_scr_ld[0] < chunk) {
             if (g_scr[0]) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr[0]); g_scr[0] = nullptr; g_scr_ld[0] = 0; }
-            if (hipMalloc((void**)&g_scr[0], sizeof(double) * (size_t)(pjs::NSCR + 3) * (size_t)chunk) != hipSuccess) return -4;
+            if (hipMalloc((void**)&g_scr[0], sizeof(double) * (size_t)SCR_ROWS * (size_t)chunk) != hipSuccess) return -4;
             g_scr_ld[0] = chunk;
         }
     }

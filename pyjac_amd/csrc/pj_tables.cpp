@@ -576,7 +576,7 @@ std::string emit_spec_header(const Programs& p)
         dev_arr("SPF", p.sp, SPW);      // full species records (pj_rows.hip fused kernel)
     }
     o += "#endif\n";
-    o += "#ifdef __HIPCC__\n__device__ const double LTAB[LT_SIZE] = {\n";
+    o += "#ifdef __HIPCC__\n__device__ __attribute__((aligned(16))) const double LTAB[LT_SIZE] = {\n";
     auto row = [&](const double* lo, const double* hi) {
         for (int c = 0; c < 7; ++c) { d(lo[c]); o += ","; }
         o += "0,";
@@ -621,7 +621,7 @@ std::string emit_rows_tables(const Programs& p, int budget)
         const int32_t* ri = &p.ri[(size_t)i * RIW];
         for (int q = 0; q < ri[RI_NET_CNT]; ++q) rx_of[p.net_sp[ri[RI_NET_PTR] + q]].push_back(i);
     }
-    const int DENSE = 3;
+    const int DENSE = 4;      // omega_k, P_k, Q_k and (pj_rblk.hip) sum nu theta per row
     std::vector<int> blk_of(nsp, -1);
     std::vector<std::vector<int>> blocks;
     std::vector<std::vector<char>> blk_rx;
@@ -666,7 +666,12 @@ std::string emit_rows_tables(const Programs& p, int budget)
                 if (p.prog[p.p4en + k + nsp * j] & 255u) sloc[(size_t)k * nsp + j] = bnnz[b]++;
         }
         brow_ptr.push_back((int32_t)brows.size());
-        for (int i = 0; i < nrxn; ++i) if (blk_rx[b][i]) brx.push_back(i);
+        // falloff / PLOG reactions last: pj_rblk.hip reads their hand-over values from memory, and a
+        // load issued at the top of a block sits behind the previous block's Jacobian stores
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i < nrxn; ++i)
+                if (blk_rx[b][i] && ((p.ri[(size_t)i * RIW + RI_FLAGS] & (F_PDEP | F_PLOG)) != 0) == (pass == 1))
+                    brx.push_back(i);
         brx_ptr.push_back((int32_t)brx.size());
         maxrows = std::max(maxrows, loc);
         maxnnz = std::max(maxnnz, (int)bnnz[b]);
@@ -682,6 +687,21 @@ std::string emit_rows_tables(const Programs& p, int budget)
         if (fl & (F_THD | F_PDEP)) scr[(size_t)i * 6 + 3] = nscr++;
         if (fl & F_EFFTYPE) scr[(size_t)i * 6 + 4] = nscr++;
         if (fl & F_COLLIDER) scr[(size_t)i * 6 + 5] = nscr++;
+    }
+    // pj_rblk.hip: only falloff / PLOG reactions are handed over (a pre-pass evaluates them once per
+    // state); everything else is rebuilt from T and the concentrations at every visit.
+    // slots: theta, c*kf, (c*kr: never, rebuilt from K_c), rp, bM, bcol
+    std::vector<int32_t> scq((size_t)nrxn * 6, -1);
+    int nscq = 0, npre = 0;
+    for (int i = 0; i < nrxn; ++i) {
+        const int fl = p.ri[(size_t)i * RIW + RI_FLAGS];
+        if (!(fl & (F_PDEP | F_PLOG))) continue;
+        ++npre;
+        scq[(size_t)i * 6 + 0] = nscq++;
+        scq[(size_t)i * 6 + 1] = nscq++;
+        if (fl & (F_THD | F_PDEP)) scq[(size_t)i * 6 + 3] = nscq++;
+        if (fl & F_EFFTYPE) scq[(size_t)i * 6 + 4] = nscq++;
+        if (fl & F_COLLIDER) scq[(size_t)i * 6 + 5] = nscq++;
     }
     // fused kernel: row blocks dealt to 4 wavefronts, longest-processing-time first, with the
     // measured cost model (cycles): ~770 per reaction visit, ~14000 per row of Jacobian stores
@@ -720,6 +740,8 @@ std::string emit_rows_tables(const Programs& p, int budget)
     arr_i("BLK_NNZ", bnnz, 1);
     arr_i("SLOC", sloc, nsp);
     arr_i("SCR", scr, 6);
+    o += "constexpr int NSCQ = " + std::to_string(nscq) + ", NPRE = " + std::to_string(npre) + ";\n";
+    arr_i("SCQ", scq, 6);
     arr_i("ARM_BLK_PTR", arm_ptr, 1);
     arr_i("ARM_BLKS", arm_list, 1);
     o += "}  // namespace pjs\n";

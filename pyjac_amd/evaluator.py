@@ -60,7 +60,8 @@ class Evaluator:
         """Which specialised kernel family specialize(build=True) compiles for this mechanism."""
         return 'lane' if self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN else 'rows'
 
-    _SPEC_STEM = {'lane': 'libpj_spec_%016x.so', 'rows': 'libpj_rows_%016x.so', 'fused': 'libpj_fused_%016x.so'}
+    _SPEC_STEM = {'lane': 'libpj_spec_%016x.so', 'rows': 'libpj_rows_%016x.so', 'fused': 'libpj_fused_%016x.so',
+                  'rblk': 'libpj_rblk_%016x.so'}
 
     def spec_path(self, kind: str = None) -> str:
         h = _lib.lib().pj_mech_spec_hash(self._h)
@@ -73,7 +74,7 @@ class Evaluator:
         'fused' is the single-kernel variant of pj_rows.hip (one translation unit: minutes to
         compile for a 53-species mechanism; coefficient tables of all reactions must fit the LDS)."""
         L = _lib.lib()
-        kinds = [kind] if kind else [self.spec_kind()] + [k for k in ('lane', 'fused', 'rows') if k != self.spec_kind()]
+        kinds = [kind] if kind else [self.spec_kind()] + [k for k in ('lane', 'rblk', 'fused', 'rows') if k != self.spec_kind()]
         so = next((self.spec_path(k) for k in kinds if os.path.exists(self.spec_path(k))), None)
         if so is None:
             if not build:
@@ -83,6 +84,8 @@ class Evaluator:
                 self._build_lane(so)
             elif kinds[0] == 'fused':
                 self._build_fused(so, **rows_opts)
+            elif kinds[0] == 'rblk':
+                self._build_rblk(so, **rows_opts)
             else:
                 self._build_rows(so, **rows_opts)
         check(L.pj_mech_attach_spec(self._h, so.encode()))
@@ -178,11 +181,79 @@ class Evaluator:
                               [os.path.join(work, j[1]) for j in jobs])
         shutil.rmtree(work, ignore_errors=True)
 
+    RBLK_BUDGET = 56          # accumulator doubles per row block of pj_rblk.hip (4 dense + non-zero S per row)
+    RBLK_FUSE = 8             # row blocks per kernel
+
+    def _build_rblk(self, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=()):
+        """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the
+        falloff / PLOG reactions), linked with the rate-output kernels of csrc/pj_rows.hip
+        (-DPJR_RATES_LIB: pj_spec_rates).  One translation unit per kernel, compiled in parallel."""
+        import re
+        import shutil
+        import subprocess
+        from concurrent.futures import ThreadPoolExecutor
+        L = _lib.lib()
+        here = os.path.dirname(os.path.abspath(__file__))
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        hdr = so[:-3] + '.h'
+        budget = int(budget or os.environ.get('PJ_RBLK_BUDGET', self.RBLK_BUDGET))
+        fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', self.RBLK_FUSE))
+        rpp = int(rates_per_part or os.environ.get('PJ_ROWS_RATES_PER_PART', self.ROWS_RATES_PER_PART))
+        check(L.pj_mech_emit_rows_spec(self._h, hdr.encode(), budget))
+        t = open(hdr).read()
+        nblk = int(re.search(r'NBLK = (\d+)', t).group(1))
+        npre = int(re.search(r'NPRE = (\d+)', t).group(1))
+        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        work = so[:-3] + '.obj'
+        os.makedirs(work, exist_ok=True)
+        # lanes per workgroup: the concentration columns (8 NSP bytes per lane) + the K_c table must fit the LDS
+        lt_sp = int(re.search(r'LT_SP = (\d+)', t).group(1))
+        fits = lambda b: self.nsp * b * 8 + lt_sp * 8 <= 158 * 1024
+        block = 256 if fits(256) else 128 if fits(128) else 64
+        block = int(os.environ.get('PJ_RBLK_BLOCK', block))
+        c_lds = int(self.nsp > 64)
+        common = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr,
+                  '-I', os.path.join(here, 'csrc')]
+        f_rows = os.environ.get('PJ_RBLK_FLAGS',
+                                '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math').split()
+        f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS',
+                                 '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
+                                 '-ffinite-math-only').split()
+        rblk = common + f_rows + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds] + list(defines) + \
+            os.environ.get('PJ_RBLK_DEFINES', '').split() + [os.path.join(here, 'csrc', 'pj_rblk.hip')]
+        rows = common + ['-DPJR_BLOCK=%d' % (256 if self.nsp * 256 * 8 <= 150 * 1024 else 128),
+                         '-DPJR_C_LDS=%d' % c_lds, '-DPJR_RATES_LIB', os.path.join(here, 'csrc', 'pj_rows.hip')]
+        jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o'), (rows + f_rows + ['-DPJR_PART=0'], 'rhost.o')]
+        if npre:
+            jobs.append((rblk + ['-DPJQ_PART=1'], 'pre.o'))
+        # row kernels of (nearly) equal block counts, at most `fuse` blocks each
+        nker = (nblk + fuse - 1) // fuse
+        bounds = [nblk * i // nker for i in range(nker + 1)]
+        for i in range(nker):
+            jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i], '-DPJQ_B1=%d' % bounds[i + 1],
+                                 '-DPJQ_FIRST=%d' % (i == 0), '-DPJQ_LAST=%d' % (i == nker - 1)], 'rblk%d.o' % i))
+        for i, r0 in enumerate(range(0, self.n_fwd, rpp)):
+            jobs.append((rows + f_rates + ['-DPJR_PART=1', '-DPJR_ID=%d' % i, '-DPJR_R0=%d' % r0,
+                                           '-DPJR_R1=%d' % min(self.n_fwd, r0 + rpp)], 'rates%d.o' % i))
+        # longest first so the pool drains evenly
+        jobs.sort(key=lambda j: 0 if j[1].startswith('rates') else 1 if j[1].startswith('rblk') else 2)
+
+        def run(job):
+            subprocess.check_call(job[0] + ['-o', os.path.join(work, job[1])])
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+            list(ex.map(run, jobs))
+        tmp = so + '.tmp.%d' % os.getpid()
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] +
+                              [os.path.join(work, j[1]) for j in jobs])
+        os.replace(tmp, so)
+        shutil.rmtree(work, ignore_errors=True)
+
     @property
     def spec_kernel(self) -> str:
         """'pj_lane' / 'pj_rows' for the attached specialisation, '' if none."""
         so = os.path.basename(self.attached_spec or '')
         return ('pj_lane' if so.startswith('libpj_spec_') else 'pj_rows' if so.startswith('libpj_rows_')
+                else 'pj_rblk' if so.startswith('libpj_rblk_')
                 else 'pj_fused' if so.startswith('libpj_fused_') else '')
 
     @property
