@@ -11,8 +11,9 @@ timed region.  Rank 0 prints ONE JSON line.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workloads (BASELINE.json configs):
+    gri  GRI-3.0-shaped synthetic, 53 sp / 325 rxn, 1e6 states/GPU, Dist-B (configs 3-4; default:
+         the configuration BASELINE.json's metric is quoted on)
     h2   H2/O2+N2, 10 sp / 28 rxn, 1e6 states/GPU, Dist-A "PaSR-tiled"     (config 2)
-    gri  GRI-3.0-shaped synthetic, 53 sp / 325 rxn, 1e6 states/GPU, Dist-B (configs 3-4)
     usc  USC-II-shaped synthetic, 111 sp / 784 rxn w/ PLOG, 2e5 states     (config 5)
 """
 import argparse
@@ -57,11 +58,22 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(w, tables, target_seconds=12.0):
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(w, tables, target_seconds=16.0):
     """Reference's generated C (oracle/_ref, kind "reference") when that library
     travelled with the snapshot, else the table-driven port (kind "port"), timed
     on this box's host cores on a bounded sample of the same workload with the
-    protocol of pyjac/performance_tester/tester.c.in:23-31."""
+    protocol of pyjac/performance_tester/tester.c.in:23-31 (OpenMP parallel-for over
+    states): at one thread and at every usable core.  `value` is the all-cores rate."""
     import numpy as np
     from oracle.oracle import Oracle, Reference
     cores = usable_cpus()
@@ -70,19 +82,36 @@ def cpu_baseline(w, tables, target_seconds=12.0):
     else:
         impl, kind = Oracle(tables, native=True), 'port'
     nsp = tables.nsp
-    pres, y = make_states(w, nsp, 200_000 if nsp <= 16 else 20_000, seed=99)
+    pres, y = make_states(w, nsp, 200_000 if nsp <= 16 else 20_000 if nsp <= 64 else 4_000, seed=99)
     y_aos = np.ascontiguousarray(y.T)
     n = pres.size
-    impl.batch_jacob(pres, y_aos, cores)            # warm-up pass (page faults, thread pool)
-    passes, dt = 0, 0.0
-    t0 = time.perf_counter()
-    while dt < target_seconds:
-        impl.batch_jacob(pres, y_aos, cores)
-        passes += 1
-        dt = time.perf_counter() - t0
-    return dict(value=passes * n / dt, unit='Jacobians/s', cores=cores, kind=kind,
-                sample='%d passes over %d states of the same synthetic distribution, OpenMP '
-                       'parallel-for over states (%d threads), %.1f s' % (passes, n, cores, dt))
+
+    def rate(threads, seconds, nn):
+        impl.batch_jacob(pres[:nn], y_aos[:nn], threads)          # warm-up pass (page faults, thread pool)
+        passes, dt = 0, 0.0
+        t0 = time.perf_counter()
+        while dt < seconds:
+            impl.batch_jacob(pres[:nn], y_aos[:nn], threads)
+            passes += 1
+            dt = time.perf_counter() - t0
+        return passes * nn / dt, passes, dt
+    n1 = max(256, n // 16)
+    r1, p1, t1 = rate(1, target_seconds * 0.4, n1)
+    rN, pN, tN = rate(cores, target_seconds * 0.6, n)
+    return dict(value=rN, unit='Jacobians/s', cores=cores, kind=kind, one_thread=r1, cpu=cpu_model(),
+                sample='%d passes over %d states on %d threads (%.1f s) and %d passes over %d states on 1 thread '
+                       '(%.1f s) of the same synthetic distribution, OpenMP parallel-for over states'
+                       % (pN, n, cores, tN, p1, n1, t1))
+
+
+def end_to_end(ev, w, n_sample, np):
+    """PCIe-inclusive time of the reference's CUDA harness (tester.cu.in:109-156: H2D of the states,
+    kernel, D2H of the Jacobians, pageable host memory) on a bounded sample; secondary figure."""
+    from pyjac_amd.performance_tester import speedtest
+    pres, y = make_states(w, ev.nsp, n_sample, seed=7)
+    r = speedtest(ev, pres, y, repeats=2, quiet=True)
+    return dict(states=n_sample, ms=r['end_to_end_ms'], jacobians_per_s=n_sample / r['end_to_end_ms'] * 1e3,
+                note='H2D + kernels + D2H through pj_run (tester.cu.in:109-156 protocol), pageable host buffers')
 
 
 def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0):
@@ -104,6 +133,7 @@ def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0):
 
 def kernel_label(ev):
     return {'pj_lane': 'pj_lane (register-resident state-per-lane kernel)',
+            'pj_rblk': 'pj_rblk (state-per-lane row-block kernels that rebuild their rates + falloff/PLOG pre-pass)',
             'pj_rows': 'pj_rows (state-per-lane rate + row-block kernels)',
             'pj_fused': 'pj_rows fused (4 wavefronts per 64-state tile, one kernel)'}.get(
                 ev.spec_kernel if ev.has_spec else '', 'k_eval (table-driven)')
@@ -165,17 +195,26 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
-    torch.cuda.set_device(local_rank)
+    # PJ_BENCH_STUB=1 (tests/test_bench_gloo.py only): the multi-rank control flow of this file --
+    # partition, barriers, MAX-reduce of the elapsed time, validation gather and checksums -- on CPU
+    # tensors over gloo with a stand-in for the evaluator; never a measurement
+    stub = os.environ.get('PJ_BENCH_STUB') == '1'
+    backend = os.environ.get('PJ_DIST_BACKEND', 'gloo' if stub else 'nccl')
+    if not stub:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, 'launch with --nproc-per-node equal to --gpus'
+    if stub:
+        return stub_main(a, world, rank, torch, dist, np)
 
     wl = a.workload
     if wl == 'auto':
-        # BASELINE.json configs[1]: the configuration its Target sentence is quoted on
-        wl = 'h2'
+        # BASELINE.json `metric` is quoted on the GRI-Mech 3.0 batch (configs[2], fits one GPU: 22.5 GB of
+        # Jacobian); GRI-Mech 3.0 itself is not available offline: same-shape synthetic mechanism
+        wl = 'gri'
     w = WORKLOADS[wl]
     ev = open_mechanism(pyjac_amd, w['mech'], dist if world > 1 else None, local_rank)
     n = a.states or w['n']
@@ -242,7 +281,7 @@ def main():
         bj = ev.jacobian_bytes_per_state
         achieved = n * bj / (ms_kernel * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % wl)
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % wl)   # rocprofv3 PMC passes of this round
         if os.path.exists(tpath):
             # PMC-measured HBM bytes of this kernel (profiles/README.md); a streaming map, so
             # a launch over n states moves n / states_per_launch times the profiled bytes
@@ -323,10 +362,57 @@ def main():
                     line['also']['rate_pass'] = {'error': repr(ex)}
         if world == 1 and not a.no_cpu_baseline:
             try:
+                line['end_to_end'] = end_to_end(ev, w, 65536 if ev.nsp <= 64 else 16384, np)
+            except Exception as ex:
+                line['end_to_end'] = {'error': repr(ex)}
+            try:
                 line['cpu_baseline'] = cpu_baseline(w, ev.tables)
             except Exception as ex:   # the baseline is reported, never required
                 line['cpu_baseline'] = {'error': repr(ex)}
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def stub_main(a, world, rank, torch, dist, np):
+    """The N > 1 branch of main() with a CPU stand-in for the evaluator (see PJ_BENCH_STUB above)."""
+    from pyjac_amd.dist import gather_shards, shard_checksums
+    rows, n = 9, 4096
+    lo = rank * n                         # every rank owns n states (weak scaling)
+    st = torch.arange(lo, lo + n, dtype=torch.float64)
+    jac = torch.empty((rows, n), dtype=torch.float64)
+
+    def step():
+        jac.copy_(torch.sin(1e-3 * st)[None, :] * torch.arange(1, rows + 1, dtype=torch.float64)[:, None])
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) >= elapsed
+        elapsed = float(t.item())
+    validation = None
+    if world > 1:
+        nv = min(a.validate_states, n)
+        shard = jac[:, :nv].contiguous()
+        g = gather_shards(shard)
+        cs = shard_checksums(shard)
+        ok = bool(torch.equal(g[rank], shard)) and bool(torch.isfinite(g).all())
+        for r in range(world):
+            ok &= bool(torch.allclose(cs[r, 0], g[r].sum()))
+        validation = dict(states_per_rank=nv, gathered_bytes=int(g.numel() * 8), ok=ok)
+    if rank == 0:
+        print(json.dumps({'metric': 'stub (control flow only)', 'value': world * n * a.steps / elapsed, 'unit': 'states/s',
+                          'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3,
+                          'scaling': 'weak', 'validation_allgather': validation}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

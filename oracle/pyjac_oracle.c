@@ -16,7 +16,7 @@
  * Parity pin: checked in this container against the reference's generated
  * code (oracle/build_ref.py -> oracle/_ref/libpyjac_ref_<mech>.so) on the
  * reference's own PaSR fixture and on synthetic mechanisms covering every
- * supported reaction type; see tests/test_oracle_vs_reference.py and the
+ * supported reaction type; see tests/test_oracle_golden.py and the
  * committed golden vectors under tests/golden/.
  *
  * Each function cites the reference emitter (file:line under /root/reference)

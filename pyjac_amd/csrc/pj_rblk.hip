@@ -68,6 +68,9 @@ using namespace pj;
 #ifndef PJQ_CHUNK
 #define PJQ_CHUNK (1L << 20) // states per chunk
 #endif
+#ifndef PJQ_LAUNDER_EVERY
+#define PJQ_LAUNDER_EVERY 1  // blocks between opaque copies of T's functions (0: never)
+#endif
 #ifndef PJQ_C_LDS
 #define PJQ_C_LDS 0         // k_pre: concentrations in LDS (set for large mechanisms)
 #endif
@@ -81,13 +84,19 @@ using namespace pj;
 #ifndef PJQ_NT_STORE
 #define PJQ_NT_STORE 1
 #endif
+#ifndef PJQ_PAIR
+#define PJQ_PAIR 0          // 1: two Jacobian columns per 16-byte store (SoA output, whole workgroups)
+#endif
 #if defined(PJQ_NO_STORE)
 // experiment: the arithmetic without the Jacobian stores (values folded into one sink per lane)
 #define PJQ_STORE(ptr, val) (pjq_sink += (val))
+#define PJQ_STORE2(ptr, val) (pjq_sink += (val).x + (val).y)
 #elif PJQ_NT_STORE
 #define PJQ_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define PJQ_STORE2(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
 #define PJQ_STORE(ptr, val) (*(ptr) = (val))
+#define PJQ_STORE2(ptr, val) (*(ptr) = (val))
 #endif
 #define PJQ_LOAD_NT(ptr) __builtin_nontemporal_load(ptr)
 #define PJQ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
@@ -172,6 +181,18 @@ __device__ __forceinline__ double exp_one(const double x)
     return y0;
 }
 
+#if PJQ_PAIR
+typedef double d2s __attribute__((ext_vector_type(2)));
+// value of the other lane of an (even, odd) lane pair
+__device__ __forceinline__ double swap_pair(const double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0xB1, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+#endif
+
 // hand-over layout [state tile][slot][PJQ_TILE]: what one workgroup reads and writes is one
 // contiguous NSLOTS * 2 KB region, each wave access is 512 B
 __device__ __forceinline__ double* scr_of(const PjqArgs& A, long s)
@@ -218,6 +239,40 @@ __device__ __forceinline__ void to_conc(State& L)
     L.C[ONE] = 1.0;
 }
 
+// K_c groups a kernel needs, in order of first use: only their NASA row pairs are staged in LDS
+// (the whole table of a 111-species mechanism is 100 KB)
+constexpr int NKC_ALL = pjs::LT_SP / 16;
+struct KcMap { int loc[NKC_ALL > 0 ? NKC_ALL : 1]; int list[NKC_ALL > 0 ? NKC_ALL : 1]; int n; };
+constexpr void kcmap_add(KcMap& m, int i)
+{
+    if (!(pjs::RI[i][RI_FLAGS] & F_REV)) return;
+    for (int c = 0; c < pjs::RI[i][RI_KC_CNT]; ++c) {
+        const int g = pjs::RI[i][RI_KC_PTR] + c;
+        if (m.loc[g] < 0) { m.loc[g] = m.n; m.list[m.n++] = g; }
+    }
+}
+// NQ 16-byte pieces per thread: rows of the listed groups -> registers (issue), registers -> LDS (land)
+template <int NQ, class M, class D2>
+__device__ __forceinline__ void kc_issue(const M& list, int nrows, D2* lt)
+{
+    static_for<NQ>([&](auto qc) PJR_INL {
+        constexpr int q = decltype(qc)::value;
+        const int x = (int)threadIdx.x + q * PJQ_BLOCK;
+        const int row = x < nrows * 8 ? x >> 3 : 0;
+        lt[q] = ((const D2*)(pjs::LTAB + pjs::LT_KC + (long)list[row] * 16))[x & 7];
+    });
+}
+template <int NQ, class D2>
+__device__ __forceinline__ void kc_land(double* table, int nrows, const D2* lt)
+{
+    static_for<NQ>([&](auto qc) PJR_INL {
+        constexpr int q = decltype(qc)::value;
+        const int x = (int)threadIdx.x + q * PJQ_BLOCK;
+        if (x < nrows * 8) ((D2*)table)[x] = lt[q];
+    });
+}
+struct __attribute__((aligned(16))) d2 { double x, y; };
+
 #if PJQ_PART == 1
 // ------------------------------------------------------------------------------------------
 // k_pre: falloff / PLOG reactions once per state -> hand-over array
@@ -227,7 +282,18 @@ __device__ __forceinline__ void to_conc(State& L)
 #define PJR_SLOT(i_, c_) pjs::SCQ[i_][c_]
 constexpr bool kf_plain(int) { return false; }
 constexpr int NEFF = (int)(sizeof(pjs::EFF_AM1) / sizeof(pjs::EFF_AM1[0]));
-constexpr int NKC = pjs::LT_SP / 16;
+constexpr KcMap make_kcmap()
+{
+    KcMap m{};
+    for (int g = 0; g < NKC_ALL; ++g) m.loc[g] = -1;
+    for (int i = 0; i < NRXN; ++i) if (is_pre(i)) kcmap_add(m, i);
+    return m;
+}
+constexpr KcMap KCM = make_kcmap();
+constexpr int NKC = KCM.n;
+struct KcList { int v[NKC > 0 ? NKC : 1]; };
+constexpr KcList make_list() { KcList l{}; for (int q = 0; q < NKC; ++q) l.v[q] = KCM.list[q]; return l; }
+__device__ const KcList KCL = make_list();
 
 __global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
 {
@@ -236,7 +302,12 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
 #if PJQ_C_LDS
     __shared__ double CLr[NSP][PJQ_BLOCK];
 #endif
-    for (int x = threadIdx.x; x < NKC * 16; x += PJQ_BLOCK) LT[x] = pjs::LTAB[pjs::LT_KC + x];
+    {
+        constexpr int NQ = (NKC * 8 + PJQ_BLOCK - 1) / PJQ_BLOCK;
+        d2 lt[NQ > 0 ? NQ : 1];
+        kc_issue<NQ>(KCL.v, NKC, lt);
+        kc_land<NQ>(LT, NKC, lt);
+    }
     __syncthreads();
     const long s = (long)blockIdx.x * PJQ_BLOCK + threadIdx.x;
     if (s >= A.n) return;
@@ -273,7 +344,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
         constexpr int i = decltype(ic)::value;
         if constexpr (is_pre(i)) {
 #define PJR_RD(i_) pjs::RD[i_]
-#define PJR_KCROW(g_) (LT + (g_) * 16)
+#define PJR_KCROW(g_) (LT + KCM.loc[g_] * 16)
 #define PJR_EFL(e_) pjs::EFF_AM1[e_][0]
 #define PJR_KC_FIRST(i_) true
 #define PJR_SCHED_BARRIER() PJQ_SCHED_BARRIER()
@@ -304,7 +375,19 @@ struct Reg { Reg() { pjq_register(0, 1, launch_pre); } } reg_;
 // ------------------------------------------------------------------------------------------
 constexpr int B0_ = PJQ_B0, B1_ = PJQ_B1;
 constexpr bool FIRST_ = PJQ_FIRST != 0, LASTK_ = PJQ_LAST != 0;
-constexpr int NKC = pjs::LT_SP / 16;
+constexpr KcMap make_kcmap()
+{
+    KcMap m{};
+    for (int g = 0; g < NKC_ALL; ++g) m.loc[g] = -1;
+    for (int b = B0_; b < B1_; ++b)
+        for (int v = pjs::BLK_RX_PTR[b][0]; v < pjs::BLK_RX_PTR[b + 1][0]; ++v) kcmap_add(m, pjs::BLK_RX[v][0]);
+    return m;
+}
+constexpr KcMap KCM = make_kcmap();
+constexpr int NKC = KCM.n;
+struct KcList { int v[NKC > 0 ? NKC : 1]; };
+constexpr KcList make_list() { KcList l{}; for (int q = 0; q < NKC; ++q) l.v[q] = KCM.list[q]; return l; }
+__device__ const KcList KCL = make_list();
 
 template <int i>
 constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
@@ -332,8 +415,16 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
 #endif
     const int tid = threadIdx.x;
     // lanes past the end repeat the last state (same values to the same addresses): no divergence
+#if PJQ_PAIR
+    // pair stores need whole lane pairs: the last workgroup is shifted back over states its neighbour
+    // also evaluates (n >= PJQ_BLOCK, host-checked)
+    long s0_wg = (long)blockIdx.x * PJQ_BLOCK;
+    if (s0_wg + PJQ_BLOCK > A.n) s0_wg = A.n - PJQ_BLOCK;
+    const long s = s0_wg + tid;
+#else
     long s = (long)blockIdx.x * PJQ_BLOCK + tid;
     if (s >= A.n) s = A.n - 1;
+#endif
 #ifdef PJQ_NO_STORE
     double pjq_sink = 0.0;
 #endif
@@ -342,21 +433,12 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         // one round trip for everything the prologue reads: the state and this thread's share of the
         // K_c table are requested before anything waits (a load behind other workgroups' Jacobian
         // stores takes microseconds)
-        struct __attribute__((aligned(16))) d2 { double x, y; };
-        constexpr int NLT2 = NKC * 8, NQ = (NLT2 + PJQ_BLOCK - 1) / PJQ_BLOCK;     // 16-byte pieces
+        constexpr int NQ = (NKC * 8 + PJQ_BLOCK - 1) / PJQ_BLOCK;     // 16-byte pieces per thread
         d2 lt[NQ > 0 ? NQ : 1];
-        static_for<NQ>([&](auto qc) PJR_INL {
-            constexpr int q = decltype(qc)::value;
-            const int x = tid + q * PJQ_BLOCK;
-            lt[q] = ((const d2*)(pjs::LTAB + pjs::LT_KC))[x < NLT2 ? x : 0];
-        });
+        kc_issue<NQ>(KCL.v, NKC, lt);
         State L;
         load_state(A, s, L);        // all loads, scheduling barrier, sums
-        static_for<NQ>([&](auto qc) PJR_INL {
-            constexpr int q = decltype(qc)::value;
-            const int x = tid + q * PJQ_BLOCK;
-            if (x < NLT2) ((d2*)LTK)[x] = lt[q];
-        });
+        kc_land<NQ>(LTK, NKC, lt);
         to_conc(L);
         T = L.T; rho = L.rho; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
         static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
@@ -369,10 +451,11 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         for (int q = 0; q < ph; ++q) __builtin_amdgcn_s_sleep(PJQ_STAGGER);
     }
 #endif
-    const double logT = log(T), invT = 1.0 / T;
+    // (not const: see PJQ_LAUNDER_EVERY)
+    double logT = log(T), invT = 1.0 / T;
     // powers of T for the K_c polynomials (sum-of-products form: no dependent Horner chain)
-    const double T2 = T * T, T3 = T2 * T, T4 = T2 * T2;
-    const double T2d = 2.0 * T2, T3d = 3.0 * T3, T4d = 4.0 * T4;
+    double T2 = T * T, T3 = T2 * T, T4 = T2 * T2;
+    double T2d = 2.0 * T2, T3d = 3.0 * T3, T4d = 4.0 * T4;
     const double WR = Wbar * invrho;
     // A DS instruction reaches 64 KB from its address register; the columns of a 53-species mechanism
     // span 106 KB.  Left alone the compiler keeps one address VGPR per column beyond the first 64 KB;
@@ -423,6 +506,12 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
     double* const Jw = A.jac + s_wave * A.j_ss;
     const unsigned jvo = (unsigned)((s - s_wave) * A.j_ss) * 8u;
 #define J_(e) (*(double*)((char*)(Jw + (long)(e) * A.j_si) + jvo))
+#if PJQ_PAIR
+    // pair stores (SoA only, host-checked: j_ss == 1, 8 * NSP * j_si < 2^32): the even lane of a pair
+    // addresses its own state in column c, the odd lane the even lane's state in column c + 1
+    const bool odd = (tid & 1) != 0;
+    const unsigned jvo2 = odd ? jvo - 8u + (unsigned)(NSP * A.j_si) * 8u : jvo;
+#endif
 
     // hand-over values of the falloff / PLOG visits: those visits come last in a block
     // (pj::emit_rows_tables), their values are fetched PJQ_DEPTH visits ahead into a register ring.
@@ -446,6 +535,14 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         constexpr int b = decltype(bc)::value;
         constexpr int r0 = pjs::BLK_ROW_PTR[b][0], nrows = pjs::BLK_ROW_PTR[b + 1][0] - r0;
         constexpr int v0 = pjs::BLK_RX_PTR[b][0], nv = pjs::BLK_RX_PTR[b + 1][0] - v0;
+#if PJQ_LAUNDER_EVERY && !defined(PJR_HOST_EMU)
+        // k_f, K_c and T dlnK_c/dT of a reaction are functions of T alone, and the optimiser knows: it
+        // evaluates them at the first visit and keeps them for every later block of the kernel -- in
+        // AGPRs while they last, then in scratch memory, whose loads queue behind the Jacobian
+        // stores.  Opaque copies of T's functions every few blocks bound that cache.
+        if constexpr ((b - B0_) % PJQ_LAUNDER_EVERY == 0 && b != B0_)
+            asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT), "+v"(T2), "+v"(T3), "+v"(T4), "+v"(T2d), "+v"(T3d), "+v"(T4d));
+#endif
         double om[nrows], P[nrows], Q[nrows], JT[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
         double JTQ = 0.0;
         static_for<nrows>([&](auto rc) PJR_INL {
@@ -480,7 +577,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             double ka[KCNT > 0 ? KCNT : 1][7];
             static_for<KCNT>([&](auto cc) PJR_INL {
                 constexpr int c = decltype(cc)::value, g = pjs::RI[i][RI_KC_PTR] + c;
-                const double* a = LTK + g * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
                 static_for<7>([&](auto ec) PJR_INL { ka[c][decltype(ec)::value] = a[decltype(ec)::value]; });
             });
 #if PJQ_SPLIT
@@ -635,25 +732,53 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             const double cpk = (RU_ * pjs::SP[k][0]) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
             H += hW[r] * om[r];
             SCP += om[r] * pjs::SP[k][1] * cpk;
-            // d/dT column (create_jacobian.py:2786-2818)
-            if constexpr (k < LAST) PJQ_STORE(&J_(k + 1), pjs::SP[k][1] * JT[r]);
             if constexpr (k == LAST) SJT += hW[r] * (A.sum_last ? JT[r] : JTQ);
             else SJT += hW[r] * JT[r];
         });
-        static_for<LAST>([&](auto jc) PJR_INL {
-            constexpr int j = decltype(jc)::value;
-            constexpr double wj = pjs::SP[j][3], iWj = pjs::SP[j][0];
-            double tot = 0.0;
-            static_for<nrows>([&](auto rc) PJR_INL {
-                constexpr int r = decltype(rc)::value;
-                constexpr int k = pjs::BLK_ROWS[r0 + r][0];
+        // Jacobian column c of a row: c = 0 is the d/dT column, c = j + 1 belongs to species j
+        auto col_val = [&](auto rc, auto cc) PJR_INL {
+            constexpr int r = decltype(rc)::value, c = decltype(cc)::value;
+            constexpr int k = pjs::BLK_ROWS[r0 + r][0];
+            if constexpr (c == 0) {
+                return pjs::SP[k][1] * JT[r];                  // create_jacobian.py:2786-2818
+            } else {
+                constexpr int j = c - 1;
                 constexpr int si = pjs::SLOC[k][j];
-                double m = P[r] - wj * Q[r];
+                double m = P[r] - pjs::SP[j][3] * Q[r];
                 if constexpr (si >= 0) m += S[si];
-                tot += hW[r] * m;
-                if constexpr (k < LAST) PJQ_STORE(&J_(k + 1 + NSP * (j + 1)), (pjs::SP[k][1] * iWj) * m);
-            });
-            E[j] += tot;
+                E[j] += hW[r] * m;
+                return (pjs::SP[k][1] * pjs::SP[j][0]) * m;
+            }
+        };
+        static_for<nrows>([&](auto rc) PJR_INL {
+            constexpr int r = decltype(rc)::value;
+            constexpr int k = pjs::BLK_ROWS[r0 + r][0];
+            if constexpr (k < LAST) {
+#if PJQ_PAIR
+                // two columns per store instruction: the lanes of a pair exchange one value each, the even
+                // lane then writes both states of column c, the odd lane both states of column c + 1
+                // (16 bytes per lane: half the store instructions in flight for the same bytes)
+                static_for<NSP / 2>([&](auto hc) PJR_INL {
+                    constexpr int c = 2 * decltype(hc)::value;
+                    const double v0 = col_val(rc, std::integral_constant<int, c>{});
+                    const double v1 = col_val(rc, std::integral_constant<int, c + 1>{});
+                    const double recv = swap_pair(odd ? v0 : v1);
+                    d2s out;
+                    out.x = odd ? recv : v0;
+                    out.y = odd ? v1 : recv;
+                    PJQ_STORE2((d2s*)((char*)(Jw + (long)(k + 1 + NSP * c) * A.j_si) + jvo2), out);
+                });
+                if constexpr (NSP % 2 != 0)
+                    PJQ_STORE(&J_(k + 1 + NSP * (NSP - 1)), col_val(rc, std::integral_constant<int, NSP - 1>{}));
+#else
+                static_for<NSP>([&](auto cc) PJR_INL {
+                    PJQ_STORE(&J_(k + 1 + NSP * decltype(cc)::value), col_val(rc, cc));
+                });
+#endif
+            } else {
+                // the last species has no row of its own; its terms still enter the energy row
+                static_for<LAST>([&](auto jc) PJR_INL { (void)col_val(rc, std::integral_constant<int, decltype(jc)::value + 1>{}); });
+            }
         });
         PJQ_SCHED_BARRIER();
         PJQ_TICK(3)
@@ -727,15 +852,15 @@ void read_timing(const PjqArgs& A, void*)   // A.scr: host buffer of 5 * 1024 * 
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol((void*)A.scr, HIP_SYMBOL(g_tim), sizeof(g_tim));
 }
-struct Reg { Reg() { pjq_register(PJQ_ID, 2, launch_part); pjq_register(PJQ_ID, 5, read_timing); } } reg_;
+struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_PAIR ? 2 : 4, launch_part); pjq_register(PJQ_ID, 5, read_timing); } } reg_;
 #else
-struct Reg { Reg() { pjq_register(PJQ_ID, 2, launch_part); } } reg_;
+struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_PAIR ? 2 : 4, launch_part); } } reg_;   // 2: pair stores, 4: general
 #endif
 #endif  // PJQ_PART == 2
 
 #if PJQ_PART == 0
 constexpr int MAXPARTS = 256;
-pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_timing[MAXPARTS];
+pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_rows_gen[MAXPARTS], g_timing[MAXPARTS];
 constexpr int MAXSTREAMS = 8;
 double* g_scr[MAXSTREAMS] = {};
 long g_scr_ld[MAXSTREAMS] = {};
@@ -751,7 +876,7 @@ extern "C" {
 void pjq_register(int id, int kind, pjq_launch_fn fn)
 {
     if (kind == 1) g_pre = fn;
-    else if (id >= 0 && id < MAXPARTS) (kind == 5 ? g_timing : g_rows)[id] = fn;
+    else if (id >= 0 && id < MAXPARTS) (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : g_rows)[id] = fn;
 }
 
 // debug builds (-DPJQ_TIMING): cycles per phase of row kernel `part`, [5][1024 workgroups][4 wavefronts]
@@ -782,15 +907,12 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
                      long j_si, long j_ss, int sum_last, void* stream)
 {
     if (n <= 0) return 0;
-    static int nstreams = 0;
-    static long chunk_env = 0;
-    if (!nstreams) {
-        const char* e = getenv("PJ_RBLK_STREAMS");
-        nstreams = e ? atoi(e) : PJQ_STREAMS;
-        if (nstreams < 1) nstreams = 1;
-        if (nstreams > MAXSTREAMS) nstreams = MAXSTREAMS;
-        if (const char* c = getenv("PJ_RBLK_CHUNK")) chunk_env = atol(c);
-    }
+    int nstreams = PJQ_STREAMS;
+    long chunk_env = 0;
+    if (const char* e = getenv("PJ_RBLK_STREAMS")) nstreams = atoi(e);
+    if (nstreams < 1) nstreams = 1;
+    if (nstreams > MAXSTREAMS) nstreams = MAXSTREAMS;
+    if (const char* c = getenv("PJ_RBLK_CHUNK")) chunk_env = atol(c);
     // chunks: a multiple of the tile, at least 2 per stream when the batch fills the device several times
     long chunk = chunk_env >= 256 ? chunk_env : PJQ_CHUNK;
     chunk = (chunk + PJQ_TILE - 1) / PJQ_TILE * PJQ_TILE;
@@ -814,14 +936,21 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
         (void)hipEventRecord(g_events[MAXSTREAMS], user);
         for (int b = 0; b < S; ++b) (void)hipStreamWaitEvent(g_streams[b], g_events[MAXSTREAMS], 0);
     }
+    // the pair-store kernels need lane-contiguous (SoA) output, whole workgroups and column offsets
+    // that fit 32 bits; everything else goes to the general kernels of the library
+    const bool have_fast = g_rows[0] != nullptr, have_gen = g_rows_gen[0] != nullptr;
+    const bool fast_ok = have_fast && j_ss == 1 && (unsigned long)NSP * 8ul * (unsigned long)j_si < (1ul << 32);
     long c = 0;
     for (long s0 = 0; s0 < n; s0 += chunk, ++c) {
         const long m = s0 + chunk < n ? chunk : n - s0;
         const int b = (int)(c % S);
         void* st = S > 1 ? (void*)g_streams[b] : stream;
         PjqArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, g_scr[b], sum_last};
+        const bool fast = fast_ok && m >= PJQ_BLOCK;
+        if (!fast && !have_gen) return -5;
         if (g_pre) g_pre(A, st);
-        for (int i = 0; i < MAXPARTS; ++i) if (g_rows[i]) g_rows[i](A, st);
+        pjq_launch_fn* rows = fast ? g_rows : g_rows_gen;
+        for (int i = 0; i < MAXPARTS; ++i) if (rows[i]) rows[i](A, st);
     }
     if (S > 1)
         for (int b = 0; b < S; ++b) {

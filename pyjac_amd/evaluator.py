@@ -50,7 +50,9 @@ class Evaluator:
 
     # ---- mechanism-specific state-per-lane kernels ----
     # csrc/pj_lane.hip: the whole Jacobian in one lane's registers (small mechanisms);
-    # csrc/pj_rows.hip: rate kernel + row-block kernels through an HBM scratch array (the rest)
+    # csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (the rest);
+    # csrc/pj_rows.hip: its predecessor (rate kernel + row-block kernels through an HBM scratch array),
+    # still the source of the rate-output kernels (pj_spec_rates) of the pj_rblk libraries
     SPEC_MAX_NSP, SPEC_MAX_RXN = 16, 64
     ROWS_BUDGET = 64          # accumulator doubles per row block (stays inside 256 VGPRs)
     ROWS_FUSE = 16            # row blocks per kernel
@@ -58,7 +60,7 @@ class Evaluator:
 
     def spec_kind(self) -> str:
         """Which specialised kernel family specialize(build=True) compiles for this mechanism."""
-        return 'lane' if self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN else 'rows'
+        return 'lane' if self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN else 'rblk'
 
     _SPEC_STEM = {'lane': 'libpj_spec_%016x.so', 'rows': 'libpj_rows_%016x.so', 'fused': 'libpj_fused_%016x.so',
                   'rblk': 'libpj_rblk_%016x.so'}
@@ -182,7 +184,8 @@ class Evaluator:
         shutil.rmtree(work, ignore_errors=True)
 
     RBLK_BUDGET = 56          # accumulator doubles per row block of pj_rblk.hip (4 dense + non-zero S per row)
-    RBLK_FUSE = 8             # row blocks per kernel
+    RBLK_FUSE = 13            # row blocks per kernel (at most)
+    RBLK_FUSE_LARGE = 8       # ... for mechanisms whose concentration columns leave little LDS for the K_c rows
 
     def _build_rblk(self, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=()):
         """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the
@@ -197,7 +200,7 @@ class Evaluator:
         os.makedirs(os.path.dirname(so), exist_ok=True)
         hdr = so[:-3] + '.h'
         budget = int(budget or os.environ.get('PJ_RBLK_BUDGET', self.RBLK_BUDGET))
-        fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', self.RBLK_FUSE))
+        fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', self.RBLK_FUSE if self.nsp <= 64 else self.RBLK_FUSE_LARGE))
         rpp = int(rates_per_part or os.environ.get('PJ_ROWS_RATES_PER_PART', self.ROWS_RATES_PER_PART))
         check(L.pj_mech_emit_rows_spec(self._h, hdr.encode(), budget))
         t = open(hdr).read()
@@ -207,9 +210,8 @@ class Evaluator:
         work = so[:-3] + '.obj'
         os.makedirs(work, exist_ok=True)
         # lanes per workgroup: the concentration columns (8 NSP bytes per lane) + the K_c table must fit the LDS
-        lt_sp = int(re.search(r'LT_SP = (\d+)', t).group(1))
-        fits = lambda b: self.nsp * b * 8 + lt_sp * 8 <= 158 * 1024
-        block = 256 if fits(256) else 128 if fits(128) else 64
+        # (a kernel stages only the K_c rows of its own reactions: at most 16 doubles per visit)
+        block = 256 if self.nsp * 256 * 8 <= 112 * 1024 else 128 if self.nsp * 128 * 8 <= 120 * 1024 else 64
         block = int(os.environ.get('PJ_RBLK_BLOCK', block))
         c_lds = int(self.nsp > 64)
         common = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr,
@@ -229,9 +231,13 @@ class Evaluator:
         # row kernels of (nearly) equal block counts, at most `fuse` blocks each
         nker = (nblk + fuse - 1) // fuse
         bounds = [nblk * i // nker for i in range(nker + 1)]
+        # each row kernel twice: with pair stores (SoA output, whole workgroups: the fast path) and general
+        pair_modes = [int(x) for x in os.environ.get('PJ_RBLK_PAIR_MODES', '1,0').split(',')]
         for i in range(nker):
-            jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i], '-DPJQ_B1=%d' % bounds[i + 1],
-                                 '-DPJQ_FIRST=%d' % (i == 0), '-DPJQ_LAST=%d' % (i == nker - 1)], 'rblk%d.o' % i))
+            for pair in pair_modes:
+                jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
+                                     '-DPJQ_B1=%d' % bounds[i + 1], '-DPJQ_FIRST=%d' % (i == 0),
+                                     '-DPJQ_LAST=%d' % (i == nker - 1), '-DPJQ_PAIR=%d' % pair], 'rblk%d_%d.o' % (i, pair)))
         for i, r0 in enumerate(range(0, self.n_fwd, rpp)):
             jobs.append((rows + f_rates + ['-DPJR_PART=1', '-DPJR_ID=%d' % i, '-DPJR_R0=%d' % r0,
                                            '-DPJR_R1=%d' % min(self.n_fwd, r0 + rpp)], 'rates%d.o' % i))

@@ -42,7 +42,7 @@ def states_for(name, nsp):
         P, T = P[sel], T[sel]
         Y = Y[sel, :9] / Y[sel, :9].sum(axis=1, keepdims=True)
     elif name in ('gri30_shaped', 'usc2_shaped', 'synth_mid24'):
-        n = {'gri30_shaped': 12, 'usc2_shaped': 4, 'synth_mid24': 40}[name]
+        n = {'gri30_shaped': 64, 'usc2_shaped': 16, 'synth_mid24': 40}[name]
         P, ysoa = synth.dist_b(n, nsp, seed=77, Tlo=600, Thi=2500)
         return P, np.ascontiguousarray(ysoa.T)
     else:

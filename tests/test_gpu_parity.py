@@ -10,6 +10,14 @@ from conftest import MECHS, jac_scaled_err, mixed_err, rate_scales, thresholded_
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-6
+# Bound on the reference tester's thresholded relative error (its mask |J| > ||J||_2 / 1e20 keeps entries
+# that are 1e-13 of their row scale, i.e. differences of terms 1e13 larger) for the 53- / 111-species
+# mechanisms; the entry-wise tolerance proper is jac_scaled_err (rtol 1e-6 + 1e-12 of the row / column
+# scale).  Measured values are printed and recorded in DESIGN.md section 2.
+MX_BIG = {'gri30_shaped': 1e-4, 'usc2_shaped': 5e-2}
+# kernel families for mechanisms beyond the register-resident kernel: pj_rblk.hip (default) and its
+# predecessor pj_rows.hip
+BIG = ('pj_rblk', 'pj_rows')
 KEYS = ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')
 
 
@@ -176,21 +184,22 @@ def test_empty_and_single_state(torch_cuda):
     assert torch.isfinite(j).all()
 
 
-@pytest.mark.parametrize('name,n', [('gri30_shaped', 300), ('usc2_shaped', 60)])
+@pytest.mark.parametrize('name,n', [('gri30_shaped', 300), ('usc2_shaped', 160), ('usc2_shaped', 60)])
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
-@pytest.mark.parametrize('kernel', ['pj_rows', 'k_eval'])
+@pytest.mark.parametrize('kernel', ['row_blocks', 'k_eval'])
 def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda):
     """Configs 3-5 (GRI-3.0-shaped 53 sp / 325 rxn; USC-II-shaped 111 sp / 784 rxn
     with PLOG; the species order is permuted so N2 ends up last), through the state-per-lane
-    row-block kernels (csrc/pj_rows.hip, prebuilt by __graft_entry__.build()) and through the
-    table-driven kernel."""
+    row-block kernels (csrc/pj_rblk.hip, prebuilt by __graft_entry__.build(); n = 300 runs the
+    pair-store kernels for SoA output, n = 60 and AoS the general ones) and through the table-driven
+    kernel.  The reference tester's thresholded relative error (test.py:1446-1463) is bounded too."""
     import pyjac_amd
     from oracle.oracle import Oracle
     from pyjac_amd import synth
     torch = torch_cuda
     ev = _ev(name)
-    if kernel == 'pj_rows':
-        assert ev.has_spec and ev.spec_kernel == 'pj_rows', 'row-block library missing: run __graft_entry__.build()'
+    if kernel == 'row_blocks':
+        assert ev.has_spec and ev.spec_kernel == 'pj_rblk', 'row-block library missing: run __graft_entry__.build()'
         ev.use_spec(2)
     else:
         ev.use_spec(False)
@@ -208,7 +217,8 @@ def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda)
     mx, fro = thresholded_rel_err(jac, ref)
     # large mechanisms have entries 1e-13 of their row scale: judge those by the scaled metric
     sc = jac_scaled_err(jac, ref, ev.nsp)
-    assert sc <= 1.0 and fro < 1e-9, (name, layout, sc, mx, fro)
+    print('%s %s %s: scaled %.3g, thresholded max rel %.3g, fro %.3g' % (name, layout, kernel, sc, mx, fro))
+    assert sc <= 1.0 and fro < 1e-9 and mx < MX_BIG[name], (name, layout, sc, mx, fro)
 
 
 @pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])
@@ -326,7 +336,7 @@ def test_row_block_rate_outputs(name, n, layout, tables, torch_cuda):
     from pyjac_amd import _lib, synth
     torch = torch_cuda
     ev = _ev(name)
-    assert ev.spec_kernel == 'pj_rows'
+    assert ev.spec_kernel in BIG
     pres, y = synth.dist_b(n, ev.nsp, seed=4, Tlo=600, Thi=2600)
     d_p = torch.from_numpy(pres).cuda()
     if layout == 'soa':
@@ -400,7 +410,7 @@ def test_row_block_kernels_mid_size(golden, torch_cuda):
     torch = torch_cuda
     g = golden('synth_mid24')
     ev = _ev('synth_mid24')
-    assert ev.spec_kernel == 'pj_rows'
+    assert ev.spec_kernel in BIG
     ev.use_spec(2)
     d_p = torch.from_numpy(g['pres'].copy()).cuda()
     soa = ev.jacobian(d_p, torch.from_numpy(np.ascontiguousarray(g['y'].T)).cuda()).cpu().numpy().T
@@ -418,7 +428,7 @@ def test_row_block_kernels_small_batches(n, torch_cuda):
     from pyjac_amd import synth
     torch = torch_cuda
     ev = _ev('synth_mid24')
-    assert ev.spec_kernel == 'pj_rows'
+    assert ev.spec_kernel in BIG
     pres, y = synth.dist_b(n, ev.nsp, seed=n)
     d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
     a = ev.jacobian(d_p, d_y).cpu().numpy().T
@@ -438,14 +448,21 @@ def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
     from pyjac_amd import synth
     torch = torch_cuda
     ev = _ev('gri30_shaped')
-    assert ev.spec_kernel == 'pj_rows'
+    assert ev.spec_kernel in BIG
     n = 3000
     pres, y = synth.dist_b(n, ev.nsp, seed=77)
     d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
     whole = ev.jacobian(d_p, d_y).clone()
     monkeypatch.setenv('PJ_ROWS_CHUNK', '1024')
-    parts = ev.jacobian(d_p, d_y)
+    monkeypatch.setenv('PJ_RBLK_CHUNK', '1024')
+    parts = ev.jacobian(d_p, d_y).clone()
     assert torch.equal(whole, parts)
+    # chunks dealt to three internal streams, last chunk smaller than a workgroup (general kernels)
+    monkeypatch.setenv('PJ_RBLK_STREAMS', '3')
+    monkeypatch.setenv('PJ_RBLK_CHUNK', '512')
+    n2 = 512 * 5 + 100
+    parts = ev.jacobian(d_p[:n2].contiguous(), d_y[:, :n2].contiguous())
+    assert torch.equal(whole[:, :n2], parts)
 
 
 @pytest.mark.parametrize('name,fused', [('h2o2_n2', True), ('synth_alltypes', True), ('h2o2_n2', False),
@@ -507,7 +524,7 @@ def test_finite_difference_arm(tables, torch_cuda):
 
 
 @pytest.mark.parametrize('name', ['gri30_shaped', 'usc2_shaped'])
-def test_large_mechanisms_vs_reference_golden(name, golden, torch_cuda):
+def test_large_mechanisms_vs_reference_golden(name, golden, tables, torch_cuda):
     """GPU Jacobians of the 53- and 111-species synthetic mechanisms against vectors
     produced by pyJac's own generated C (tests/golden/make_golden.py)."""
     import pyjac_amd
@@ -523,7 +540,171 @@ def test_large_mechanisms_vs_reference_golden(name, golden, torch_cuda):
         jac = ev.jacobian(d_p, d_y, y_layout=pyjac_amd.LAYOUT_AOS, jac_layout=pyjac_amd.LAYOUT_AOS).cpu().numpy()
         mx, fro = thresholded_rel_err(jac, g['jac'])
         assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0 and fro < 1e-9, (name, use, mx, fro)
-    r = ev.rates(d_p, d_y, y_layout=pyjac_amd.LAYOUT_AOS)
-    for k, rows in (('conc', ev.nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
-        mx, fro = thresholded_rel_err(r[k].cpu().numpy().T[:, :rows], g[k][:, :rows])
-        assert mx < RTOL, (name, k, mx)
+        print('%s use_spec=%d: thresholded max rel %.3g, fro %.3g' % (name, use, mx, fro))
+        assert mx < MX_BIG[name]
+    # every rate output of both paths (state-per-lane rate kernels, table-driven kernel) against the
+    # reference's vectors: net rates are judged against the gross rate they are the difference of
+    gross, sdy = rate_scales(tables(name), g['pres'], g['y'], g['conc'], g['fwd'], g['rev'], g['pres_mod'])
+    for use in (1, 0):
+        ev.use_spec(use)
+        if not use and ev.get_launch()['lds_bytes'] > 160 * 1024:
+            continue
+        r = {k: v.cpu().numpy().T for k, v in ev.rates(d_p, d_y, y_layout=pyjac_amd.LAYOUT_AOS).items()}
+        for k, rows in (('conc', ev.nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
+            mx, fro = thresholded_rel_err(r[k][:, :rows], g[k][:, :rows])
+            assert mx < RTOL, (name, use, k, mx)
+        assert mixed_err(r['spec_rates'], g['spec_rates'], gross[:, None]) <= 1.0, (name, use)
+        assert mixed_err(r['dydt'], g['dydt'], sdy) <= 1.0, (name, use)
+
+
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+@pytest.mark.parametrize('n', [4099, 256, 100])
+def test_rblk_kernels_all_reaction_types(layout, n, tables, torch_cuda):
+    """csrc/pj_rblk.hip (row blocks that rebuild their rates, falloff / PLOG pre-pass, energy-row
+    partials handed from kernel to kernel) on the mechanism that holds every supported reaction type,
+    built with a deliberately fine partition (several row kernels, multi-row blocks): against the
+    oracle and the table-driven kernel, with and without the J_nplusone quirk.  n = 4099 ends
+    mid-workgroup (the pair-store kernels shift their last workgroup back), n = 256 is exactly one
+    workgroup, n = 100 and AoS output run the general kernels."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    name = 'synth_alltypes'
+    ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
+    assert ev.specialize(build=True, kind='rblk', budget=16, fuse=3, rates_per_part=7)
+    assert ev.spec_kernel == 'pj_rblk'
+    pres, y = synth.dist_b(n, ev.nsp, seed=31, Tlo=400, Thi=2800)
+    pres = 101325 * 10 ** np.random.default_rng(8).uniform(-1.5, 1.5, n)
+    d_p = torch.from_numpy(pres).cuda()
+    if layout == 'soa':
+        d_y, L = torch.from_numpy(y).cuda(), pyjac_amd.LAYOUT_SOA
+    else:
+        d_y, L = torch.from_numpy(np.ascontiguousarray(y.T)).cuda(), pyjac_amd.LAYOUT_AOS
+    o = Oracle(tables(name))
+    for sum_last in (0, 1):
+        ev.set_sum_last_species(bool(sum_last))
+        ev.use_spec(2)
+        out = torch.full((ev.nsp ** 2, n) if layout == 'soa' else (n, ev.nsp ** 2), float('nan'),
+                         dtype=torch.float64, device='cuda')
+        spec = ev.jacobian(d_p, d_y, y_layout=L, out=out, jac_layout=L).cpu().numpy()
+        ev.use_spec(False)
+        gen = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+        if layout == 'soa':
+            spec, gen = spec.T, gen.T
+        o.lib.pjo_set_sum_last_species(sum_last)
+        try:
+            ref = o.batch_jacob(pres, np.ascontiguousarray(y.T))
+        finally:
+            o.lib.pjo_set_sum_last_species(0)
+        assert np.isfinite(spec).all()          # every entry written
+        mx, fro = thresholded_rel_err(spec, ref)
+        assert mx < RTOL and fro < 1e-9, (layout, n, sum_last, mx, fro)
+        mx, fro = thresholded_rel_err(spec, gen)
+        assert mx < RTOL and fro < 1e-9, ('rblk vs table-driven', sum_last, mx, fro)
+
+
+@pytest.mark.parametrize('name,n', [('gri30_shaped', 700), ('usc2_shaped', 200)])
+def test_large_mechanism_rate_outputs_vs_oracle(name, n, tables, torch_cuda):
+    """a4 / a6 on configs 3 and 5: spec_rates and dydt (and conc, fwd, rev, pres_mod) of the
+    state-per-lane rate kernels AND of the table-driven kernel against the CPU oracle."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev(name)
+    assert ev.spec_kernel in BIG
+    pres, y = synth.dist_b(n, ev.nsp, seed=14, Tlo=600, Thi=2600)
+    y_aos = np.ascontiguousarray(y.T)
+    orc = Oracle(tables(name))
+    o = [orc.eval_all(float(pres[s]), y_aos[s]) for s in range(n)]
+    g = {k: np.array([x[k] for x in o]) for k in ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt')}
+    gross, sdy = rate_scales(tables(name), pres, y_aos, g['conc'], g['fwd'], g['rev'], g['pres_mod'])
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    for use in (1, 0):
+        ev.use_spec(use)
+        if not use and ev.get_launch()['lds_bytes'] > 160 * 1024:
+            continue
+        r = {k: v.cpu().numpy().T for k, v in ev.rates(d_p, d_y).items()}
+        for k, rows in (('conc', ev.nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
+            mx, _ = thresholded_rel_err(r[k][:, :rows], g[k][:, :rows])
+            assert mx < 1e-9, (name, use, k, mx)
+        assert mixed_err(r['spec_rates'], g['spec_rates'], gross[:, None]) <= 1.0, (name, use)
+        assert mixed_err(r['dydt'], g['dydt'], sdy) <= 1.0, (name, use)
+
+
+@pytest.mark.parametrize('name,n', [('gri30_shaped', 1_000_000), ('usc2_shaped', 200_000)])
+def test_full_size_large_mechanism_properties(name, n, tables, torch_cuda, monkeypatch):
+    """BASELINE.json configs 3 and 5 at full size (22.5 GB / 19.7 GB of Jacobian): everything finite, a
+    strided sample equal to the same states evaluated as a small batch and within tolerance of the
+    oracle, and the whole batch bit-identical when it runs in chunks over several internal streams."""
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev(name)
+    assert ev.spec_kernel == 'pj_rblk'
+    pres, y = synth.dist_b(n, ev.nsp, seed=20240901)
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    jac = ev.jacobian(d_p, d_y)
+    step = 8191
+    assert all(bool(torch.isfinite(jac[:, i::64]).all()) for i in range(0, 64, 7))
+    idx = torch.arange(3, n, step, device='cuda')
+    sample = jac[:, idx].clone()
+    small = ev.jacobian(d_p[idx].contiguous(), d_y[:, idx].contiguous())      # general kernels (n < workgroup) or pair
+    ii = idx.cpu().numpy()
+    ref = Oracle(tables(name)).batch_jacob(pres[ii], np.ascontiguousarray(y[:, ii].T))
+    got = sample.cpu().numpy().T
+    mx, fro = thresholded_rel_err(got, ref)
+    sc = jac_scaled_err(got, ref, ev.nsp)
+    print('%s full size: scaled %.3g, thresholded max rel %.3g, fro %.3g' % (name, sc, mx, fro))
+    assert sc <= 1.0 and fro < 1e-9 and mx < MX_BIG[name]
+    assert jac_scaled_err(small.cpu().numpy().T, got, ev.nsp) <= 1e-3       # same arithmetic, other kernel variant
+    # checksum of the batch, then the same batch in 3 x 131072-state chunks on three streams
+    cs = jac.sum(dim=1).clone()
+    del jac, small, sample
+    torch.cuda.empty_cache()
+    monkeypatch.setenv('PJ_RBLK_STREAMS', '3')
+    monkeypatch.setenv('PJ_RBLK_CHUNK', '131072')
+    jac2 = ev.jacobian(d_p, d_y)
+    assert torch.equal(cs, jac2.sum(dim=1))
+
+
+def test_table_file_through_c_abi_only(tmp_path, tables, torch_cuda):
+    """N1: a mechanism written as a .pjtab table file is loaded by pj_mech_load and evaluated
+    through the C ABI alone (no Python parser, no Evaluator): Jacobian and dydt against the oracle."""
+    import ctypes
+    from oracle.oracle import Oracle
+    from pyjac_amd import _lib, synth
+    torch = torch_cuda
+    name = 'synth_alltypes'
+    tab = tables(name)
+    path = str(tmp_path / 'mech.pjtab')
+    tab.save(path)
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.pj_mech_load(path.encode(), ctypes.byref(h)) == 0
+    nsp = L.pj_mech_nsp(h)
+    assert (nsp, L.pj_mech_fwd_rates(h), L.pj_mech_rev_rates(h), L.pj_mech_pres_mod_rates(h)) == \
+        (tab.nsp, tab.nrxn, tab.nrev, tab.npres)
+    n = 500
+    pres, y = synth.dist_b(n, nsp, seed=3)
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    jac = torch.empty((nsp * nsp, n), dtype=torch.float64, device='cuda')
+    dy = torch.empty((nsp, n), dtype=torch.float64, device='cuda')
+    assert L.pj_eval_jacobian_dev(h, n, d_p.data_ptr(), d_y.data_ptr(), 0, jac.data_ptr(), 0, None) == 0
+    assert L.pj_eval_rates_dev(h, n, d_p.data_ptr(), d_y.data_ptr(), 0, None, None, None, None, None,
+                               dy.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    o = Oracle(tab)
+    y_aos = np.ascontiguousarray(y.T)
+    mx, fro = thresholded_rel_err(jac.cpu().numpy().T, o.batch_jacob(pres, y_aos))
+    assert mx < RTOL and fro < 1e-9
+    ref = o.batch_dydt(pres, y_aos)
+    sc = np.abs(ref).max(axis=0, keepdims=True) + 1e-300
+    assert (np.abs(dy.cpu().numpy().T - ref) / (1e-6 * np.abs(ref) + 1e-9 * sc)).max() <= 1.0
+    # a truncated file must be refused, not crash
+    bad = str(tmp_path / 'bad.pjtab')
+    open(bad, 'wb').write(open(path, 'rb').read()[:200])
+    h2 = ctypes.c_void_p()
+    assert L.pj_mech_load(bad.encode(), ctypes.byref(h2)) != 0
+    L.pj_mech_destroy(h)

@@ -136,3 +136,35 @@ def test_kernel_phases_match_oracle(name, TS, NT, aos, tables):
     ref_d = o.batch_dydt(pres, np.ascontiguousarray(y.T))
     mx, _ = thresholded_rel_err(out['dydt'].reshape(-1, n).T, ref_d)
     assert mx < 1e-10
+
+
+def test_generated_build_dir_matches_reference_callers(tmp_path):
+    """pyjac_amd.pywrap.generate_wrapper: the build directory the reference's functional tester works from --
+    mechanism.h / mechanism.cuh carrying what check_numbers / check_optimized parse
+    (functional_tester/test.py:289-332, 352-364) and modules importable by bare name
+    (test.py:432-437, 739-741)."""
+    import re
+    import subprocess
+    import sys
+    from pyjac_amd.pywrap import generate_wrapper
+    from pyjac_amd.mechanism import read_mech
+    mech_file = os.path.join(ROOT, 'tests', 'golden', 'synth_alltypes.inp')
+    d = generate_wrapper(mech_file, str(tmp_path / 'out'))
+    m = read_mech(mech_file)
+    for fn in ('mechanism.h', 'mechanism.cuh'):
+        n_spec = n_reac = last_spec = None
+        for line in open(os.path.join(d, fn)).read().split('\n'):
+            a = re.search(r'^#define NSP (\d+)$', line)
+            b = re.search(r'^#define FWD_RATES (\d+)$', line)
+            c = re.search(r'^//last_spec (\d+)$', line)
+            n_spec = int(a.group(1)) if a else n_spec
+            n_reac = int(b.group(1)) if b else n_reac
+            last_spec = int(c.group(1)) if c else last_spec
+        assert n_spec == len(m.specs) and n_reac == len(m.reacs) and last_spec == m.fwd_spec_map[-1]
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); "
+            "p = __import__('pyjacob'); c = __import__('cu_pyjacob'); "
+            "assert all(hasattr(p, f) for f in ('py_dydt', 'py_eval_jacobian', 'py_eval_rxn_rates', "
+            "'py_eval_spec_rates', 'py_get_rxn_pres_mod', 'py_eval_conc')); "
+            "assert all(hasattr(c, f) for f in ('py_cuinit', 'py_cujac', 'py_cuclean')); print('ok')" % (d, ROOT))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == 'ok', out.stderr[-1500:]

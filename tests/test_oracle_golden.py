@@ -78,3 +78,21 @@ def test_jacobian_consistent_with_finite_differences(tables):
         fd = (o.eval_all(P, yp)['dydt'] - o.eval_all(P, ym)['dydt']) / (2 * h)
         scale = np.abs(jac[1:, j]).max()
         assert np.abs(fd[1:] - jac[1:, j]).max() < 1e-5 * scale
+
+
+@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes'])
+def test_fd_arm_oracle_pinned_to_reference(name, tables):
+    """N3 pin: the restated finite-difference Jacobian (pyjac/performance_tester/fd_jacob.c:10-113)
+    is bit-identical to the reference's own fd_jacob.c compiled into oracle/_ref."""
+    if not Reference.available(name):
+        pytest.skip('oracle/_ref not built (no /root/reference here)')
+    tab = tables(name)
+    o, r = Oracle(tab), Reference(name)
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        T = rng.uniform(500, 2800)
+        P = 101325 * 10 ** rng.uniform(-1.5, 1.5)
+        Y = rng.uniform(0, 1, tab.nsp) ** 2 + 1e-7
+        Y /= Y.sum()
+        y = np.concatenate([[T], Y[:-1]])
+        assert np.array_equal(o.fd_jacob(P, y.copy()), r.fd_jacob(P, y.copy()), equal_nan=True)
