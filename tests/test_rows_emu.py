@@ -176,3 +176,83 @@ def test_fused_kernel_vs_oracle(name, budget, tmp_path, tables):
             jac = _run(L, ev.nsp, pres, y, sum_last=sum_last, aos=aos)
             assert not np.isnan(jac).any()
             assert jac_scaled_err(jac, ref, ev.nsp) <= 1.0
+
+
+def _rblk_emu_lib(name, budget, tmp, **kw):
+    """csrc/pj_rblk.hip (+ the rate-output kernels of pj_rows.hip) compiled for the host."""
+    ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
+    hdr = os.path.join(tmp, '%s_q%d.h' % (name, budget))
+    _lib.check(_lib.lib().pj_mech_emit_rows_spec(ev._h, hdr.encode(), budget))
+    so = build_rows_emu.build_rblk(hdr, os.path.join(tmp, 'lib%s_q%d.so' % (name, budget)), **kw)
+    L = ctypes.CDLL(so)
+    L.pj_spec_jacobian.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp,
+                                   ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    L.pj_spec_hash.restype = ctypes.c_ulonglong
+    assert L.pj_spec_hash() == _lib.lib().pj_mech_spec_hash(ev._h)
+    return ev, L
+
+
+@pytest.mark.parametrize('name,budget,kw', [
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1)),
+    ('synth_alltypes', 200, dict(blocks_per_part=1, rates_per_part=1000)),
+    ('h2o2', 24, dict(blocks_per_part=3, rates_per_part=10)),
+    ('h2o2_n2', 12, dict(blocks_per_part=100, rates_per_part=5)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_DEPTH=1',))),
+])
+def test_rblk_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
+    """Row blocks that rebuild their rates (Arrhenius, K_c, third body, theta per visit), the falloff /
+    PLOG pre-pass with its register ring, the d/dT column finished per block, energy-row partials handed
+    from kernel to kernel: against the oracle, both layouts, with and without the J_nplusone quirk."""
+    from oracle.oracle import Oracle
+    ev, L = _rblk_emu_lib(name, budget, str(tmp_path), **kw)
+    orc = Oracle(tables(name))
+    n = 300                               # crosses a 256-state hand-over tile
+    pres, y = synth.dist_b(n, ev.nsp)
+    ref = orc.batch_jacob(pres, np.ascontiguousarray(y.T))
+    for aos in (False, True):
+        jac = _run(L, ev.nsp, pres, y, aos=aos)
+        assert not np.isnan(jac).any()    # every entry written
+        assert jac_scaled_err(jac, ref, ev.nsp) <= 1.0
+    orc.lib.pjo_set_sum_last_species(1)
+    try:
+        ref1 = orc.batch_jacob(pres, np.ascontiguousarray(y.T))
+    finally:
+        orc.lib.pjo_set_sum_last_species(0)
+    assert jac_scaled_err(_run(L, ev.nsp, pres, y, sum_last=1), ref1, ev.nsp) <= 1.0
+
+
+def test_rblk_kernels_chunked(tmp_path, tables, monkeypatch):
+    """Batches larger than the chunk run chunk by chunk through the hand-over arrays of the internal streams."""
+    from oracle.oracle import Oracle
+    monkeypatch.setenv('PJ_RBLK_CHUNK', '256')
+    monkeypatch.setenv('PJ_RBLK_STREAMS', '2')
+    ev, L = _rblk_emu_lib('synth_alltypes', 16, str(tmp_path), blocks_per_part=2, rates_per_part=10)
+    n = 256 * 3 + 17
+    pres, y = synth.dist_b(n, ev.nsp, seed=5)
+    ref = Oracle(tables('synth_alltypes')).batch_jacob(pres, np.ascontiguousarray(y.T))
+    jac = _run(L, ev.nsp, pres, y)
+    assert not np.isnan(jac).any() and jac_scaled_err(jac, ref, ev.nsp) <= 1.0
+
+
+def test_rblk_kernels_vs_reference_golden(tmp_path, golden):
+    """53-species mechanism at the shipping budget against vectors from pyJac's generated C; the library's
+    rate outputs (k_rates<true> + k_dy of pj_rows.hip, linked in) against the same vectors."""
+    ev, L = _rblk_emu_lib('gri30_shaped', 56, str(tmp_path), blocks_per_part=13)
+    g = golden('gri30_shaped')
+    pres, y = g['pres'], np.ascontiguousarray(g['y'].T)
+    jac = _run(L, ev.nsp, pres, y)
+    assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0
+    fro = np.linalg.norm(jac - g['jac']) / np.linalg.norm(g['jac'])
+    assert fro < 1e-9
+    mx, _ = thresholded_rel_err(jac, g['jac'])
+    assert mx < 1e-4
+    L.pj_spec_rates.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long] + [_dp] * 6 + [ctypes.c_void_p]
+    n, nsp = pres.size, ev.nsp
+    rows = dict(conc=nsp, fwd=ev.n_fwd, rev=max(ev.n_rev, 1), pres_mod=max(ev.n_pres_mod, 1), spec_rates=nsp, dy=nsp)
+    bufs = {k: np.full((r, n), np.nan) for k, r in rows.items()}
+    P = lambda a: a.ctypes.data_as(_dp)
+    assert L.pj_spec_rates(n, P(pres), P(y), n, 1, *[P(bufs[k]) for k in rows], None) == 0
+    for k, cols in (('conc', nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
+        mx, _ = thresholded_rel_err(bufs[k].T[:, :cols], g[k][:, :cols])
+        assert mx < 1e-9, (k, mx)
