@@ -305,7 +305,7 @@ def main():
         line['config']['kernel'] = kernel_label(ev)
         if world == 1 and not a.no_also:
             line['also'] = also_workloads(wl, pyjac_amd, torch, np)
-            if ev.spec_kernel == 'pj_lane' and L == pyjac_amd.LAYOUT_SOA:
+            if ev.spec_kernel in ('pj_lane', 'pj_rblk') and L == pyjac_amd.LAYOUT_SOA:
                 # the Jacobian consumed in registers (w = J v), nothing but T, p, Y, v read
                 # and w written -- reported next to the headline, never part of `value`
                 try:

@@ -117,6 +117,13 @@ int pj_time_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
                          int y_layout, double* d_jac, int jac_layout, void* stream,
                          int iters, double* ms_per_launch);
 
+#ifdef PJ_TIMING
+/* debug builds only (-DPJ_TIMING: libpyjac_hip_timing.so, tools/phase_cycles.py): per-phase cycle
+ * counts of the table-driven kernel's first 64 workgroups (d_dbg: 640 doubles) */
+int pj_debug_phase_cycles(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
+                          double* d_jac, int jac_layout, double* d_dbg);
+#endif
+
 /* ---- host-pointer batch driver: pyjacob.cuh:6-10 init / run / cleanup ---- */
 /* returns padded (>= 1, multiple of 64; may be < num when device memory is
  * short, the caller then chunks as test.py:709-714 does) or a negative code */

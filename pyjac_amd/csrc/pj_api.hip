@@ -261,7 +261,15 @@ size_t bytes_per_state(const pj_mech* m)
 
 int ensure_device(pj_mech* m)
 {
-    if (m->on_device) return PJ_OK;
+    if (m->on_device) {
+        // a handle (its tables, workspaces and the scratch of an attached library) lives on the device
+        // that was current at its first evaluation
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != m->device)
+            return fail(PJ_EINVAL, "mechanism handle belongs to HIP device " + std::to_string(m->device) +
+                                   ", current device is " + std::to_string(dev) + ": create one handle per device");
+        return PJ_OK;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -434,11 +442,17 @@ const char* pj_version(void) { return "pyjac_amd 0.1 (gfx950)"; }
 int pj_mech_create(const int32_t* I, long nI, const double* D, long nD, pj_mech** out)
 {
     if (!I || !D || !out) return fail(PJ_EINVAL, "null argument");
-    pj_mech* m = new pj_mech();
-    if (!build_programs(I, nI, D, nD, m->P)) {
-        std::string e = m->P.error;
+    pj_mech* m = nullptr;
+    try {       // nothing may unwind through the C ABI
+        m = new pj_mech();
+        if (!build_programs(I, nI, D, nD, m->P)) {
+            std::string e = m->P.error;
+            delete m;
+            return fail(PJ_EUNSUPPORTED, e);
+        }
+    } catch (const std::exception& ex) {
         delete m;
-        return fail(PJ_EUNSUPPORTED, e);
+        return fail(PJ_ENOMEM, std::string("mechanism tables: ") + ex.what());
     }
     DevMech& M = m->M;
     memset(&M, 0, sizeof(M));
@@ -456,12 +470,21 @@ int pj_mech_load(const char* path, pj_mech** out)
     if (!f) return fail(PJ_EIO, std::string("cannot open ") + path);
     uint64_t hdr[2];
     if (fread(hdr, sizeof(uint64_t), 2, f) != 2) { fclose(f); return fail(PJ_EIO, "short table file"); }
-    std::vector<int32_t> I(hdr[0]);
-    std::vector<double> D(hdr[1]);
-    bool ok = fread(I.data(), 4, I.size(), f) == I.size() && fread(D.data(), 8, D.size(), f) == D.size();
-    fclose(f);
-    if (!ok) return fail(PJ_EIO, "short table file");
-    return pj_mech_create(I.data(), (long)I.size(), D.data(), (long)D.size(), out);
+    if (hdr[0] < (uint64_t)HDR || hdr[0] > (1ull << 28) || hdr[1] > (1ull << 28)) {
+        fclose(f);
+        return fail(PJ_EIO, "not a mechanism table file (implausible sizes)");
+    }
+    try {
+        std::vector<int32_t> I(hdr[0]);
+        std::vector<double> D(hdr[1]);
+        bool ok = fread(I.data(), 4, I.size(), f) == I.size() && fread(D.data(), 8, D.size(), f) == D.size();
+        fclose(f);
+        if (!ok) return fail(PJ_EIO, "short table file");
+        return pj_mech_create(I.data(), (long)I.size(), D.data(), (long)D.size(), out);
+    } catch (const std::exception& ex) {
+        fclose(f);
+        return fail(PJ_ENOMEM, std::string("table file: ") + ex.what());
+    }
 }
 
 void pj_mech_destroy(pj_mech* m)

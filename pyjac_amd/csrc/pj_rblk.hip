@@ -24,6 +24,10 @@
 //                  through hand-over slots that the next kernel loads with its state; the last kernel
 //                  finishes the row and jac[0].
 //
+//   PJQ_JV         the same row kernels with the Jacobian stores replaced by w_k += J(k, c) v_c: the
+//                  consumer of pyJac's sparse_multiplier (create_jacobian.py:3301-3404) fused in, NSP
+//                  instead of NSP^2 doubles written per state; v sits in AGPRs next to the energy row.
+//
 // The mechanism is injected as constexpr tables (pj::emit_spec_header + pj::emit_rows_tables ->
 // PJS_HEADER); every loop is a compile-time loop.  One translation unit per kernel (PJQ_PART).
 //
@@ -49,6 +53,12 @@ using namespace pj;
 
 #ifndef PJQ_BLOCK
 #define PJQ_BLOCK 256
+#endif
+#ifndef PJQ_JV
+#define PJQ_JV 0            // 1: the Jacobian is consumed in registers, w = J v per state (no Jacobian stores)
+#endif
+#ifndef PJQ_PAIR
+#define PJQ_PAIR 0          // 1: two Jacobian columns per 16-byte store (SoA output, whole workgroups)
 #endif
 #ifndef PJQ_SB_EVERY
 #define PJQ_SB_EVERY 1      // scheduling barrier after every n-th visit (0: none)
@@ -84,9 +94,6 @@ using namespace pj;
 #ifndef PJQ_NT_STORE
 #define PJQ_NT_STORE 1
 #endif
-#ifndef PJQ_PAIR
-#define PJQ_PAIR 0          // 1: two Jacobian columns per 16-byte store (SoA output, whole workgroups)
-#endif
 #if defined(PJQ_NO_STORE)
 // experiment: the arithmetic without the Jacobian stores (values folded into one sink per lane)
 #define PJQ_STORE(ptr, val) (pjq_sink += (val))
@@ -115,8 +122,11 @@ struct PjqArgs {
     const double* pres;                // chunk base
     const double* y; long y_si, y_ss;  // chunk base
     double* jac; long j_si, j_ss;      // chunk base
-    double* scr;                       // hand-over array [tile][NSCQ + 3][PJQ_TILE]
+    double* scr;                       // hand-over array [tile][NSLOTS][PJQ_TILE]
     int sum_last;
+    // PJQ_JV kernels (w = J v per state): chunk bases, element (i, s) at base[i*si + s*ss]
+    const double* v; long v_si, v_ss;
+    double* w; long w_si, w_ss;
 };
 typedef void (*pjq_launch_fn)(const PjqArgs&, void* stream);
 extern "C" void pjq_register(int id, int kind, pjq_launch_fn fn);
@@ -477,6 +487,15 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         if constexpr (sp == ONE) return 1.0;
         else return ((const double*)((const char*)clb[sp / CGRP] + vzo))[(sp % CGRP) * PJQ_BLOCK];
     };
+#if PJQ_JV
+    // the vector this state's Jacobian is applied to (read once per kernel; AGPRs)
+    double V[NSP];
+    {
+        const double* vp = A.v + s * A.v_ss;
+        static_for<NSP>([&](auto cc) PJR_INL { V[decltype(cc)::value] = vp[decltype(cc)::value * A.v_si]; });
+    }
+    double* const wp = A.w + s * A.w_ss;
+#endif
     // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
     double E[LAST > 0 ? LAST : 1];
     double H = 0.0, SCP = 0.0, SJT = 0.0;
@@ -754,7 +773,11 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             constexpr int r = decltype(rc)::value;
             constexpr int k = pjs::BLK_ROWS[r0 + r][0];
             if constexpr (k < LAST) {
-#if PJQ_PAIR
+#if PJQ_JV
+                double wk = 0.0;
+                static_for<NSP>([&](auto cc) PJR_INL { wk += col_val(rc, cc) * V[decltype(cc)::value]; });
+                wp[(k + 1) * A.w_si] = wk;
+#elif PJQ_PAIR
                 // two columns per store instruction: the lanes of a pair exchange one value each, the even
                 // lane then writes both states of column c, the odd lane both states of column c + 1
                 // (16 bytes per lane: half the store instructions in flight for the same bytes)
@@ -821,6 +844,17 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         });
         const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
         const double icp = 1.0 / cpavg;
+#if PJQ_JV
+        double w0 = (-(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg)) * V[0];
+        static_for<LAST>([&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+            double cpm, dcpm;
+            cp_of(jc, cpm, dcpm);
+            const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
+            w0 += (-E[j] * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp) * V[j + 1];
+        });
+        wp[0] = w0;
+#else
         PJQ_STORE(&J_(0), -(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg));
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
@@ -829,6 +863,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
             PJQ_STORE(&J_(NSP * (j + 1)), -E[j] * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp);
         });
+#endif
     }
 #ifdef PJQ_NO_STORE
     if (pjq_sink == 1.2345e-300) J_(0) = pjq_sink;
@@ -852,15 +887,15 @@ void read_timing(const PjqArgs& A, void*)   // A.scr: host buffer of 5 * 1024 * 
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol((void*)A.scr, HIP_SYMBOL(g_tim), sizeof(g_tim));
 }
-struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_PAIR ? 2 : 4, launch_part); pjq_register(PJQ_ID, 5, read_timing); } } reg_;
+struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_JV ? 6 : PJQ_PAIR ? 2 : 4, launch_part); pjq_register(PJQ_ID, 5, read_timing); } } reg_;
 #else
-struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_PAIR ? 2 : 4, launch_part); } } reg_;   // 2: pair stores, 4: general
+struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_JV ? 6 : PJQ_PAIR ? 2 : 4, launch_part); } } reg_;   // 2: pair stores, 4: general, 6: w = J v
 #endif
 #endif  // PJQ_PART == 2
 
 #if PJQ_PART == 0
 constexpr int MAXPARTS = 256;
-pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_rows_gen[MAXPARTS], g_timing[MAXPARTS];
+pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_rows_gen[MAXPARTS], g_rows_jv[MAXPARTS], g_timing[MAXPARTS];
 constexpr int MAXSTREAMS = 8;
 double* g_scr[MAXSTREAMS] = {};
 long g_scr_ld[MAXSTREAMS] = {};
@@ -876,7 +911,7 @@ extern "C" {
 void pjq_register(int id, int kind, pjq_launch_fn fn)
 {
     if (kind == 1) g_pre = fn;
-    else if (id >= 0 && id < MAXPARTS) (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : g_rows)[id] = fn;
+    else if (id >= 0 && id < MAXPARTS) (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : kind == 6 ? g_rows_jv : g_rows)[id] = fn;
 }
 
 // debug builds (-DPJQ_TIMING): cycles per phase of row kernel `part`, [5][1024 workgroups][4 wavefronts]
@@ -903,10 +938,13 @@ long pj_spec_scratch_doubles_per_state(void) { return NSLOTS; }
 // different chunks are out of step with each other.  The internal streams are forked from and joined
 // to the caller's stream with events: the call is asynchronous and ordered like one kernel launch on
 // `stream`.  PJ_RBLK_STREAMS=1: everything on the caller's stream.
-int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
-                     long j_si, long j_ss, int sum_last, void* stream)
+static int run_batch(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac, long j_si,
+                     long j_ss, const double* v, long v_si, long v_ss, double* w, long w_si, long w_ss, int sum_last,
+                     void* stream)
 {
     if (n <= 0) return 0;
+    const bool jv = w != nullptr;
+    if (jv && !g_rows_jv[0]) return -5;
     int nstreams = PJQ_STREAMS;
     long chunk_env = 0;
     if (const char* e = getenv("PJ_RBLK_STREAMS")) nstreams = atoi(e);
@@ -939,17 +977,18 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
     // the pair-store kernels need lane-contiguous (SoA) output, whole workgroups and column offsets
     // that fit 32 bits; everything else goes to the general kernels of the library
     const bool have_fast = g_rows[0] != nullptr, have_gen = g_rows_gen[0] != nullptr;
-    const bool fast_ok = have_fast && j_ss == 1 && (unsigned long)NSP * 8ul * (unsigned long)j_si < (1ul << 32);
+    const bool fast_ok = !jv && have_fast && j_ss == 1 && (unsigned long)NSP * 8ul * (unsigned long)j_si < (1ul << 32);
     long c = 0;
     for (long s0 = 0; s0 < n; s0 += chunk, ++c) {
         const long m = s0 + chunk < n ? chunk : n - s0;
         const int b = (int)(c % S);
         void* st = S > 1 ? (void*)g_streams[b] : stream;
-        PjqArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jac + s0 * j_ss, j_si, j_ss, g_scr[b], sum_last};
+        PjqArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jv ? nullptr : jac + s0 * j_ss, j_si, j_ss, g_scr[b], sum_last,
+                  jv ? v + s0 * v_ss : nullptr, v_si, v_ss, jv ? w + s0 * w_ss : nullptr, w_si, w_ss};
         const bool fast = fast_ok && m >= PJQ_BLOCK;
-        if (!fast && !have_gen) return -5;
+        if (!jv && !fast && !have_gen) return -5;
         if (g_pre) g_pre(A, st);
-        pjq_launch_fn* rows = fast ? g_rows : g_rows_gen;
+        pjq_launch_fn* rows = jv ? g_rows_jv : fast ? g_rows : g_rows_gen;
         for (int i = 0; i < MAXPARTS; ++i) if (rows[i]) rows[i](A, st);
     }
     if (S > 1)
@@ -958,6 +997,21 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
             (void)hipStreamWaitEvent(user, g_events[b], 0);
         }
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
+                     long j_si, long j_ss, int sum_last, void* stream)
+{
+    return run_batch(n, pres, y, y_si, y_ss, jac, j_si, j_ss, nullptr, 0, 0, nullptr, 0, 0, sum_last, stream);
+}
+
+// w_s = J(Phi_s) v_s per state, the Jacobian consumed in registers (include/pyjac_amd.h:
+// pj_eval_jacobian_vec_dev; pyJac's consumer: sparse_multiplier, create_jacobian.py:3301-3404)
+int pj_spec_jacvec(long n, const double* pres, const double* y, long y_si, long y_ss, const double* v,
+                   long v_si, long v_ss, double* w, long w_si, long w_ss, int sum_last, void* stream)
+{
+    if (!v || !w) return -1;
+    return run_batch(n, pres, y, y_si, y_ss, nullptr, 0, 0, v, v_si, v_ss, w, w_si, w_ss, sum_last, stream);
 }
 
 }  // extern "C"

@@ -28,12 +28,70 @@ int kind_rank(int fl)
 }
 }  // namespace
 
+// Structural validation of a table blob before anything indexes through it: a corrupt or truncated
+// .pjtab must be refused, not read out of bounds.  Array j of the blob extends to the start of array
+// j + 1 (pyjac_amd/tables.py writes them back to back).
+static bool validate_blob(const int32_t* I, long nI, const double*, long nD, std::string& err)
+{
+    auto bad = [&](const char* what) { err = std::string("malformed mechanism table blob: ") + what; return false; };
+    if (nI < HDR || I[0] != MAGIC || I[1] != 1 || I[12] != nI || I[13] != nD) return bad("header");
+    const int nsp = I[2], nrxn = I[3];
+    if (nsp < 1 || nsp > 4096 || nrxn < 0 || nrxn > 8191 || I[4] < 0 || I[4] > nrxn || I[5] < 0 || I[5] > nrxn)
+        return bad("sizes");
+    constexpr int NIA = 15, NDA = 20;
+    long ilen[NIA], dlen[NDA];
+    for (int j = 0; j < NIA; ++j) {
+        const long off = I[16 + j], nxt = j + 1 < NIA ? I[16 + j + 1] : nI;
+        if (off < HDR || off > nI || nxt < off || nxt > nI) return bad("integer array offsets");
+        ilen[j] = nxt - off;
+    }
+    for (int j = 0; j < NDA; ++j) {
+        const long off = I[48 + j], nxt = j + 1 < NDA ? I[48 + j + 1] : nD;
+        if (off < 0 || off > nD || nxt < off || nxt > nD) return bad("real array offsets");
+        dlen[j] = nxt - off;
+    }
+    auto ia = [&](int j) { return I + I[16 + j]; };
+    // per-reaction arrays
+    for (int j : {(int)IA_FLAGS, (int)IA_PDEP_SP, (int)IA_REV_IDX, (int)IA_PRES_IDX})
+        if (ilen[j] < nrxn) return bad("per-reaction integer array too short");
+    for (int j : {(int)IA_REAC_PTR, (int)IA_PROD_PTR, (int)IA_NET_PTR, (int)IA_EFF_PTR, (int)IA_PLOG_PTR, (int)IA_KC_PTR})
+        if (ilen[j] < nrxn + 1) return bad("CSR pointer array too short");
+    if (ilen[IA_SEEN] < nsp) return bad("species array too short");
+    for (int j : {(int)DA_A, (int)DA_B, (int)DA_E, (int)DA_KCPREF})
+        if (dlen[j] < nrxn) return bad("per-reaction real array too short");
+    if (dlen[DA_MW] < nsp || dlen[DA_TMID] < nsp || dlen[DA_LO] < 7L * nsp || dlen[DA_HI] < 7L * nsp) return bad("species tables");
+    if (dlen[DA_PD] < 3L * nrxn || dlen[DA_TROE] < 4L * nrxn || dlen[DA_SRI] < 5L * nrxn || dlen[DA_INFS] < 4L * nrxn ||
+        dlen[DA_TROE8] < 5L * nrxn)
+        return bad("falloff tables");
+    // CSR lists: monotone pointers inside their payload arrays, species indices in range
+    struct Csr { int ptr, sp, nu; long per; };
+    const Csr lists[] = {{IA_REAC_PTR, IA_REAC_SP, DA_REAC_NU, 1}, {IA_PROD_PTR, IA_PROD_SP, DA_PROD_NU, 1},
+                         {IA_NET_PTR, IA_NET_SP, DA_NET_NU, 1}, {IA_EFF_PTR, IA_EFF_SP, DA_EFF, 1}};
+    for (const Csr& c : lists) {
+        const int32_t* ptr = ia(c.ptr);
+        if (ptr[0] != 0) return bad("CSR pointer does not start at 0");
+        for (int i = 0; i < nrxn; ++i) if (ptr[i + 1] < ptr[i]) return bad("CSR pointer not monotone");
+        if (ptr[nrxn] > ilen[c.sp] || ptr[nrxn] > dlen[c.nu]) return bad("CSR payload too short");
+        const int32_t* sp = ia(c.sp);
+        for (int q = 0; q < ptr[nrxn]; ++q) if (sp[q] < 0 || sp[q] >= nsp) return bad("species index out of range");
+    }
+    {
+        const int32_t *pp = ia(IA_PLOG_PTR), *kp = ia(IA_KC_PTR);
+        if (pp[0] != 0 || kp[0] != 0) return bad("PLOG / K_c pointer does not start at 0");
+        for (int i = 0; i < nrxn; ++i) if (pp[i + 1] < pp[i] || kp[i + 1] < kp[i]) return bad("PLOG / K_c pointer not monotone");
+        if ((long)pp[nrxn] * 4 > dlen[DA_PLOG] || (long)pp[nrxn] > dlen[DA_PLOG4]) return bad("PLOG table too short");
+        if ((long)kp[nrxn] * KCW > dlen[DA_KCG]) return bad("K_c group table too short");
+    }
+    const int32_t *pd = ia(IA_PDEP_SP), *ri = ia(IA_REV_IDX), *pi = ia(IA_PRES_IDX);
+    for (int i = 0; i < nrxn; ++i)
+        if (pd[i] < -1 || pd[i] >= nsp || ri[i] < -1 || ri[i] >= I[4] || pi[i] < -1 || pi[i] >= I[5])
+            return bad("reaction index out of range");
+    return true;
+}
+
 bool build_programs(const int32_t* I, long nI, const double* D, long nD, Programs& p)
 {
-    if (nI < HDR || I[0] != MAGIC || I[1] != 1 || I[12] != nI || I[13] != nD) {
-        p.error = "malformed mechanism table blob";
-        return false;
-    }
+    if (!validate_blob(I, nI, D, nD, p.error)) return false;
     Blob B{I, D};
     const int nsp = I[2], nrxn = I[3];
     p.nsp = nsp; p.nrxn = nrxn; p.nrev = I[4]; p.npres = I[5];

@@ -65,10 +65,31 @@ class Evaluator:
     _SPEC_STEM = {'lane': 'libpj_spec_%016x.so', 'rows': 'libpj_rows_%016x.so', 'fused': 'libpj_fused_%016x.so',
                   'rblk': 'libpj_rblk_%016x.so'}
 
-    def spec_path(self, kind: str = None) -> str:
+    _SPEC_SOURCES = {'lane': ('pj_lane.hip',), 'rows': ('pj_rows.hip', 'pj_rows_rate.inc', 'pj_rows_block.inc'),
+                     'fused': ('pj_rows.hip', 'pj_rows_rate.inc', 'pj_rows_block.inc'),
+                     'rblk': ('pj_rblk.hip', 'pj_rows.hip', 'pj_rows_rate.inc')}
+    _SPEC_ENV = ('PJ_LANE_FLAGS', 'PJ_ROWS_FLAGS', 'PJ_ROWS_RATES_FLAGS', 'PJ_ROWS_BUDGET', 'PJ_ROWS_FUSE',
+                 'PJ_ROWS_RATES_PER_PART', 'PJ_ROWS_BLOCK', 'PJ_ROWS_RECOMPUTE_KR', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE',
+                 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES', 'PJ_RBLK_PAIR_MODES')
+
+    def spec_path(self, kind: str = None, **opts) -> str:
+        """File name of a specialised library: mechanism hash + a digest of everything else that shapes the
+        binary (the kernel sources, pj_tables.{h,cpp}, this file with its flags, the build options and
+        the PJ_* environment overrides), so a library built from other sources or with other options is
+        never attached by accident."""
+        import hashlib
+        kind = kind or self.spec_kind()
+        here = os.path.dirname(os.path.abspath(__file__))
+        d = hashlib.sha1(repr((kind, sorted((k, v) for k, v in opts.items() if v is not None),
+                               [(e, os.environ.get(e)) for e in self._SPEC_ENV if os.environ.get(e)])).encode())
+        for f in self._SPEC_SOURCES[kind] + ('pj_tables.h', 'pj_tables.cpp'):
+            with open(os.path.join(here, 'csrc', f), 'rb') as fh:
+                d.update(fh.read())
+        with open(os.path.abspath(__file__).replace('.pyc', '.py'), 'rb') as fh:
+            d.update(fh.read())
         h = _lib.lib().pj_mech_spec_hash(self._h)
-        return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'spec',
-                            self._SPEC_STEM[kind or self.spec_kind()] % h)
+        stem = self._SPEC_STEM[kind] % h
+        return os.path.join(here, 'spec', stem[:-3] + '_' + d.hexdigest()[:10] + '.so')
 
     def specialize(self, build: bool = False, kind: str = None, **rows_opts) -> bool:
         """Attach (and with build=True compile if missing) the mechanism-specific kernels.
@@ -77,11 +98,11 @@ class Evaluator:
         compile for a 53-species mechanism; coefficient tables of all reactions must fit the LDS)."""
         L = _lib.lib()
         kinds = [kind] if kind else [self.spec_kind()] + [k for k in ('lane', 'rblk', 'fused', 'rows') if k != self.spec_kind()]
-        so = next((self.spec_path(k) for k in kinds if os.path.exists(self.spec_path(k))), None)
+        so = next((self.spec_path(k, **rows_opts) for k in kinds if os.path.exists(self.spec_path(k, **rows_opts))), None)
         if so is None:
             if not build:
                 return False
-            so = self.spec_path(kinds[0])
+            so = self.spec_path(kinds[0], **rows_opts)
             if kinds[0] == 'lane':
                 self._build_lane(so)
             elif kinds[0] == 'fused':
@@ -110,7 +131,8 @@ class Evaluator:
                                '-ffinite-math-only -mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
                               ['-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
-                               '-o', so, os.path.join(here, 'csrc', 'pj_lane.hip')])
+                               '-o', so + '.tmp.%d' % os.getpid(), os.path.join(here, 'csrc', 'pj_lane.hip')])
+        os.replace(so + '.tmp.%d' % os.getpid(), so)     # other ranks / processes never see a half-written library
 
     def _build_fused(self, so: str, budget: int = None, **_):
         """csrc/pj_rows.hip as ONE kernel (PJR_PART=3): a workgroup of 4 wavefronts per 64-state
@@ -126,7 +148,8 @@ class Evaluator:
                                '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math').split()
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
                               ['-DPJR_PART=3', '-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
-                               '-o', so, os.path.join(here, 'csrc', 'pj_rows.hip')])
+                               '-o', so + '.tmp.%d' % os.getpid(), os.path.join(here, 'csrc', 'pj_rows.hip')])
+        os.replace(so + '.tmp.%d' % os.getpid(), so)
 
     def _build_rows(self, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None):
         """One translation unit per kernel of csrc/pj_rows.hip, compiled in parallel."""
@@ -179,13 +202,14 @@ class Evaluator:
             subprocess.check_call(base + job[0] + ['-o', os.path.join(work, job[1])])
         with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
             list(ex.map(run, jobs))
-        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] +
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so + '.tmp.%d' % os.getpid()] +
                               [os.path.join(work, j[1]) for j in jobs])
+        os.replace(so + '.tmp.%d' % os.getpid(), so)
         shutil.rmtree(work, ignore_errors=True)
 
     RBLK_BUDGET = 56          # accumulator doubles per row block of pj_rblk.hip (4 dense + non-zero S per row)
     RBLK_FUSE = 13            # row blocks per kernel (at most)
-    RBLK_FUSE_LARGE = 8       # ... for mechanisms whose concentration columns leave little LDS for the K_c rows
+    RBLK_FUSE_LARGE = 13      # ... for mechanisms whose concentration columns leave little LDS for the K_c rows
 
     def _build_rblk(self, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=()):
         """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the
@@ -238,6 +262,10 @@ class Evaluator:
                 jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
                                      '-DPJQ_B1=%d' % bounds[i + 1], '-DPJQ_FIRST=%d' % (i == 0),
                                      '-DPJQ_LAST=%d' % (i == nker - 1), '-DPJQ_PAIR=%d' % pair], 'rblk%d_%d.o' % (i, pair)))
+            # ... and as w = J v (the Jacobian consumed in registers)
+            jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
+                                 '-DPJQ_B1=%d' % bounds[i + 1], '-DPJQ_FIRST=%d' % (i == 0),
+                                 '-DPJQ_LAST=%d' % (i == nker - 1), '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % i))
         for i, r0 in enumerate(range(0, self.n_fwd, rpp)):
             jobs.append((rows + f_rates + ['-DPJR_PART=1', '-DPJR_ID=%d' % i, '-DPJR_R0=%d' % r0,
                                            '-DPJR_R1=%d' % min(self.n_fwd, r0 + rpp)], 'rates%d.o' % i))
@@ -309,16 +337,29 @@ class Evaluator:
         import torch
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    @staticmethod
+    def _chk(name, t, numel, device=None):
+        """The C ABI takes raw pointers: a wrong size, dtype, device or a strided view would be an
+        out-of-bounds access on the device, so refuse it here."""
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError('%s: expected a contiguous float64 CUDA tensor' % name)
+        if t.numel() != numel:
+            raise ValueError('%s: expected %d elements, got %d' % (name, numel, t.numel()))
+        if device is not None and t.device != device:
+            raise ValueError('%s: on %s, expected %s' % (name, t.device, device))
+
     def jacobian(self, pres, y, y_layout=LAYOUT_SOA, out=None, jac_layout=LAYOUT_SOA):
         """pres: (n,) cuda f64; y: SoA (NSP, n) or AoS (n, NSP) cuda f64.
         Returns jac as SoA (NSP*NSP, n) or AoS (n, NSP*NSP)."""
         import torch
         n = pres.numel()
-        assert pres.is_cuda and y.is_cuda and pres.dtype == torch.float64 and y.dtype == torch.float64
-        assert y.is_contiguous() and pres.is_contiguous() and y.numel() == n * self.nsp
+        self._chk('pres', pres, n)
+        self._chk('y', y, n * self.nsp, pres.device)
         if out is None:
             shape = (self.nsp * self.nsp, n) if jac_layout == LAYOUT_SOA else (n, self.nsp * self.nsp)
             out = torch.empty(shape, dtype=torch.float64, device=pres.device)
+        self._chk('out', out, n * self.nsp * self.nsp, pres.device)
         check(_lib.lib().pj_eval_jacobian_dev(self._h, n, pres.data_ptr(), y.data_ptr(), y_layout,
                                               out.data_ptr(), jac_layout, self._stream()))
         return out
@@ -328,10 +369,12 @@ class Evaluator:
         Jacobian kernel when a pj_lane library is attached).  y, v, w: SoA (NSP, n) or AoS (n, NSP)."""
         import torch
         n = pres.numel()
-        assert pres.is_cuda and y.is_cuda and v.is_cuda and y.dtype == v.dtype == torch.float64
-        assert y.is_contiguous() and v.is_contiguous() and y.numel() == v.numel() == n * self.nsp
+        self._chk('pres', pres, n)
+        self._chk('y', y, n * self.nsp, pres.device)
+        self._chk('v', v, n * self.nsp, pres.device)
         if out is None:
             out = torch.empty_like(v)
+        self._chk('out', out, n * self.nsp, pres.device)
         check(_lib.lib().pj_eval_jacobian_vec_dev(self._h, n, pres.data_ptr(), y.data_ptr(), layout,
                                                   v.data_ptr(), out.data_ptr(), layout, self._stream()))
         return out
@@ -341,6 +384,8 @@ class Evaluator:
         """All SoA outputs of pyjacob.cu's k_dydt pass as a dict of (rows, n) tensors."""
         import torch
         n = pres.numel()
+        self._chk('pres', pres, n)
+        self._chk('y', y, n * self.nsp, pres.device)
         rows = dict(conc=self.nsp, fwd=self.n_fwd, rev=max(self.n_rev, 1),
                     pres_mod=max(self.n_pres_mod, 1), spec_rates=self.nsp, dydt=self.nsp)
         outs = {k: torch.zeros((rows[k], n), dtype=torch.float64, device=pres.device) for k in want}
@@ -355,9 +400,12 @@ class Evaluator:
         performance_tester/fd_jacob.c); y SoA (NSP, n)."""
         import torch
         n = pres.numel()
+        self._chk('pres', pres, n)
+        self._chk('y', y, n * self.nsp, pres.device)
         if out is None:
             shape = (self.nsp * self.nsp, n) if jac_layout == LAYOUT_SOA else (n, self.nsp * self.nsp)
             out = torch.empty(shape, dtype=torch.float64, device=pres.device)
+        self._chk('out', out, n * self.nsp * self.nsp, pres.device)
         check(_lib.lib().pj_eval_fd_jacobian_dev(self._h, n, pres.data_ptr(), y.data_ptr(), out.data_ptr(),
                                                  jac_layout, self._stream()))
         return out
@@ -365,6 +413,9 @@ class Evaluator:
     def time_jacobian(self, pres, y, out, iters: int, y_layout=LAYOUT_SOA, jac_layout=LAYOUT_SOA):
         """Average kernel time (ms) over `iters` launches, HIP events on the
         launch stream (pj_time_jacobian_dev)."""
+        self._chk('pres', pres, pres.numel())
+        self._chk('y', y, pres.numel() * self.nsp, pres.device)
+        self._chk('out', out, pres.numel() * self.nsp * self.nsp, pres.device)
         ms = ctypes.c_double()
         check(_lib.lib().pj_time_jacobian_dev(self._h, pres.numel(), pres.data_ptr(), y.data_ptr(),
                                               y_layout, out.data_ptr(), jac_layout, self._stream(),

@@ -14,12 +14,13 @@ Reference behaviours reproduced on purpose (each cited where it is done):
   * last species = first of N2/AR/HE     create_jacobian.py:3521-3563
   * element weights / RU / PA            chem_utilities.py:16-24, 51-99
 
-Not supported (pyJac reads them; out of scope per SURVEY.md section 8(f) N4):
-CHEB reactions raise ``NotImplementedError``; Cantera input is not read.
+Not supported (pyJac reads it):
+Cantera input is not read.
 """
 from __future__ import annotations
 
 import copy
+import math
 import re
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
@@ -87,6 +88,12 @@ class Reaction:
     sri_par: list = field(default_factory=list)
     plog: bool = False
     plog_par: list = field(default_factory=list)       # [[P, A, b, E], ...]
+    cheb: bool = False
+    cheb_n_temp: int = 0
+    cheb_n_pres: int = 0
+    cheb_par: list = field(default_factory=list)       # row-major [n_temp][n_pres], log10 k
+    cheb_tlim: list = field(default_factory=list)      # [Tmin, Tmax] K
+    cheb_plim: list = field(default_factory=list)      # [Pmin, Pmax] Pa
 
 
 @dataclass
@@ -429,9 +436,24 @@ def parse_mech(text: str, therm_text: Optional[str] = None,
                     rx.sri_par = [_fl(body[1]), _fl(body[2]), _fl(body[3])]
                     if len(body) > 4:
                         rx.sri_par += [_fl(body[4]), _fl(body[5])]
-                elif aux in ('che', 'pch', 'tch'):
-                    raise NotImplementedError(
-                        'Chebyshev reactions are out of scope (SURVEY.md 8(f) N4)')
+                elif aux == 'che':
+                    # Chebyshev rate expression (mech_interpret.py:589-606): "CHEB / n m c.. /", then
+                    # continuation lines of coefficients; not lumped in with the falloff reactions
+                    if not rx.cheb:
+                        rx.cheb = True
+                        rx.pdep = False
+                        rx.cheb_n_temp, rx.cheb_n_pres = int(_fl(body[1])), int(_fl(body[2]))
+                        rx.cheb_par = [_fl(t) for t in body[3:]]
+                    else:
+                        rx.cheb_par += [_fl(t) for t in body[1:]]
+                elif aux == 'pch':
+                    rx.cheb_plim = [_fl(body[1]) * PA, _fl(body[2]) * PA]       # atm -> Pa
+                    if len(body) > 5 and body[3].lower() == 'tcheb':
+                        rx.cheb_tlim = [_fl(body[4]), _fl(body[5])]
+                elif aux == 'tch':
+                    rx.cheb_tlim = [_fl(body[1]), _fl(body[2])]
+                    if len(body) > 5 and body[3].lower() == 'pcheb':
+                        rx.cheb_plim = [_fl(body[4]) * PA, _fl(body[5]) * PA]
                 elif aux == 'plo':
                     if not rx.plog:
                         rx.plog = True
@@ -446,6 +468,22 @@ def parse_mech(text: str, therm_text: Optional[str] = None,
                 else:
                     for i in range(0, len(body) - 1, 2):
                         rx.thd_body_eff.append((body[i], _fl(body[i + 1])))
+
+    # Chebyshev reactions: coefficient count, unit conversion of the leading coefficient
+    # (mech_interpret.py:663-680)
+    for idx, rx in enumerate(reacs):
+        if not rx.cheb:
+            continue
+        if len(rx.cheb_par) != rx.cheb_n_temp * rx.cheb_n_pres:
+            raise ValueError('incorrect number of CHEB coefficients in reaction %d' % idx)
+        if len(rx.cheb_tlim) != 2 or len(rx.cheb_plim) != 2:
+            raise ValueError('reaction %d: CHEB needs TCHEB and PCHEB limits' % idx)
+        if rx.cheb_n_temp < 3 or rx.cheb_n_pres < 2:
+            # the reference's emitters index dot_prod[2] / cheb_par[i, 1] unconditionally
+            # (rate_subs.py:199-230, create_jacobian.py:1553-1585)
+            raise ValueError('reaction %d: CHEB needs at least 3 x 2 coefficients' % idx)
+        if units_A == 'moles':
+            rx.cheb_par[0] += math.log10(0.001 ** (sum(rx.reac_nu) - 1.))
 
     # explicit REV -> pair of irreversible reactions (mech_interpret.py:693-713)
     out: List[Reaction] = []

@@ -15,6 +15,11 @@ order, so the tables hold bit-identical constants:
   * Troe parameters as ``get_rxn_pres_mod`` prints them ('%.8e')  rate_subs.py:1187-1211
   * falloff beta difference as the Jacobian prints it ('%.4e')    create_jacobian.py:1167
   * PLOG pressure breakpoints as printed ('%.4e')        rate_subs.py:601-629
+  * SRI parameters as each emitter prints them ('{:.6}' in get_rxn_pres_mod and the F_i factor,
+    '{:.4}' in the dPr/dY_j term, '{:.16}' in the d/dT term)
+                                                         rate_subs.py:1229-1256, create_jacobian.py:173-179, 249-266, 1194-1237
+  * Chebyshev coefficients and reduced-variable constants as printed ('{:.8e}' in the rate,
+    '{:.16e}' in the d/dT sum)                           rate_subs.py:149-251, create_jacobian.py:1532-1684
 
 Blob layout (version 1).  ``I[0:HDR]`` is a header; ``I[16+j]`` is the offset in
 ``I`` of int array j, ``I[48+j]`` the offset in ``D`` of double array j.
@@ -35,15 +40,17 @@ HDR = 96
 # reaction flag bits
 F_REV, F_THD, F_PDEP, F_LOW, F_HIGH = 1, 2, 4, 8, 16
 F_TROE, F_SRI, F_PLOG, F_TROE4, F_SRI5, F_HAS_EFF = 32, 64, 128, 256, 512, 1024
+F_CHEB = 32768      # (2048 .. 16384 are derived by the device-table builder, csrc/pj_tables.h)
 
 # int arrays
 (IA_FLAGS, IA_REAC_PTR, IA_REAC_SP, IA_PROD_PTR, IA_PROD_SP, IA_NET_PTR,
  IA_NET_SP, IA_EFF_PTR, IA_EFF_SP, IA_PLOG_PTR, IA_KC_PTR, IA_PDEP_SP,
- IA_REV_IDX, IA_PRES_IDX, IA_SEEN) = range(15)
+ IA_REV_IDX, IA_PRES_IDX, IA_SEEN, IA_CHEB_PTR) = range(16)
 # double arrays
 (DA_MW, DA_TMID, DA_LO, DA_HI, DA_A, DA_B, DA_E, DA_REAC_NU, DA_PROD_NU,
  DA_NET_NU, DA_EFF, DA_PD, DA_TROE, DA_SRI, DA_PLOG, DA_KCG, DA_KCPREF,
- DA_INFS, DA_TROE8, DA_PLOG4) = range(20)
+ DA_INFS, DA_TROE8, DA_PLOG4, DA_SRIQ, DA_CHEB) = range(22)
+SRIQ_W = 16         # doubles per reaction in DA_SRIQ
 
 
 def _r(fmt: str, x: float) -> float:
@@ -123,8 +130,8 @@ def _kc_groups(mech: Mechanism, rx):
 
 def build_tables(mech: Mechanism) -> MechTables:
     nsp, nrxn = mech.nsp, len(mech.reacs)
-    ia = [[] for _ in range(15)]
-    da = [[] for _ in range(20)]
+    ia = [[] for _ in range(16)]
+    da = [[] for _ in range(22)]
 
     for sp in mech.specs:
         da[DA_MW].append(sp.mw)
@@ -134,7 +141,7 @@ def build_tables(mech: Mechanism) -> MechTables:
 
     seen = [0] * nsp
     rev_i = pres_i = 0
-    for p in (IA_REAC_PTR, IA_PROD_PTR, IA_NET_PTR, IA_EFF_PTR, IA_PLOG_PTR, IA_KC_PTR):
+    for p in (IA_REAC_PTR, IA_PROD_PTR, IA_NET_PTR, IA_EFF_PTR, IA_PLOG_PTR, IA_KC_PTR, IA_CHEB_PTR):
         ia[p].append(0)
     for rx in mech.reacs:
         fl = 0
@@ -160,6 +167,10 @@ def build_tables(mech: Mechanism) -> MechTables:
                 fl |= F_SRI5
         if rx.plog:
             fl |= F_PLOG
+        if rx.cheb:
+            fl |= F_CHEB
+            if rx.plog or rx.pdep or rx.thd_body:
+                raise ValueError('Chebyshev reaction combined with another pressure dependence')
         if rx.thd_body_eff:
             fl |= F_HAS_EFF
         if any(not float(n).is_integer() for n in rx.reac_nu + rx.prod_nu):
@@ -205,6 +216,31 @@ def build_tables(mech: Mechanism) -> MechTables:
         da[DA_TROE] += tro[:4]
         sri = list(rx.sri_par) + [0.0] * (5 - len(rx.sri_par))
         da[DA_SRI] += sri[:5]
+        if rx.sri:
+            a, b, c = rx.sri_par[0], rx.sri_par[1], rx.sri_par[2]
+            five = len(rx.sri_par) == 5
+            d, e = (rx.sri_par[3], rx.sri_par[4]) if five else (1.0, 0.0)
+            da[DA_SRIQ] += [_r('{:.6}', a), _r('{:.6}', b), _r('{:.6}', c), _r('{:.8e}', d), _r('{:.6}', e),
+                            1.0 if (five and d != 1.0 and e != 0.0) else 0.0,
+                            _r('{:.4}', a), _r('{:.4}', b), _r('{:.4}', c),
+                            _r('{:.16}', a), _r('{:.16}', b), _r('{:.16}', c), _r('{:.16}', a * b),
+                            _r('{:.16e}', 1.0 / c), _r('{:.16}', e) if (five and e != 0.0) else 0.0, 0.0]
+        else:
+            da[DA_SRIQ] += [0.0] * SRIQ_W
+        if rx.cheb:
+            n, m = rx.cheb_n_temp, rx.cheb_n_pres
+            par = np.reshape(np.array(rx.cheb_par, dtype=float), (n, m))
+            tsum = 1.0 / rx.cheb_tlim[0] + 1.0 / rx.cheb_tlim[1]
+            tsub = 1.0 / rx.cheb_tlim[1] - 1.0 / rx.cheb_tlim[0]
+            psum = math.log10(rx.cheb_plim[0]) + math.log10(rx.cheb_plim[1])
+            psub = math.log10(rx.cheb_plim[1]) - math.log10(rx.cheb_plim[0])
+            rec = [float(n), float(m), _r('{:.8e}', tsum), _r('{:.8e}', tsub), _r('{:.8e}', psum), _r('{:.8e}', psub),
+                   _r('{:.16e}', tsum), _r('{:.16e}', tsub), _r('{:.16e}', psum), _r('{:.16e}', psub),
+                   _r('{:.16e}', -2.0 * math.log(10) / tsub)]
+            rec += [_r('{:.8e}', par[i, j]) for i in range(n) for j in range(m)]
+            rec += [_r('{:.16e}', i * par[i, j]) for i in range(1, n) for j in range(m)]
+            da[DA_CHEB] += rec
+        ia[IA_CHEB_PTR].append(len(da[DA_CHEB]))
         if rx.troe:
             a, T3, T1 = rx.troe_par[0], rx.troe_par[1], rx.troe_par[2]
             T2 = tro[3]

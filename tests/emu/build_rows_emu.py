@@ -59,6 +59,9 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
         jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % n, '-DPJQ_B0=%d' % b0,
                              '-DPJQ_B1=%d' % min(nblk, b0 + blocks_per_part), '-DPJQ_FIRST=%d' % (n == 0),
                              '-DPJQ_LAST=%d' % (n == len(starts) - 1), '-DPJQ_PAIR=0'], 'rblk%d.o' % n))
+        jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % n, '-DPJQ_B0=%d' % b0,
+                             '-DPJQ_B1=%d' % min(nblk, b0 + blocks_per_part), '-DPJQ_FIRST=%d' % (n == 0),
+                             '-DPJQ_LAST=%d' % (n == len(starts) - 1), '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % n))
     for n, r0 in enumerate(range(0, nrxn, rates_per_part)):
         jobs.append((rows + ['-DPJR_PART=1', '-DPJR_ID=%d' % n, '-DPJR_R0=%d' % r0,
                              '-DPJR_R1=%d' % min(nrxn, r0 + rates_per_part)], 'rates%d.o' % n))

@@ -466,22 +466,24 @@ def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
 
 
 @pytest.mark.parametrize('name,fused', [('h2o2_n2', True), ('synth_alltypes', True), ('h2o2_n2', False),
-                                        ('gri30_shaped', False)])
+                                        ('gri30_shaped', 'rblk'), ('gri30_shaped', False), ('usc2_shaped', 'rblk')])
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
 def test_jacobian_vector_product(name, fused, layout, tables, torch_cuda):
     """N2: w = J v per state (pyJac's sparse_multiplier consumer, create_jacobian.py:3301-3404), fused
-    into the register-resident kernel (no Jacobian in memory) and through the unfused chunked path,
-    against the oracle's Jacobian times the same vectors."""
+    into the register-resident kernel and into the row-block kernels (no Jacobian in memory) and through
+    the unfused chunked path, against the oracle's Jacobian times the same vectors."""
     import pyjac_amd
     from oracle.oracle import Oracle
     from pyjac_amd import synth
     torch = torch_cuda
     ev = _ev(name)
-    if fused:
+    if fused == 'rblk':
+        assert ev.spec_kernel == 'pj_rblk'          # PJQ_JV kernels of csrc/pj_rblk.hip
+    elif fused:
         assert ev.spec_kernel == 'pj_lane'
-    elif ev.spec_kernel == 'pj_lane':
-        ev.use_spec(False)
-    n = 1500
+    else:
+        ev.use_spec(False)                          # unfused: Jacobian chunks + mat-vec kernel
+    n = 1500 if ev.nsp <= 64 else 400
     pres, y = synth.dist_b(n, ev.nsp, seed=12, Tlo=700, Thi=2500)
     v = np.random.default_rng(3).standard_normal((ev.nsp, n))
     v[0] *= 100.0                                   # temperature component on its own scale

@@ -256,3 +256,30 @@ def test_rblk_kernels_vs_reference_golden(tmp_path, golden):
     for k, cols in (('conc', nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
         mx, _ = thresholded_rel_err(bufs[k].T[:, :cols], g[k][:, :cols])
         assert mx < 1e-9, (k, mx)
+
+
+@pytest.mark.parametrize('name,budget,kw', [
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+])
+def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
+    """N2 for the row-block family: w = J v per state with the Jacobian consumed in registers
+    (pj_spec_jacvec, PJQ_JV kernels) against the oracle's Jacobian times the same vectors, both layouts."""
+    from oracle.oracle import Oracle
+    ev, L = _rblk_emu_lib(name, budget, str(tmp_path), **kw)
+    L.pj_spec_jacvec.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp, ctypes.c_long, ctypes.c_long,
+                                 _dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    n, nsp = 300, ev.nsp
+    pres, y = synth.dist_b(n, nsp, seed=12, Tlo=700, Thi=2500)
+    v = np.random.default_rng(3).standard_normal((nsp, n))
+    v[0] *= 100.0
+    J = Oracle(tables(name)).batch_jacob(pres, np.ascontiguousarray(y.T)).reshape(n, nsp, nsp)   # [s][col][row]
+    ref = np.einsum('scr,cs->sr', J, v)
+    scale = np.einsum('scr,cs->sr', np.abs(J), np.abs(v)) + 1e-300
+    P = lambda a: a.ctypes.data_as(_dp)
+    ys, vs, ws = np.ascontiguousarray(y), np.ascontiguousarray(v), np.full((nsp, n), np.nan)
+    assert L.pj_spec_jacvec(n, P(pres), P(ys), n, 1, P(vs), n, 1, P(ws), n, 1, 0, None) == 0
+    assert (np.abs(ws.T - ref) / scale).max() < 1e-9
+    ya, va, wa = np.ascontiguousarray(y.T), np.ascontiguousarray(v.T), np.full((n, nsp), np.nan)
+    assert L.pj_spec_jacvec(n, P(pres), P(ya), 1, nsp, P(va), 1, nsp, P(wa), 1, nsp, 0, None) == 0
+    assert (np.abs(wa - ref) / scale).max() < 1e-9
