@@ -34,13 +34,13 @@
 #define MAGIC 0x314D4A50
 
 enum { F_REV = 1, F_THD = 2, F_PDEP = 4, F_LOW = 8, F_HIGH = 16, F_TROE = 32,
-       F_SRI = 64, F_PLOG = 128, F_TROE4 = 256, F_SRI5 = 512, F_HAS_EFF = 1024 };
+       F_SRI = 64, F_PLOG = 128, F_TROE4 = 256, F_SRI5 = 512, F_HAS_EFF = 1024, F_CHEB = 32768 };
 enum { IA_FLAGS, IA_REAC_PTR, IA_REAC_SP, IA_PROD_PTR, IA_PROD_SP, IA_NET_PTR,
        IA_NET_SP, IA_EFF_PTR, IA_EFF_SP, IA_PLOG_PTR, IA_KC_PTR, IA_PDEP_SP,
-       IA_REV_IDX, IA_PRES_IDX, IA_SEEN };
+       IA_REV_IDX, IA_PRES_IDX, IA_SEEN, IA_CHEB_PTR };
 enum { DA_MW, DA_TMID, DA_LO, DA_HI, DA_A, DA_B, DA_E, DA_REAC_NU, DA_PROD_NU,
        DA_NET_NU, DA_EFF, DA_PD, DA_TROE, DA_SRI, DA_PLOG, DA_KCG, DA_KCPREF,
-       DA_INFS, DA_TROE8, DA_PLOG4 };
+       DA_INFS, DA_TROE8, DA_PLOG4, DA_SRIQ, DA_CHEB };
 
 #define RU 8314.4621 /* chem_utilities.py:16, printed '%.8e' = 8.31446210e+03 */
 
@@ -53,7 +53,8 @@ typedef struct pjo_mech {
         *pres_idx, *seen;
     const double *mw, *tmid, *lo, *hi, *A, *b, *E, *reac_nu, *prod_nu,
         *net_nu, *eff, *pd, *troe, *sri, *plog, *kcg, *kcpref, *infs, *troe8,
-        *plog4;
+        *plog4, *sriq, *cheb;
+    const int32_t *cheb_ptr;
 } pjo_mech;
 
 pjo_mech *pjo_create(const int32_t *I, long nI, const double *D, long nD)
@@ -79,6 +80,7 @@ pjo_mech *pjo_create(const int32_t *I, long nI, const double *D, long nD)
     m->pd = DP(DA_PD); m->troe = DP(DA_TROE); m->sri = DP(DA_SRI); m->plog = DP(DA_PLOG);
     m->kcg = DP(DA_KCG); m->kcpref = DP(DA_KCPREF); m->infs = DP(DA_INFS);
     m->troe8 = DP(DA_TROE8); m->plog4 = DP(DA_PLOG4);
+    m->sriq = DP(DA_SRIQ); m->cheb = DP(DA_CHEB); m->cheb_ptr = IP(IA_CHEB_PTR);
     return m;
 }
 
@@ -142,9 +144,92 @@ static double plog_kf(const pjo_mech *m, int i, double T, double logT, double pr
     return 0.0; /* unreachable for ordered breakpoints */
 }
 
+/* Chebyshev record (pyjac_amd/tables.py): n, m, the reduced-variable constants as the rate emitter prints
+ * them ('{:.8e}'), as the Jacobian emitter does ('{:.16e}'), -2 ln10 / (1/Tmax - 1/Tmin), n x m coefficients
+ * ('{:.8e}'), (n-1) x m coefficients i * c_ij ('{:.16e}'). */
+enum { CH_N, CH_M, CH_TSUM8, CH_TSUB8, CH_PSUM8, CH_PSUB8, CH_TSUM16, CH_TSUB16, CH_PSUM16, CH_PSUB16, CH_DFAC, CH_COEF };
+
+/* get_cheb_rate, rate_subs.py:149-251 */
+static double cheb_kf(const pjo_mech *m, int i, double T, double pres, int in_jacobian)
+{
+    const double *C = m->cheb + m->cheb_ptr[i];
+    const int n = (int)C[CH_N], mm = (int)C[CH_M];
+    const double *c = C + CH_COEF;
+    double dot_prod[16];
+    /* eval_jacob re-evaluates k_f for the dR/dY_j terms with get_cheb_rate(write_defns=False): the
+     * '{:.8e}' coefficients, but the Tred / Pred of write_cheb_rxn_dt ('{:.16e}' constants,
+     * create_jacobian.py:1647-1664) */
+    double Tred = in_jacobian ? ((2.0 / T) - C[CH_TSUM16]) / C[CH_TSUB16] : ((2.0 / T) - C[CH_TSUM8]) / C[CH_TSUB8];
+    double Pred = in_jacobian ? (2.0 * log10(pres) - C[CH_PSUM16]) / C[CH_PSUB16]
+                              : (2.0 * log10(pres) - C[CH_PSUM8]) / C[CH_PSUB8];
+    double ct[2] = {1, Pred};
+    for (int a = 0; a < n; ++a) dot_prod[a] = c[a * mm] + Pred * c[a * mm + 1];
+    int upd = 1;
+    for (int j = 2; j < mm; ++j) {
+        int nw = upd ? 1 : 0, old = upd ? 0 : 1;
+        ct[old] = 2 * Pred * ct[nw] - ct[old];
+        for (int a = 0; a < n; ++a) dot_prod[a] += c[a * mm + j] * ct[old];
+        upd = !upd;
+    }
+    ct[0] = 1; ct[1] = Tred;
+    double kf = dot_prod[0] + Tred * dot_prod[1];
+    upd = 1;
+    for (int a = 2; a < n; ++a) {
+        int nw = upd ? 1 : 0, old = upd ? 0 : 1;
+        ct[old] = 2 * Tred * ct[nw] - ct[old];
+        kf += dot_prod[a] * ct[old];
+        upd = !upd;
+    }
+    return pow(10.0, kf);
+}
+
+/* write_cheb_ut, create_jacobian.py:1532-1607: sum_i i c_ij T_j(Pred) U_{i-1}(Tred) */
+static double cheb_ut(const pjo_mech *m, int i, double T, double pres)
+{
+    const double *C = m->cheb + m->cheb_ptr[i];
+    const int n = (int)C[CH_N], mm = (int)C[CH_M];
+    const double *c = C + CH_COEF + n * mm;      /* rows i = 1 .. n-1 */
+    double dot_prod[16];
+    double Tred = ((2.0 / T) - C[CH_TSUM16]) / C[CH_TSUB16];
+    double Pred = (2.0 * log10(pres) - C[CH_PSUM16]) / C[CH_PSUB16];
+    double ct[2] = {1, Pred};
+    for (int a = 1; a < n; ++a) dot_prod[a] = c[(a - 1) * mm] + Pred * c[(a - 1) * mm + 1];
+    int upd = 1;
+    for (int j = 2; j < mm; ++j) {
+        int nw = upd ? 1 : 0, old = upd ? 0 : 1;
+        ct[old] = 2 * Pred * ct[nw] - ct[old];
+        for (int a = 1; a < n; ++a) dot_prod[a] += c[(a - 1) * mm + j] * ct[old];
+        upd = !upd;
+    }
+    ct[0] = 1.0; ct[1] = 2.0 * Tred;
+    double kf = dot_prod[1] + 2.0 * Tred * dot_prod[2];
+    upd = 1;
+    for (int a = 3; a < n; ++a) {
+        int nw = upd ? 1 : 0, old = upd ? 0 : 1;
+        ct[old] = 2.0 * Tred * ct[nw] - ct[old];
+        kf += dot_prod[a] * ct[old];
+        upd = !upd;
+    }
+    return kf;
+}
+
+/* SRI parameter variants (pyjac_amd/tables.py DA_SRIQ): each emitter's print precision */
+enum { SR_A6, SR_B6, SR_C6, SR_D8, SR_E6, SR_USE_DE, SR_A4, SR_B4, SR_C4, SR_A16, SR_B16, SR_C16, SR_AB16,
+       SR_INVC16, SR_E16, SRW = 16 };
+
+/* the F_i factor as get_rxn_pres_mod and write_dr_dy print it (rate_subs.py:1229-1256,
+ * create_jacobian.py:249-266): '{:.6}' parameters, d as '{:.8e}' */
+static double sri_F(const double *Q, double T, double X)
+{
+    double F = pow(Q[SR_A6] * exp(-Q[SR_B6] / T) + exp(-T / Q[SR_C6]), X);
+    if (Q[SR_USE_DE] != 0.0) F = F * Q[SR_D8] * pow(T, Q[SR_E6]);
+    return F;
+}
+
 static double fwd_kf(const pjo_mech *m, int i, double T, double logT, double pres)
 {
     if (m->flags[i] & F_PLOG) return plog_kf(m, i, T, logT, pres);
+    if (m->flags[i] & F_CHEB) return cheb_kf(m, i, T, pres, 0);
     return rate_const(m->A[i], m->b[i], m->E[i], T, logT);
 }
 
@@ -246,6 +331,12 @@ void pjo_get_rxn_pres_mod(const pjo_mech *m, double T, double pres, const double
                 double A = log10(fmax(Pr, 1.0e-300)) - 0.67 * logFcent - 0.4;
                 double B = 0.806 - 1.1762 * logFcent - 0.14 * log10(fmax(Pr, 1.0e-300));
                 val = pow(10.0, logFcent / (1.0 + A * A / (B * B)));
+                if (fl & F_LOW) val = val * Pr / (1.0 + Pr);
+                else val = val / (1.0 + Pr);
+            } else if (fl & F_SRI) {
+                /* rate_subs.py:1229-1256 */
+                double X = 1.0 / (1.0 + log10(fmax(Pr, 1.0e-300)) * log10(fmax(Pr, 1.0e-300)));
+                val = sri_F(m->sriq + SRW * i, T, X);
                 if (fl & F_LOW) val = val * Pr / (1.0 + Pr);
                 else val = val / (1.0 + Pr);
             } else {
@@ -397,7 +488,8 @@ void pjo_eval_jacob(const pjo_mech *m, double t, double pres, const double *y, d
         const double R = isrev ? (Rf - Rr) : Rf;
         const double nu_r = sum_nu(m->reac_nu, r0, r1);
         const double nu_p = sum_nu(m->prod_nu, p0, p1);
-        double Pr = 0.0, Fcent = 0.0, A = 0.0, B = 0.0, lnF_AB = 0.0;
+        double Pr = 0.0, Fcent = 0.0, A = 0.0, B = 0.0, lnF_AB = 0.0, X = 0.0;
+        const double *Q = m->sriq + SRW * i;
         const double *inf = m->infs + 4 * i;
 
         /* ---------------- d/dT, create_jacobian.py:2728-2845 ---------------- */
@@ -427,6 +519,15 @@ void pjo_eval_jacob(const pjo_mech *m, double t, double pres, const double *y, d
                         lnF_AB * ((1.0 / log(10.0)) * B + (0.14 / log(10.0)) * A) *
                             (inf[1] + (inf[2] / T) - 1.0) / T;
             }
+            if (fl & F_SRI) {
+                /* write_sri / write_sri_dt, create_jacobian.py:1114-1132, 1194-1237 ('{:.16}' parameters) */
+                X = 1.0 / (1.0 + log10(fmax(Pr, 1.0e-300)) * log10(fmax(Pr, 1.0e-300)));
+                extra = X * (((Q[SR_AB16] / (T * T)) * exp(-Q[SR_B16] / T) - Q[SR_INVC16] * exp(T / -Q[SR_C16])) /
+                                 (Q[SR_A16] * exp(-Q[SR_B16] / T) + exp(T / -Q[SR_C16])) -
+                             X * 0.8685889638065035 * log10(fmax(Pr, 1.0e-300)) * (inf[1] + (inf[2] / T) - 1.0) *
+                                 log(Q[SR_A16] * exp(-Q[SR_B16] / T) + exp(T / -Q[SR_C16])) / T);
+                if (Q[SR_E16] != 0.0) extra += (Q[SR_E16] / T);
+            }
             /* get_pdep_dt, create_jacobian.py:1135-1191 (beta difference '%.4e') */
             double dpr = (inf[3] + (inf[2] / T) - 1.0) / (T * (1.0 + Pr));
             if (fl & F_HIGH) dpr = -Pr * dpr;
@@ -441,7 +542,17 @@ void pjo_eval_jacob(const pjo_mech *m, double t, double pres, const double *y, d
 
         int doT = 1;
         double el = 0.0;
-        if (fl & F_PLOG) {
+        if (fl & F_CHEB) {
+            /* write_cheb_rxn_dt, create_jacobian.py:1610-1684 */
+            const double *C = m->cheb + m->cheb_ptr[i];
+            el = cheb_ut(m, i, T, pres) * (C[CH_DFAC] / T) * R;
+            if (nu_r != 1.0) el += Rf * (1.0 - nu_r);
+            if (isrev) {
+                double db = 0.0;
+                for (int p = m->net_ptr[i]; p < m->net_ptr[i + 1]; ++p) db += m->net_nu[p] * dBdT[m->net_sp[p]];
+                el -= Rr * ((1.0 - nu_p) + (-T * db));
+            }
+        } else if (fl & F_PLOG) {
             /* write_plog_rxn_dt, create_jacobian.py:1687-1850 */
             int q0 = m->plog_ptr[i], q1 = m->plog_ptr[i + 1];
             const double *P = m->plog, *P4 = m->plog4;
@@ -538,6 +649,9 @@ void pjo_eval_jacob(const pjo_mech *m, double t, double pres, const double *y, d
                     x -= log(fmax(Fcent, 1.0e-300)) * 2.0 * A *
                          (B * (1.0 / log(10.0)) + A * (0.14 / log(10.0))) /
                          (B * B * B * (1.0 + A * A / (B * B)) * (1.0 + A * A / (B * B)));
+                else if (fl & F_SRI)      /* create_jacobian.py:173-179 ('{:.4}' parameters) */
+                    x -= X * X * 0.8685889638065035 * log10(fmax(Pr, 1.0e-300)) *
+                         log(Q[SR_A4] * exp(-Q[SR_B4] / T) + exp(T / -Q[SR_C4]));
                 pres_mod_temp = x * R;
             } else {
                 pres_mod_temp = R;
@@ -553,9 +667,10 @@ void pjo_eval_jacob(const pjo_mech *m, double t, double pres, const double *y, d
         if (pdep_has) {
             pres_mod_temp *= rate_const(inf[0], inf[1], inf[2], T, logT);
             if (fl & F_TROE) pres_mod_temp *= pow(Fcent, 1.0 / (1 + A * A / (B * B)));
+            else if (fl & F_SRI) pres_mod_temp *= sri_F(Q, T, X);      /* create_jacobian.py:249-266 */
             pres_mod_temp /= (1.0 + Pr);
         }
-        double kf = fwd_kf(m, i, T, logT, pres);
+        double kf = (fl & F_CHEB) ? cheb_kf(m, i, T, pres, 1) : fwd_kf(m, i, T, logT, pres);
         double kr = 0.0;
         if (isrev) kr = kf / eval_Kc(m, i, T, logT);
 

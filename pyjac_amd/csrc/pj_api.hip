@@ -226,7 +226,7 @@ struct pj_mech {
     DevMech M;
     bool on_device = false;
     int device = -1;
-    DevBuf<double> sp, rd, rtd, eff_am1, kcg, plog, net_nu, sp_nu;
+    DevBuf<double> sp, rd, rtd, eff_am1, kcg, plog, sri, cheb, net_nu, sp_nu;
     DevBuf<int32_t> ri, rti, eff_sp, net_sp, sp_ptr, sp_rxn, fin_tgt, fin_part, fin_cnt;
     DevBuf<uint32_t> sched, ecol;
     DevBuf<uint16_t> smap;
@@ -284,12 +284,13 @@ int ensure_device(pj_mech* m)
     HIPCHK(m->smap.upload(P.smap)); HIPCHK(m->ecol_ptr.upload(P.ecol_ptr)); HIPCHK(m->ecol.upload(P.ecol));
     HIPCHK(m->eff_sp.upload(P.eff_sp)); HIPCHK(m->eff_am1.upload(P.eff_am1));
     HIPCHK(m->kcg.upload(P.kcg)); HIPCHK(m->plog.upload(P.plog));
+    HIPCHK(m->sri.upload(P.sri)); HIPCHK(m->cheb.upload(P.cheb));
     HIPCHK(m->net_sp.upload(P.net_sp)); HIPCHK(m->net_nu.upload(P.net_nu));
     HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
     DevMech& M = m->M;
     M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.rti = m->rti.p; M.rtd = m->rtd.p; M.nrp = P.nrp;
     M.smap = m->smap.p; M.ecol_ptr = m->ecol_ptr.p; M.ecol = m->ecol.p; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
-    M.kcg = m->kcg.p; M.plog = m->plog.p; M.net_sp = m->net_sp.p; M.net_nu = m->net_nu.p;
+    M.kcg = m->kcg.p; M.plog = m->plog.p; M.sri = m->sri.p; M.cheb = m->cheb.p; M.net_sp = m->net_sp.p; M.net_nu = m->net_nu.p;
     M.sp_ptr = m->sp_ptr.p; M.sp_rxn = m->sp_rxn.p; M.sp_nu = m->sp_nu.p;
     m->on_device = true;
     return PJ_OK;
@@ -493,7 +494,7 @@ void pj_mech_destroy(pj_mech* m)
     if (!m) return;
     if (m->on_device) {
         m->sp.release(); m->rd.release(); m->rtd.release(); m->rti.release();
-        m->smap.release(); m->ecol_ptr.release(); m->ecol.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release();
+        m->smap.release(); m->ecol_ptr.release(); m->ecol.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release(); m->sri.release(); m->cheb.release();
         m->net_nu.release(); m->sp_nu.release(); m->sched.release(); m->ri.release(); m->eff_sp.release();
         m->fin_tgt.release(); m->fin_part.release(); m->fin_cnt.release();
         m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release();

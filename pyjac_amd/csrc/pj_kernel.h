@@ -50,6 +50,8 @@ struct DevMech {
     const double* eff_am1;
     const double* kcg;
     const double* plog;
+    const double* sri;         // SRI parameter rows (pj_tables.h: SRW)
+    const double* cheb;        // Chebyshev records
     const int32_t* net_sp;
     const double* net_nu;
     const int32_t* sp_ptr;
@@ -230,6 +232,58 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
                 lnk = k1 + (k2 - k1) * f;
                 dlnk = r1[3] + r1[4] * invT + ((r2[3] - r1[3]) + (r2[4] - r1[4]) * invT) * f;
             }
+        } else if (fl & F_CHEB) {
+            // rate_subs.py:149-251 ('{:.8e}' constants); create_jacobian.py:1532-1684 ('{:.16e}')
+            const double* C = M.cheb + RI_(RI_PLOG_PTR);
+            const int cn = RI_(RI_PLOG_CNT) >> 8, cm = RI_(RI_PLOG_CNT) & 255;
+            const double lg10p = L.logp * INV_LN10;
+            double dp[CHEB_MAXT];
+            {
+                const double Tred = (2.0 * invT - C[CH_TSUM8]) / C[CH_TSUB8];
+                const double Pred = (2.0 * lg10p - C[CH_PSUM8]) / C[CH_PSUB8];
+                const double* c = C + CH_COEF;
+                for (int a = 0; a < cn; ++a) {
+                    double acc = c[a * cm] + Pred * c[a * cm + 1];
+                    double t0 = 1.0, t1 = Pred;
+                    for (int j = 2; j < cm; ++j) {
+                        const double tn = 2.0 * Pred * t1 - t0;
+                        acc += c[a * cm + j] * tn;
+                        t0 = t1; t1 = tn;
+                    }
+                    dp[a] = acc;
+                }
+                double kl = dp[0] + Tred * dp[1];
+                double u0 = 1.0, u1 = Tred;
+                for (int a = 2; a < cn; ++a) {
+                    const double un = 2.0 * Tred * u1 - u0;
+                    kl += dp[a] * un;
+                    u0 = u1; u1 = un;
+                }
+                lnk = kl * LN10;
+            }
+            {
+                const double Tred = (2.0 * invT - C[CH_TSUM16]) / C[CH_TSUB16];
+                const double Pred = (2.0 * lg10p - C[CH_PSUM16]) / C[CH_PSUB16];
+                const double* c = C + CH_COEF + cn * cm;         // rows i = 1 .. cn-1 of i * c_ij
+                for (int a = 1; a < cn; ++a) {
+                    double acc = c[(a - 1) * cm] + Pred * c[(a - 1) * cm + 1];
+                    double t0 = 1.0, t1 = Pred;
+                    for (int j = 2; j < cm; ++j) {
+                        const double tn = 2.0 * Pred * t1 - t0;
+                        acc += c[(a - 1) * cm + j] * tn;
+                        t0 = t1; t1 = tn;
+                    }
+                    dp[a] = acc;
+                }
+                double U = dp[1] + 2.0 * Tred * dp[2];
+                double w0 = 1.0, w1 = 2.0 * Tred;
+                for (int a = 3; a < cn; ++a) {
+                    const double wn = 2.0 * Tred * w1 - w0;
+                    U += dp[a] * wn;
+                    w0 = w1; w1 = wn;
+                }
+                dlnk = U * C[CH_DFAC] * invT;
+            }
         } else {
             lnk = RD_(RD_LNA) + RD_(RD_B) * logT - RD_(RD_TA) * invT;
             dlnk = RD_(RD_B) + RD_(RD_TA) * invT;
@@ -310,6 +364,23 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
                     Xtroe = lnF_AB * (INV_LN10 * Bt + (0.14 * INV_LN10) * At);
                     extra = (iFc * iden - lnF_AB * (-(0.67 * INV_LN10) * Bt + (1.1762 * INV_LN10) * At) * iFc) * dF -
                             Xtroe * (RD_(RD_B0) + e0T - 1.0) * invT;
+                }
+                if (fl & F_SRI) {
+                    // rate_subs.py:1229-1256; create_jacobian.py:173-179, 249-266, 1194-1237: each emitter's
+                    // parameter digits (pj_tables.h: SRW)
+                    const double* Q = M.sri + RI_(RI_PLOG_PTR) * SRW;
+                    const double lgPr = log(fmax(Pr, 1.0e-300)) * INV_LN10;
+                    const double Xs = 1.0 / (1.0 + lgPr * lgPr);
+                    const double S6 = Q[SR_A6] * exp(-Q[SR_B6] * invT) + exp(-T / Q[SR_C6]);
+                    F = exp(Xs * log(S6));
+                    if (Q[SR_USE_DE] != 0.0) F *= Q[SR_D8] * exp(Q[SR_E6] * logT);
+                    const double S4 = Q[SR_A4] * exp(-Q[SR_B4] * invT) + exp(-T / Q[SR_C4]);
+                    const double C2 = 0.8685889638065035;        // '{:.16}'.format(2 / ln 10)
+                    Xtroe = Xs * Xs * C2 * lgPr * log(S4);
+                    const double eb = exp(-Q[SR_B16] * invT), ec = exp(-T / Q[SR_C16]);
+                    const double S16 = Q[SR_A16] * eb + ec;
+                    const double dS = (Q[SR_AB16] * invT * invT) * eb - Q[SR_INVC16] * ec;
+                    extra = Xs * (dS / S16 - Xs * C2 * lgPr * (RD_(RD_B0) + e0T - 1.0) * log(S16) * invT) + Q[SR_E16] * invT;
                 }
                 // get_pdep_dt (create_jacobian.py:1135-1191): beta difference as printed ('%.4e')
                 double dpr = (RD_(RD_B04) + e0T - 1.0) * invT * i1Pr;

@@ -29,6 +29,17 @@
 
 using namespace pj;
 
+// SRI falloff and Chebyshev rate expressions live in pj_rows_rate.inc / pj_kernel.h only: such mechanisms
+// are served by the row-block family (Evaluator.spec_kind) or the table-driven kernel
+constexpr bool lane_supported()
+{
+    for (int i = 0; i < pjs::NRXN; ++i)
+        if (pjs::RI[i][RI_FLAGS] & (F_SRI | F_CHEB)) return false;
+    return true;
+}
+static_assert(lane_supported(), "pj_lane.hip: SRI / Chebyshev reactions are not implemented here; build kind 'rblk'");
+
+
 namespace {
 
 constexpr double RU_ = 8314.4621;

@@ -16,8 +16,8 @@
 //                  (the d/dT column, finished here too) and the structurally non-zero S_kj of the
 //                  block's rows in registers with compile-time indices.  No loads in the steady
 //                  state: the Jacobian stores of block b drain while block b+1 is being computed.
-//   k_pre          the few reactions whose rate factor is expensive (falloff: Lindemann / Troe,
-//                  PLOG) are evaluated once per state and handed over: theta, c*k_f, rp, b_M, b_col --
+//   k_pre          the few reactions whose rate factor is expensive (falloff: Lindemann / Troe / SRI,
+//                  PLOG, Chebyshev) are evaluated once per state and handed over: theta, c*k_f, rp, b_M, b_col --
 //                  4-5 doubles for ~10 % of the reactions.  Their loads for block b+1 are issued
 //                  BEFORE the stores of block b.
 //   energy row     partial sums in registers (AGPRs), carried between the kernels of one library
@@ -142,7 +142,7 @@ constexpr int SUM_E = pjs::NSCQ + 3;            // energy-row partial sums, LAST
 constexpr int NSLOTS = pjs::NSCQ + 3 + (pjs::NSP - 1);
 
 // reactions evaluated once per state by k_pre and handed over
-constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG)) != 0; }
+constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG | F_CHEB)) != 0; }
 
 #define PJR_INL __attribute__((always_inline))
 template <int I0, class F, int... Is>

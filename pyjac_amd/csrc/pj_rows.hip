@@ -95,7 +95,7 @@ constexpr int S_TH = 0, S_KF = 1, S_KR = 2, S_RP = 3, S_BM = 4, S_BC = 5;
 constexpr int SUM_H = pjs::NSCR, SUM_SCP = pjs::NSCR + 1, SUM_SJT = pjs::NSCR + 2;
 
 // plain Arrhenius reaction: c = 1 and k_f = sgn * exp(ln A + b ln T - Ta / T) is a function of T alone
-constexpr bool kf_plain(int i) { return (pjs::RI[i][RI_FLAGS] & (F_THD | F_PDEP | F_PLOG)) == 0; }
+constexpr bool kf_plain(int i) { return (pjs::RI[i][RI_FLAGS] & (F_THD | F_PDEP | F_PLOG | F_CHEB)) == 0; }
 
 #define PJR_INL __attribute__((always_inline))
 #define PJR_SLOT(i_, c_) pjs::SCR[i_][c_]      // hand-over slots of pj_rows_rate.inc

@@ -22,7 +22,7 @@ int kind_rank(int fl)
     if ((fl & F_PDEP) && (fl & F_TROE)) return 0;
     if (fl & F_PDEP) return 1;
     if (fl & F_THD) return 2;
-    if (fl & F_PLOG) return 3;
+    if (fl & (F_PLOG | F_CHEB)) return 3;
     if (fl & F_REV) return 4;
     return 5;
 }
@@ -31,14 +31,14 @@ int kind_rank(int fl)
 // Structural validation of a table blob before anything indexes through it: a corrupt or truncated
 // .pjtab must be refused, not read out of bounds.  Array j of the blob extends to the start of array
 // j + 1 (pyjac_amd/tables.py writes them back to back).
-static bool validate_blob(const int32_t* I, long nI, const double*, long nD, std::string& err)
+static bool validate_blob(const int32_t* I, long nI, const double* D, long nD, std::string& err)
 {
     auto bad = [&](const char* what) { err = std::string("malformed mechanism table blob: ") + what; return false; };
     if (nI < HDR || I[0] != MAGIC || I[1] != 1 || I[12] != nI || I[13] != nD) return bad("header");
     const int nsp = I[2], nrxn = I[3];
     if (nsp < 1 || nsp > 4096 || nrxn < 0 || nrxn > 8191 || I[4] < 0 || I[4] > nrxn || I[5] < 0 || I[5] > nrxn)
         return bad("sizes");
-    constexpr int NIA = 15, NDA = 20;
+    constexpr int NIA = IA_COUNT, NDA = DA_COUNT;
     long ilen[NIA], dlen[NDA];
     for (int j = 0; j < NIA; ++j) {
         const long off = I[16 + j], nxt = j + 1 < NIA ? I[16 + j + 1] : nI;
@@ -54,15 +54,32 @@ static bool validate_blob(const int32_t* I, long nI, const double*, long nD, std
     // per-reaction arrays
     for (int j : {(int)IA_FLAGS, (int)IA_PDEP_SP, (int)IA_REV_IDX, (int)IA_PRES_IDX})
         if (ilen[j] < nrxn) return bad("per-reaction integer array too short");
-    for (int j : {(int)IA_REAC_PTR, (int)IA_PROD_PTR, (int)IA_NET_PTR, (int)IA_EFF_PTR, (int)IA_PLOG_PTR, (int)IA_KC_PTR})
+    for (int j : {(int)IA_REAC_PTR, (int)IA_PROD_PTR, (int)IA_NET_PTR, (int)IA_EFF_PTR, (int)IA_PLOG_PTR, (int)IA_KC_PTR,
+                  (int)IA_CHEB_PTR})
         if (ilen[j] < nrxn + 1) return bad("CSR pointer array too short");
     if (ilen[IA_SEEN] < nsp) return bad("species array too short");
     for (int j : {(int)DA_A, (int)DA_B, (int)DA_E, (int)DA_KCPREF})
         if (dlen[j] < nrxn) return bad("per-reaction real array too short");
     if (dlen[DA_MW] < nsp || dlen[DA_TMID] < nsp || dlen[DA_LO] < 7L * nsp || dlen[DA_HI] < 7L * nsp) return bad("species tables");
     if (dlen[DA_PD] < 3L * nrxn || dlen[DA_TROE] < 4L * nrxn || dlen[DA_SRI] < 5L * nrxn || dlen[DA_INFS] < 4L * nrxn ||
-        dlen[DA_TROE8] < 5L * nrxn)
+        dlen[DA_TROE8] < 5L * nrxn || dlen[DA_SRIQ] < (long)SRW * nrxn)
         return bad("falloff tables");
+    {
+        // Chebyshev records: CH_COEF + n*m + (n-1)*m doubles each, inside the array
+        const int32_t* cp = ia(IA_CHEB_PTR);
+        const int32_t* fl = ia(IA_FLAGS);
+        const double* ch = D + I[48 + DA_CHEB];
+        if (cp[0] != 0) return bad("Chebyshev pointer does not start at 0");
+        for (int i = 0; i < nrxn; ++i) {
+            if (cp[i + 1] < cp[i] || cp[i + 1] > dlen[DA_CHEB]) return bad("Chebyshev pointer");
+            if (!(fl[i] & F_CHEB)) continue;
+            if (cp[i + 1] - cp[i] < CH_COEF) return bad("Chebyshev record too short");
+            const double n = ch[cp[i] + CH_N], m = ch[cp[i] + CH_M];
+            if (!(n >= 3 && n <= CHEB_MAXT && m >= 2 && m <= CHEB_MAXP) || n != std::floor(n) || m != std::floor(m))
+                return bad("Chebyshev dimensions (3..12 x 2..12 supported)");
+            if (cp[i + 1] - cp[i] != CH_COEF + (long)(n * m) + (long)((n - 1) * m)) return bad("Chebyshev record size");
+        }
+    }
     // CSR lists: monotone pointers inside their payload arrays, species indices in range
     struct Csr { int ptr, sp, nu; long per; };
     const Csr lists[] = {{IA_REAC_PTR, IA_REAC_SP, DA_REAC_NU, 1}, {IA_PROD_PTR, IA_PROD_SP, DA_PROD_NU, 1},
@@ -127,7 +144,7 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
     // quirk: which reaction's d/dT survives in J_nplusone (create_jacobian.py:2786-2818)
     auto no_dt = [&](int i) {
         const int fl = flags[i];
-        if ((fl & F_REV) || (fl & F_PLOG)) return false;
+        if ((fl & F_REV) || (fl & (F_PLOG | F_CHEB))) return false;
         double nr = 0;
         for (int q = reac_ptr[i]; q < reac_ptr[i + 1]; ++q) nr += reac_nu[q];
         return std::fabs(b[i]) <= 1e-90 && std::fabs(E[i]) <= 1e-90 && nr == 1.0;
@@ -152,7 +169,6 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         int fl = flags[i];
         int32_t* ri = &p.ri[(size_t)d * RIW];
         double* rd = &p.rd[(size_t)d * RDW];
-        if (fl & F_SRI) { p.error = "SRI falloff is out of scope"; return false; }
 
         auto slots = [&](const int32_t* ptr, const int32_t* sp, const double* nu, int* out, double& total) {
             int n = 0;
@@ -210,7 +226,7 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
             if (Av < 0 && Ev == 0.0 && bv != 0.0 && bv == std::floor(bv) && bv < 0) *bb = 0.0;
             return true;
         };
-        if (!(fl & F_PLOG)) {
+        if (!(fl & (F_PLOG | F_CHEB))) {
             if (!set_rate(A[i], b[i], E[i], &rd[RD_LNA], &rd[RD_B], &rd[RD_TA], &rd[RD_SGN])) {
                 p.error = "reaction with A == 0"; return false;
             }
@@ -241,6 +257,20 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
             }
         }
         ri[RI_PLOG_CNT] = (int)(p.plog.size() / PLW) - ri[RI_PLOG_PTR];
+        if (fl & F_CHEB) {
+            // Chebyshev record, copied as is (RI_PLOG_PTR / RI_PLOG_CNT are free: never PLOG as well)
+            const int32_t* cp = B.ia(IA_CHEB_PTR);
+            const double* ch = B.da(DA_CHEB);
+            ri[RI_PLOG_PTR] = (int)p.cheb.size();
+            ri[RI_PLOG_CNT] = (int)ch[cp[i] + CH_N] * 256 + (int)ch[cp[i] + CH_M];
+            p.cheb.insert(p.cheb.end(), ch + cp[i], ch + cp[i + 1]);
+        }
+        if (fl & F_SRI) {
+            if (!(fl & F_PDEP) || (fl & F_TROE)) { p.error = "SRI parameters on a reaction that is not a plain falloff"; return false; }
+            ri[RI_PLOG_PTR] = (int)(p.sri.size() / SRW);
+            const double* sq = B.da(DA_SRIQ) + (size_t)SRW * i;
+            p.sri.insert(p.sri.end(), sq, sq + SRW);
+        }
 
         if (fl & F_PDEP) {
             const double* in = infs + 4 * (size_t)i;
@@ -529,6 +559,8 @@ uint64_t programs_hash(const Programs& p)
     mix(p.sp.data(), p.sp.size() * 8); mix(p.ri.data(), p.ri.size() * 4); mix(p.rd.data(), p.rd.size() * 8);
     mix(p.eff_sp.data(), p.eff_sp.size() * 4); mix(p.eff_am1.data(), p.eff_am1.size() * 8);
     mix(p.kcg.data(), p.kcg.size() * 8); mix(p.plog.data(), p.plog.size() * 8);
+    if (!p.sri.empty()) mix(p.sri.data(), p.sri.size() * 8);        // (hashes of mechanisms without them unchanged)
+    if (!p.cheb.empty()) mix(p.cheb.data(), p.cheb.size() * 8);
     mix(p.net_sp.data(), p.net_sp.size() * 4); mix(p.net_nu.data(), p.net_nu.size() * 8);
     mix(p.prog.data(), p.prog.size() * 4);
     return h;
@@ -580,6 +612,8 @@ std::string emit_spec_header(const Programs& p)
     arr_d("EFF_AM1", p.eff_am1, 1);
     arr_d("KCG", p.kcg, KCW);
     arr_d("PLOG", p.plog, PLW);
+    arr_d("SRI", p.sri, SRW);
+    arr_d("CHEB", p.cheb, 1);
     arr_i("NET_SP", p.net_sp, 1);
     arr_d("NET_NU", p.net_nu, 1);
     arr_i("SIDX", sidx, nsp);
@@ -728,7 +762,7 @@ std::string emit_rows_tables(const Programs& p, int budget)
         // load issued at the top of a block sits behind the previous block's Jacobian stores
         for (int pass = 0; pass < 2; ++pass)
             for (int i = 0; i < nrxn; ++i)
-                if (blk_rx[b][i] && ((p.ri[(size_t)i * RIW + RI_FLAGS] & (F_PDEP | F_PLOG)) != 0) == (pass == 1))
+                if (blk_rx[b][i] && ((p.ri[(size_t)i * RIW + RI_FLAGS] & (F_PDEP | F_PLOG | F_CHEB)) != 0) == (pass == 1))
                     brx.push_back(i);
         brx_ptr.push_back((int32_t)brx.size());
         maxrows = std::max(maxrows, loc);
@@ -753,7 +787,7 @@ std::string emit_rows_tables(const Programs& p, int budget)
     int nscq = 0, npre = 0;
     for (int i = 0; i < nrxn; ++i) {
         const int fl = p.ri[(size_t)i * RIW + RI_FLAGS];
-        if (!(fl & (F_PDEP | F_PLOG))) continue;
+        if (!(fl & (F_PDEP | F_PLOG | F_CHEB))) continue;
         ++npre;
         scq[(size_t)i * 6 + 0] = nscq++;
         scq[(size_t)i * 6 + 1] = nscq++;

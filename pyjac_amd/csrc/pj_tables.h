@@ -21,13 +21,14 @@ enum { F_REV = 1, F_THD = 2, F_PDEP = 4, F_LOW = 8, F_HIGH = 16, F_TROE = 32,
        F_NO_DT = 2048,     // reference emits no d/dT line (create_jacobian.py:1512-1529)
        F_EFFTYPE = 4096,   // [M] carries enhanced efficiencies -> b_i acts on every column
        F_COLLIDER = 8192,  // falloff with a specific collider species
-       F_LASTQ = 16384 };  // the one reaction whose d/dT survives in J_nplusone (quirk)
+       F_LASTQ = 16384,    // the one reaction whose d/dT survives in J_nplusone (quirk)
+       F_CHEB = 32768 };   // blob flag again: Chebyshev rate expression (rate_subs.py:149-251)
 enum { IA_FLAGS, IA_REAC_PTR, IA_REAC_SP, IA_PROD_PTR, IA_PROD_SP, IA_NET_PTR,
        IA_NET_SP, IA_EFF_PTR, IA_EFF_SP, IA_PLOG_PTR, IA_KC_PTR, IA_PDEP_SP,
-       IA_REV_IDX, IA_PRES_IDX, IA_SEEN };
+       IA_REV_IDX, IA_PRES_IDX, IA_SEEN, IA_CHEB_PTR, IA_COUNT };
 enum { DA_MW, DA_TMID, DA_LO, DA_HI, DA_A, DA_B, DA_E, DA_REAC_NU, DA_PROD_NU,
        DA_NET_NU, DA_EFF, DA_PD, DA_TROE, DA_SRI, DA_PLOG, DA_KCG, DA_KCPREF,
-       DA_INFS, DA_TROE8, DA_PLOG4 };
+       DA_INFS, DA_TROE8, DA_PLOG4, DA_SRIQ, DA_CHEB, DA_COUNT };
 
 // ---- record widths ----
 constexpr int SPW = 18;   // species: invW, W, tmid, w=W/W_N, lo[7], hi[7]
@@ -41,6 +42,21 @@ enum { RD_LNA, RD_B, RD_TA, RD_SGN, RD_NR, RD_NP, RD_LNPREF, RD_LNAR, RD_B0, RD_
 constexpr int EFF_INL = 8;  // enhanced colliders held inline in the field-major tables
 constexpr int PLW = 5;    // plog row: P ('%.4e'), lnP, lnA, b, Ta
 constexpr int KCW = 15;   // kc group: tmid, lo[7], hi[7]
+// SRI falloff (F_SRI): RI_PLOG_PTR = row of the SRI table.  The reference prints the parameters
+// a, b, c, d, e with a different number of digits in each emitter; the table carries each variant:
+//   '{:.6}' (d: '{:.8e}')  get_rxn_pres_mod and the F_i factor    rate_subs.py:1229-1256, create_jacobian.py:249-266
+//   '{:.4}'                the dPr/dY_j term                       create_jacobian.py:173-179
+//   '{:.16}'               the d/dT term                           create_jacobian.py:1194-1237
+constexpr int SRW = 16;
+enum { SR_A6, SR_B6, SR_C6, SR_D8, SR_E6, SR_USE_DE, SR_A4, SR_B4, SR_C4, SR_A16, SR_B16, SR_C16, SR_AB16,
+       SR_INVC16, SR_E16 };
+// Chebyshev (F_CHEB): RI_PLOG_PTR = offset of the reaction's record in the Chebyshev array, RI_PLOG_CNT =
+// n_temp * 256 + n_pres.  Record: n_temp, n_pres, the reduced-variable constants as the rate emitter
+// prints them ('{:.8e}': 1/Tmin+1/Tmax, 1/Tmax-1/Tmin, lg Pmin+lg Pmax, lg Pmax-lg Pmin) and as the
+// Jacobian emitter does ('{:.16e}'), -2 ln10 / (1/Tmax - 1/Tmin), the n x m coefficients ('{:.8e}'),
+// then (n-1) x m coefficients i * c_ij ('{:.16e}') of the d/dT sum.
+enum { CH_N, CH_M, CH_TSUM8, CH_TSUB8, CH_PSUM8, CH_PSUB8, CH_TSUM16, CH_TSUB16, CH_PSUM16, CH_PSUB16, CH_DFAC, CH_COEF };
+constexpr int CHEB_MAXT = 12, CHEB_MAXP = 12;
 
 // V-array slot map (per-state working set, doubles)
 struct VMap {
@@ -89,6 +105,8 @@ struct Programs {
     std::vector<double> eff_am1;   // alpha - 1
     std::vector<double> kcg;       // [n*KCW]
     std::vector<double> plog;      // [n*PLW]
+    std::vector<double> sri;       // [n*SRW]
+    std::vector<double> cheb;      // Chebyshev records, back to back
     std::vector<int32_t> net_sp;   // per-reaction net list
     std::vector<double> net_nu;
     // P3: per species gather over reactions (global copy: k_spec_rates)

@@ -60,7 +60,12 @@ class Evaluator:
 
     def spec_kind(self) -> str:
         """Which specialised kernel family specialize(build=True) compiles for this mechanism."""
-        return 'lane' if self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN else 'rblk'
+        from .tables import F_CHEB, F_SRI, IA_FLAGS
+        I = self.tables.I
+        flags = I[I[16 + IA_FLAGS]:I[16 + IA_FLAGS] + self.n_fwd]
+        # (pj_lane.hip carries no SRI / Chebyshev code: those mechanisms take the row-block family at any size)
+        small = self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN
+        return 'lane' if small and not any(int(f) & (F_SRI | F_CHEB) for f in flags) else 'rblk'
 
     _SPEC_STEM = {'lane': 'libpj_spec_%016x.so', 'rows': 'libpj_rows_%016x.so', 'fused': 'libpj_fused_%016x.so',
                   'rblk': 'libpj_rblk_%016x.so'}

@@ -16,6 +16,7 @@ MECHS = {
     'gri30_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'gri30_shaped.inp'),
     'usc2_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'),
     'synth_mid24': os.path.join(GOLDEN, 'synth_mid24.inp'),     # 24 sp / 96 rxn incl. Troe, PLOG
+    'synth_srichb': os.path.join(GOLDEN, 'synth_srichb.inp'),   # SRI falloff (3 / 5 parameters) + Chebyshev
 }
 
 

@@ -54,7 +54,7 @@ extern "C" int emu_run(const int32_t* I, long nI, const double* D, long nD, long
     M.rti = P.rti.data(); M.rtd = P.rtd.data(); M.nrp = P.nrp;
     M.smap = P.smap.data(); M.ecol_ptr = P.ecol_ptr.data(); M.ecol = P.ecol.data();
     M.eff_sp = P.eff_sp.data(); M.eff_am1 = P.eff_am1.data(); M.kcg = P.kcg.data();
-    M.plog = P.plog.data(); M.net_sp = P.net_sp.data(); M.net_nu = P.net_nu.data();
+    M.plog = P.plog.data(); M.sri = P.sri.data(); M.cheb = P.cheb.data(); M.net_sp = P.net_sp.data(); M.net_nu = P.net_nu.data();
     M.sp_ptr = P.sp_ptr.data(); M.sp_rxn = P.sp_rxn.data(); M.sp_nu = P.sp_nu.data();
     Schedule S;
     if (!build_schedule(P, NT / 64, 64 / TS, S)) return -3;

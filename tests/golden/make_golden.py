@@ -28,6 +28,7 @@ CASES = {
     'gri30_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'gri30_shaped.inp'),
     'usc2_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'),
     'synth_mid24': os.path.join(HERE, 'synth_mid24.inp'),
+    'synth_srichb': os.path.join(HERE, 'synth_srichb.inp'),     # SRI falloff + Chebyshev rate forms
 }
 
 

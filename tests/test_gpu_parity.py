@@ -50,7 +50,7 @@ def _batch_api(ev, pres, y_soa):
     return {k: v.reshape(-1, n).T for k, v in out.items()}
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'synth_srichb'])
 def test_batch_api_matches_reference_golden(name, golden, tables, torch_cuda):
     g = golden(name)
     ev = _ev(name)
@@ -710,3 +710,51 @@ def test_table_file_through_c_abi_only(tmp_path, tables, torch_cuda):
     h2 = ctypes.c_void_p()
     assert L.pj_mech_load(bad.encode(), ctypes.byref(h2)) != 0
     L.pj_mech_destroy(h)
+
+
+@pytest.mark.parametrize('path', ['k_eval', 'rblk'])
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_sri_and_chebyshev_rate_forms(path, layout, tables, golden, torch_cuda):
+    """N4: SRI falloff (3 and 5 parameters, LOW and HIGH, with efficiencies and with a collider species) and
+    Chebyshev rate expressions (reversible and not), through the table-driven kernel and through the
+    row-block family (where the pre-pass evaluates them), against the oracle on random states and against
+    vectors from pyJac's generated C: Jacobian and every rate output."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    name = 'synth_srichb'
+    ev = _ev(name)
+    assert ev.spec_kernel == 'pj_rblk'
+    ev.use_spec(2 if path == 'rblk' else 0)
+    n = 1029
+    pres, y = synth.dist_b(n, ev.nsp, seed=31, Tlo=400, Thi=2800)
+    pres = 101325 * 10 ** np.random.default_rng(8).uniform(-1.5, 1.5, n)
+    g = golden(name)
+    pres = np.concatenate([pres, g['pres']])
+    y = np.concatenate([y, g['y'].T], axis=1)
+    n = pres.size
+    d_p = torch.from_numpy(pres).cuda()
+    if layout == 'soa':
+        d_y, L = torch.from_numpy(np.ascontiguousarray(y)).cuda(), pyjac_amd.LAYOUT_SOA
+    else:
+        d_y, L = torch.from_numpy(np.ascontiguousarray(y.T)).cuda(), pyjac_amd.LAYOUT_AOS
+    jac = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+    jac = jac.T if layout == 'soa' else jac
+    o = Oracle(tables(name))
+    y_aos = np.ascontiguousarray(y.T)
+    ref = o.batch_jacob(pres, y_aos)
+    mx, fro = thresholded_rel_err(jac, ref)
+    assert np.isfinite(jac).all() and mx < RTOL and fro < 1e-9, (path, layout, mx, fro)
+    ng = g['pres'].size
+    mx, fro = thresholded_rel_err(jac[-ng:], g['jac'])
+    assert mx < RTOL and fro < 1e-9, ('vs pyJac generated C', mx, fro)
+    r = {k: v.cpu().numpy().T for k, v in ev.rates(d_p, d_y, y_layout=L).items()}
+    e = [o.eval_all(float(pres[s]), y_aos[s]) for s in range(n)]
+    ref = {k: np.array([x[k] for x in e]) for k in ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt')}
+    for k, rows in (('conc', ev.nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
+        mx, _ = thresholded_rel_err(r[k][:, :rows], ref[k][:, :rows])
+        assert mx < 1e-9, (path, k, mx)
+    gross, sdy = rate_scales(tables(name), pres, y_aos, ref['conc'], ref['fwd'], ref['rev'], ref['pres_mod'])
+    assert mixed_err(r['spec_rates'], ref['spec_rates'], gross[:, None]) <= 1.0
+    assert mixed_err(r['dydt'], ref['dydt'], sdy) <= 1.0

@@ -57,6 +57,7 @@ def test_tables_roundtrip(tmp_path, tables):
 def test_cabi_exports_every_declared_symbol():
     from pyjac_amd import _lib
     hdr = open(os.path.join(ROOT, 'include', 'pyjac_amd.h')).read()
+    hdr = re.sub(r'#ifdef PJ_TIMING.*?#endif', '', hdr, flags=re.S)      # debug-build-only declarations
     declared = set(re.findall(r'\b(pj_[a-z_0-9]+)\s*\(', hdr))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.lib()
@@ -121,7 +122,8 @@ def _run_emu(tab, pres, y_soa, TS, NT, aos):
 @pytest.mark.parametrize('name,TS,NT,aos', [('h2o2_n2', 64, 256, False), ('h2o2', 16, 256, False),
                                             ('synth_alltypes', 4, 128, True),
                                             ('synth_alltypes', 64, 64, False),
-                                            ('synth_alltypes', 1, 64, True)])
+                                            ('synth_alltypes', 1, 64, True),
+                                            ('synth_srichb', 16, 256, False), ('synth_srichb', 1, 64, True)])
 def test_kernel_phases_match_oracle(name, TS, NT, aos, tables):
     tab = tables(name)
     o = Oracle(tab)
@@ -132,7 +134,11 @@ def test_kernel_phases_match_oracle(name, TS, NT, aos, tables):
     ref_j = o.batch_jacob(pres, np.ascontiguousarray(y.T))
     got_j = out['jac'].reshape(n, -1) if aos else out['jac'].reshape(-1, n).T
     mx, fro = thresholded_rel_err(got_j, ref_j)
-    assert mx < 1e-8 and fro < 1e-12, (mx, fro)
+    # Chebyshev reactions: the reference's eval_jacob re-evaluates k_f for the dR/dY_j terms with reduced
+    # variables printed at 16 digits while the rates use 8 (create_jacobian.py:1647-1664 vs
+    # rate_subs.py:176-193); the oracle reproduces both, the kernels use the rate's k_f throughout
+    # (<= 1e-7 relative on those entries, inside the 1e-6 tolerance)
+    assert mx < (1e-8 if name != 'synth_srichb' else 1e-6) and fro < (1e-12 if name != 'synth_srichb' else 1e-9), (mx, fro)
     ref_d = o.batch_dydt(pres, np.ascontiguousarray(y.T))
     mx, _ = thresholded_rel_err(out['dydt'].reshape(-1, n).T, ref_d)
     assert mx < 1e-10

@@ -10,7 +10,8 @@ from oracle.oracle import Oracle, Reference
 KEYS = ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24',
+                                  'synth_srichb'])
 def test_oracle_matches_reference_golden(name, golden, tables):
     g = golden(name)
     tab = tables(name)
@@ -39,7 +40,7 @@ def test_oracle_writes_full_jacobian_block(tables):
     assert np.isfinite(jac).all()
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24', 'synth_srichb'])
 def test_oracle_matches_reference_live(name, tables):
     if not Reference.available(name):
         pytest.skip('oracle/_ref not built (no /root/reference here)')
@@ -80,7 +81,7 @@ def test_jacobian_consistent_with_finite_differences(tables):
         assert np.abs(fd[1:] - jac[1:, j]).max() < 1e-5 * scale
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes', 'synth_srichb'])
 def test_fd_arm_oracle_pinned_to_reference(name, tables):
     """N3 pin: the restated finite-difference Jacobian (pyjac/performance_tester/fd_jacob.c:10-113)
     is bit-identical to the reference's own fd_jacob.c compiled into oracle/_ref."""

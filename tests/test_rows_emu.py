@@ -61,6 +61,7 @@ def _run(L, nsp, pres, y_soa, sum_last=0, aos=False):
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJR_RECOMPUTE_KR=1',))),
     ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7,
                                 defines=('-DPJR_RECOMPUTE_KR=1', '-DPJR_RECOMPUTE_KF=1', '-DPJR_DUMMY=1'))),
+    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
 ])
 def test_rows_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     from oracle.oracle import Oracle
@@ -85,6 +86,7 @@ def test_rows_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
 @pytest.mark.parametrize('name,budget,kw', [
     ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
 ])
 def test_rows_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     """k_rates<true> + k_dy (pj_spec_rates of the row-block library): conc, fwd, rev, pres_mod,
@@ -199,6 +201,8 @@ def _rblk_emu_lib(name, budget, tmp, **kw):
     ('h2o2_n2', 12, dict(blocks_per_part=100, rates_per_part=5)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_DEPTH=1',))),
+    # SRI falloff (3 / 5 parameters, LOW / HIGH, collider) and Chebyshev reactions: evaluated by the pre-pass
+    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
 ])
 def test_rblk_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     """Row blocks that rebuild their rates (Arrhenius, K_c, third body, theta per visit), the falloff /
