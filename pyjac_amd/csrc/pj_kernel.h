@@ -213,6 +213,7 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
 
         // ---- forward rate constant and T d(ln kf)/dT ----
         double lnk, dlnk;
+        double kf_jac_ratio = 1.0;     // Chebyshev only: (k_f of eval_jacob's dR/dY_j terms) / (k_f of the rates)
         if (fl & F_PLOG) {
             // rate_subs.py:598-632; create_jacobian.py:1687-1850
             const double* P = M.plog + RI_(RI_PLOG_PTR) * PLW;
@@ -264,6 +265,25 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
             {
                 const double Tred = (2.0 * invT - C[CH_TSUM16]) / C[CH_TSUB16];
                 const double Pred = (2.0 * lg10p - C[CH_PSUM16]) / C[CH_PSUB16];
+                {
+                    // eval_jacob's own k_f for the dR/dY_j terms: the rate's coefficients with THESE reduced
+                    // variables (get_cheb_rate(write_defns=False), create_jacobian.py:1647-1664)
+                    const double* c8 = C + CH_COEF;
+                    double kl = 0.0, u0 = 1.0, u1 = Tred;
+                    for (int a = 0; a < cn; ++a) {
+                        double acc = c8[a * cm] + Pred * c8[a * cm + 1];
+                        double t0 = 1.0, t1 = Pred;
+                        for (int j = 2; j < cm; ++j) {
+                            const double tn = 2.0 * Pred * t1 - t0;
+                            acc += c8[a * cm + j] * tn;
+                            t0 = t1; t1 = tn;
+                        }
+                        if (a == 0) kl = acc;
+                        else if (a == 1) kl += Tred * acc;
+                        else { const double un = 2.0 * Tred * u1 - u0; kl += acc * un; u0 = u1; u1 = un; }
+                    }
+                    kf_jac_ratio = exp(kl * LN10 - lnk);
+                }
                 const double* c = C + CH_COEF + cn * cm;         // rows i = 1 .. cn-1 of i * c_ij
                 for (int a = 1; a < cn; ++a) {
                     double acc = c[(a - 1) * cm] + Pred * c[(a - 1) * cm + 1];
@@ -407,7 +427,7 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         const double a = c * (nr * Rf - ((fl & F_REV) ? np_ * Rr : 0.0)) + a_extra;
 
         // ---- sparse column values g (one per molecule slot) ----
-        const double ckf = c * kf, ckr = c * kr;
+        const double ckf = c * kf * kf_jac_ratio, ckr = c * kr * kf_jac_ratio;
         int g = M.v.G + RI_(RI_GBASE);
         double gN = bM * RD_(RD_ANM1);
         #define PJ_GSLOT(spidx, val)                                        \

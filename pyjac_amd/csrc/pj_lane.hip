@@ -59,6 +59,11 @@ __device__ __forceinline__ void static_for_impl(F&& f)
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
 
+#include "pj_math.h"
+
+template <int J>
+constexpr std::integral_constant<int, J + 1> jc_plus1(std::integral_constant<int, J>) { return {}; }
+
 // does reaction i feed the last species' column (g_N != 0)?
 constexpr bool has_gn(int i)
 {
@@ -104,6 +109,7 @@ struct Args {
 // (conc, fwd, rev, pres_mod, spec_rates, dy of pyjacob.cu's k_dydt pass -- the Jacobian
 // accumulations are dead code there and the compiler drops them)
 // ST (Jacobian store path, MODE 0): 0 strided plain stores, 1 lane-contiguous SoA (nontemporal),
+// 3 the same as pair stores (two rows per 16-byte store, whole wavefronts only: see emit_col),
 // 2 AoS (state-major NSP x NSP blocks, pyJac's per-state C layout) through a per-wavefront LDS
 // transpose: a wavefront's 64 blocks are one contiguous region of memory, written in runs of whole
 // columns instead of 8-byte stores that are NSP^2 doubles apart
@@ -111,7 +117,7 @@ template <int MODE, int ST>
 __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
 {
     constexpr bool JV = MODE == 1;
-    constexpr bool NT = ST == 1;
+    constexpr bool NT = ST == 1 || ST == 3;
     // AoS transpose tile: CC whole columns per flush, row stride padded to an odd number of doubles
     constexpr int CC = (48 / NSP) > 0 ? (48 / NSP) : 1, TW = CC * NSP, TWP = TW | 1;
     __shared__ double TL[(PJL_BLOCK + 63) / 64][ST == 2 ? 64 : 1][TWP];   // 1.3 KB placeholder when unused
@@ -131,6 +137,24 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     __syncthreads();
   // ST == 2: the trip count is workgroup-uniform (every lane takes part in the transpose; lanes past
   // the end repeat the last state); otherwise a lane simply stops at the end of the batch
+  // The state of the NEXT grid-stride iteration is requested at the top of the current one: at one
+  // wavefront per SIMD nothing else covers the loaded memory latency (several microseconds behind other
+  // wavefronts' Jacobian stores), and these loads sit in front of this iteration's stores in the
+  // in-order vmcnt queue.
+#define PJL_INL __attribute__((always_inline))
+  double nxT = 0.0, nxP = 0.0, nxY[LAST > 0 ? LAST : 1];
+  auto fetch_state = [&](const long sl_) PJL_INL {
+      const bool in = (ST == 2 ? sl_ - threadIdx.x : sl_) < A.n;
+      if (in) {
+          const long s_ = (ST == 2 && sl_ >= A.n) ? A.n - 1 : sl_;
+          const double* y_ = A.y + s_ * A.y_ss;
+          nxT = y_[0];
+          nxP = A.pres[s_];
+#pragma unroll
+          for (int k = 0; k < LAST; ++k) nxY[k] = y_[(k + 1) * A.y_si];
+      }
+  };
+  fetch_state(A.s0 + (long)blockIdx.x * PJL_BLOCK + threadIdx.x);
   for (long sl = A.s0 + (long)blockIdx.x * PJL_BLOCK + threadIdx.x; (ST == 2 ? sl - threadIdx.x : sl) < A.n;
        sl += (long)gridDim.x * PJL_BLOCK) {
     const long tb = sl - threadIdx.x;
@@ -146,9 +170,8 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     const double (*RDT)[RDW] = (const double (*)[RDW])((const char*)RDL + zoff);
     const double (*EFFT)[1] = (const double (*)[1])((const char*)EFL + zoff);
     const double (*SPT)[4] = (const double (*)[4])((const char*)SPL + zoff);
-    const double* y = A.y + s * A.y_ss;
-    const double T = y[0];
-    const double p = A.pres[s];
+    const double T = nxT;
+    const double p = nxP;
     const double logT = log(T), invT = 1.0 / T, logp = log(p);
 
     // ---- eval_conc + NASA properties ----
@@ -156,10 +179,11 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     double sumY = 0.0, sumYW = 0.0;
 #pragma unroll
     for (int k = 0; k < LAST; ++k) {
-        C[k] = y[(k + 1) * A.y_si];
+        C[k] = nxY[k];
         sumY += C[k];
         sumYW += C[k] * SPT[k][0];
     }
+    fetch_state(sl + (long)gridDim.x * PJL_BLOCK);
     const double yN = 1.0 - sumY;
     C[LAST] = yN;
     sumYW += yN * SPT[LAST][0];
@@ -190,7 +214,6 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     for (int e = 0; e < pjs::NNZ; ++e) S[e] = 0.0;
 
     // ---- reactions: compile-time loop, every table read is a constant expression ----
-#define PJL_INL __attribute__((always_inline))
     static_for<NRXN>([&](auto ic) PJL_INL {
         constexpr int i = decltype(ic)::value;
         constexpr int fl = pjs::RI[i][RI_FLAGS];
@@ -225,9 +248,9 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             lnk = RDT[i][RD_LNA] + RDT[i][RD_B] * logT - RDT[i][RD_TA] * invT;
             dlnk = RDT[i][RD_B] + RDT[i][RD_TA] * invT;
         }
-        const double kf = (pjs::RD[i][RD_SGN] < 0.0) ? -exp(lnk) : exp(lnk);
-
-        double kr = 0.0, TdlnKc = 0.0;
+        // k_f and, where this reaction is the first of its K_c class, exp(-ln K_c): side by side
+        // (pj_math.h: two independent Horner chains fill each other's pipeline latency)
+        double kf, kr = 0.0, TdlnKc = 0.0;
         if constexpr ((fl & F_REV) != 0) {
             constexpr int kcls = pjs::KC_CLASS[i][0];
             if constexpr (pjs::KC_FIRST[i][0] != 0) {
@@ -238,11 +261,17 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
                     lnKc += a[0] + a[1] * logT + T * (a[2] + T * (a[3] + T * (a[4] + a[5] * T))) - a[6] * invT;
                     td += a[1] + T * (a[2] + T * (2.0 * a[3] + T * (3.0 * a[4] + 4.0 * a[5] * T))) + a[6] * invT;
                 });
-                ekc[kcls] = exp(-lnKc);
+                exp_pair(lnk, -lnKc, kf, ekc[kcls]);
                 tdk[kcls] = td;
+            } else {
+                kf = exp_one(lnk);
             }
+            if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
             kr = kf * ekc[kcls];
             TdlnKc = tdk[kcls];
+        } else {
+            kf = exp_one(lnk);
+            if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
         }
 
         const double cr0 = C[pjs::RI[i][RI_R0]], cr1 = C[pjs::RI[i][RI_R1]], cr2 = C[pjs::RI[i][RI_R2]];
@@ -431,32 +460,97 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             __builtin_amdgcn_wave_barrier();
         }
     };
-// e = row + NSP * col, compile-time wherever this is used
-#define JST(e, val) do { if constexpr (JV) ww[(e) % NSP] += (val) * vv[(e) / NSP]; else JMEM(e, val); } while (0)
+    // SoA output from whole wavefronts goes out as PAIR stores (ST == 3): the lanes of an (even, odd) pair
+    // swap one value per two rows, then the even lane writes both states of row r1, the odd lane both
+    // states of row r2 > r1 -- 16 bytes per lane, half the store instructions in flight (a wavefront may
+    // have 64 outstanding; the store phase is bound by that window, profiles/r02_micro_burst_bw.txt).
+    // Rows are paired as they are produced: (1,2), (3,4), ... and the energy row 0, which needs the
+    // whole column, with the last species row.
+    [[maybe_unused]] const unsigned jlo = (unsigned)(threadIdx.x & 63) * 8u;
+    [[maybe_unused]] const bool odd = (threadIdx.x & 1) != 0;
+    // wavefront base: a scalar, so that a store is "SGPR base + 32-bit lane offset" with no 64-bit vector
+    // address arithmetic; the strides are laundered per state (the optimiser would hoist every entry
+    // offset e * j_si out of the persistent loop as an SGPR pair and spill them)
+    [[maybe_unused]] double* Jw = nullptr;
+    [[maybe_unused]] long jsi = A.j_si;
+#ifndef PJL_HOST_EMU
+    if constexpr (ST == 3 && !JV) {
+        const long sw = sl - (threadIdx.x & 63);
+        const long swu = ((long)__builtin_amdgcn_readfirstlane((int)((unsigned long)sw >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sw);
+        Jw = A.jac + (swu - A.s0) * A.j_ss;
+        asm volatile("" : "+s"(jsi));
+    }
+#endif
+    auto pair_store = [&](auto e1c, const double v1, auto e2c, const double v2) PJL_INL {
+#ifndef PJL_HOST_EMU
+        constexpr int e1 = decltype(e1c)::value, e2 = decltype(e2c)::value;
+        static_assert(e2 > e1, "pair stores: second entry above the first");
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const double give = odd ? v1 : v2;
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, give);
+        const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+        const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0xB1, 0xF, 0xF, true);
+        const double recv = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+        d2v out;
+        out.x = odd ? recv : v1;
+        out.y = odd ? v2 : recv;
+        const unsigned off = odd ? jlo - 8u + (unsigned)(e2 - e1) * ((unsigned)jsi * 8u) : jlo;
+        __builtin_nontemporal_store(out, (d2v*)((char*)(Jw + (long)e1 * jsi) + off));
+#endif
+    };
+    auto single_store = [&](auto ec, const double v) PJL_INL {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (JV) ww[e % NSP] += v * vv[e / NSP];
+        else JMEM(e, v);
+    };
+#define PJL_E(e_) std::integral_constant<int, (e_)>{}
     const double icp = 1.0 / cpavg;
-    JST(0, -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg));
-    static_for<LAST>([&](auto kc) PJL_INL {
-        constexpr int k = decltype(kc)::value;
-        JST(k + 1, SPT[k][1] * jt[k]);
-    });
-    flush(std::integral_constant<int, 0>{});
+    // one column: val(k) -> row k + 1 for k = 0 .. LAST-1 (called in order), then row 0
+    auto column = [&](auto colc, auto&& val, auto&& row0) PJL_INL {
+        constexpr int col = decltype(colc)::value;
+        if constexpr (ST == 3 && !JV) {
+            double held = 0.0;      // odd-numbered species row waiting for its partner
+            static_for<LAST>([&](auto kc) PJL_INL {
+                constexpr int k = decltype(kc)::value;
+                const double v = val(kc);
+                if constexpr (k % 2 == 0) held = v;
+                else pair_store(PJL_E(k + NSP * col), held, PJL_E(k + 1 + NSP * col), v);
+            });
+            const double v0 = row0();
+            if constexpr (LAST % 2 == 1) pair_store(PJL_E(NSP * col), v0, PJL_E(LAST + NSP * col), held);
+            else __builtin_nontemporal_store(v0, (double*)((char*)(Jw + (long)(NSP * col) * jsi) + jlo));
+        } else {
+            static_for<LAST>([&](auto kc) PJL_INL {
+                constexpr int k = decltype(kc)::value;
+                single_store(PJL_E(k + 1 + NSP * col), val(kc));
+            });
+            single_store(PJL_E(NSP * col), row0());
+        }
+        flush(colc);
+    };
+    column(PJL_E(0), [&](auto kc) PJL_INL { return SPT[decltype(kc)::value][1] * jt[decltype(kc)::value]; },
+           [&]() PJL_INL { return -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg); });
     static_for<LAST>([&](auto jc) PJL_INL {
         constexpr int j = decltype(jc)::value;
         const double wj = SPT[j][3], iWj = SPT[j][0];
         double tot = 0.0;
-        static_for<NSP>([&](auto kc) PJL_INL {
+        auto mval = [&](auto kc) PJL_INL {
             constexpr int k = decltype(kc)::value;
             constexpr int si = pjs::SIDX[k][j];
             double m;
             if constexpr (ANY_GN) m = P[k] - wj * Q[k]; else m = P[k] - wj * P[k];
             if constexpr (si >= 0) m += S[si];
             tot += hW[k] * m;
-            if constexpr (k < LAST) JST(k + 1 + NSP * (j + 1), (SPT[k][1] * iWj) * m);
-        });
-        JST(NSP * (j + 1), -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp);
-        flush(std::integral_constant<int, j + 1>{});
+            return m;
+        };
+        column(jc_plus1(jc), [&](auto kc) PJL_INL { return (SPT[decltype(kc)::value][1] * iWj) * mval(kc); },
+               [&]() PJL_INL {
+                   (void)mval(PJL_E(LAST));       // the last species has no row; its term enters the energy row
+                   return -tot * iWj * icp + (cpk[j] - cpk[LAST]) * H * invrho * icp * icp;
+               });
     });
-#undef JST
+#undef PJL_E
 #undef JMEM
     if constexpr (JV) {
         double* ws = A.w + s * A.w_ss;
@@ -498,7 +592,28 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         long blocks = (s1 - s0 + PJL_BLOCK - 1) / PJL_BLOCK;
         if (blocks > resident * PJL_PERSIST) blocks = resident * PJL_PERSIST;
-        if (j_ss == 1) hipLaunchKernelGGL((k_lane<0, 1>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        if (j_ss == 1) {
+#ifndef PJL_HOST_EMU
+            // whole wavefronts through the pair-store kernel, the ragged tail (< 64 states) through the
+            // scalar-store one
+            const long s_main = s0 + (s1 - s0) / 64 * 64;
+            const bool pair = s_main > s0 && (unsigned long)j_si * 8ul * (unsigned long)NSP < (1ul << 32);
+            if (pair) {
+                Args M = A;
+                M.n = s_main;
+                long mb = (s_main - s0 + PJL_BLOCK - 1) / PJL_BLOCK;
+                if (mb > resident * PJL_PERSIST) mb = resident * PJL_PERSIST;
+                hipLaunchKernelGGL((k_lane<0, 3>), dim3((unsigned)mb), dim3(PJL_BLOCK), 0, (hipStream_t)stream, M);
+                if (s_main < s1) {
+                    Args Tl = A;
+                    Tl.s0 = s_main;
+                    Tl.jac = jac + s_main * j_ss;
+                    hipLaunchKernelGGL((k_lane<0, 1>), dim3(1), dim3(PJL_BLOCK), 0, (hipStream_t)stream, Tl);
+                }
+            } else
+#endif
+            hipLaunchKernelGGL((k_lane<0, 1>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);
+        }
 #ifndef PJL_HOST_EMU                  // the transpose needs whole wavefronts
         else if (j_si == 1 && j_ss == NSP * NSP)
             hipLaunchKernelGGL((k_lane<0, 2>), dim3((unsigned)blocks), dim3(PJL_BLOCK), 0, (hipStream_t)stream, A);

@@ -161,35 +161,7 @@ __device__ __forceinline__ void static_range(F&& f)
     if constexpr (I1 > I0) static_for_seq<I0>(f, std::make_integer_sequence<int, I1 - I0>{});
 }
 
-// exp(x) with the arithmetic of the device library's double-precision exp (same reduction and
-// polynomial) minus its range selects: ldexp saturates to 0 / inf by itself.  Two arguments at once,
-// statement by statement: the two Horner chains are independent and a lane at one wavefront per
-// SIMD has nothing else to fill the fp64 pipeline latency with.
-__device__ __forceinline__ void exp_pair(const double x0, const double x1, double& y0, double& y1)
-{
-    constexpr double LOG2E = 0x1.71547652b82fep+0, NLN2H = -0x1.62e42fefa39efp-1, NLN2L = -0x1.abc9e3b39803fp-56;
-    constexpr double C[10] = {0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22, 0x1.71dee623fde64p-19, 0x1.a01997c89e6bp-16,
-                              0x1.a01a014761f6ep-13, 0x1.6c16c1852b7bp-10, 0x1.1111111122322p-7, 0x1.55555555502a1p-5,
-                              0x1.5555555555511p-3, 0x1.000000000000bp-1};
-    const double n0 = __builtin_rint(x0 * LOG2E), n1 = __builtin_rint(x1 * LOG2E);
-    double r0 = __builtin_fma(n0, NLN2H, x0), r1 = __builtin_fma(n1, NLN2H, x1);
-    r0 = __builtin_fma(n0, NLN2L, r0); r1 = __builtin_fma(n1, NLN2L, r1);
-    double p0 = __builtin_fma(C[0], r0, C[1]), p1 = __builtin_fma(C[0], r1, C[1]);
-    static_for<8>([&](auto cc) PJR_INL {
-        constexpr int c = decltype(cc)::value + 2;
-        p0 = __builtin_fma(p0, r0, C[c]); p1 = __builtin_fma(p1, r1, C[c]);
-    });
-    p0 = __builtin_fma(r0, p0, 1.0); p1 = __builtin_fma(r1, p1, 1.0);
-    p0 = __builtin_fma(r0, p0, 1.0); p1 = __builtin_fma(r1, p1, 1.0);
-    y0 = __builtin_ldexp(p0, (int)n0); y1 = __builtin_ldexp(p1, (int)n1);
-}
-__device__ __forceinline__ double exp_one(const double x)
-{
-    double y0, y1;
-    exp_pair(x, x, y0, y1);
-    (void)y1;
-    return y0;
-}
+#include "pj_math.h"
 
 #if PJQ_PAIR
 typedef double d2s __attribute__((ext_vector_type(2)));
@@ -625,6 +597,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             else if constexpr ((fl & F_REV) != 0) ekc = exp_one(-lnKc);
             if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
             double ckf, ckr = 0.0, theta = 0.0, rp, bM = 0.0, bcol = 0.0;
+            double kf_slot = 0.0;       // Chebyshev: the k_f eval_jacob uses in its dR/dY_j terms (pj_rows_rate.inc)
             if constexpr (is_pre(i)) {
                 // falloff / PLOG: handed over by k_pre
                 constexpr int pp = v - (nv - npre);
@@ -635,7 +608,10 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
                 if constexpr (pjs::SCQ[i][S_BM] >= 0) bM = ring[pp % PJQ_DEPTH][S_BM];
                 if constexpr (pjs::SCQ[i][S_BC] >= 0) bcol = ring[pp % PJQ_DEPTH][S_BC];
                 if constexpr (pjs::SCQ[i][S_RP] >= 0) rp_ld = ring[pp % PJQ_DEPTH][S_RP];
+                double kfj_ld = 0.0;
+                if constexpr (pjs::SCQ[i][S_KR] >= 0) kfj_ld = ring[pp % PJQ_DEPTH][S_KR];
                 if constexpr (pp + PJQ_DEPTH < npre) issue_pre(bc, std::integral_constant<int, pp + PJQ_DEPTH>{});
+                if constexpr (pjs::SCQ[i][S_KR] >= 0) kf_slot = kfj_ld;
                 if constexpr ((fl & F_REV) != 0) ckr = ckf * ekc;
                 if constexpr (pjs::SCQ[i][S_RP] >= 0) rp = rp_ld;
                 else rp = WR * ((1.0 - nr) * (ckf * pr_) - ((fl & F_REV) ? (1.0 - np_) * (ckr * pp_) : 0.0));
@@ -693,13 +669,15 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
                     });
                 }
             };
-            slot(std::integral_constant<int, pjs::RI[i][RI_R0]>{}, ckf * (cr1 * cr2));
-            slot(std::integral_constant<int, pjs::RI[i][RI_R1]>{}, ckf * (cr0 * cr2));
-            slot(std::integral_constant<int, pjs::RI[i][RI_R2]>{}, ckf * (cr0 * cr1));
+            double gkf = ckf, gkr = ckr;
+            if constexpr (is_pre(i) && pjs::SCQ[i][S_KR] >= 0) { gkf = kf_slot; gkr = kf_slot * ekc; }
+            slot(std::integral_constant<int, pjs::RI[i][RI_R0]>{}, gkf * (cr1 * cr2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_R1]>{}, gkf * (cr0 * cr2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_R2]>{}, gkf * (cr0 * cr1));
             if constexpr ((fl & F_REV) != 0) {
-                slot(std::integral_constant<int, pjs::RI[i][RI_P0]>{}, -ckr * (cp1 * cp2));
-                slot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -ckr * (cp0 * cp2));
-                slot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -ckr * (cp0 * cp1));
+                slot(std::integral_constant<int, pjs::RI[i][RI_P0]>{}, -gkr * (cp1 * cp2));
+                slot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -gkr * (cp0 * cp2));
+                slot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -gkr * (cp0 * cp1));
             }
             if constexpr ((fl & F_COLLIDER) != 0)
                 slot(std::integral_constant<int, (pjs::RI[i][RI_COLLIDER] >= 0 ? pjs::RI[i][RI_COLLIDER] : ONE)>{}, bcol);

@@ -782,7 +782,7 @@ std::string emit_rows_tables(const Programs& p, int budget)
     }
     // pj_rblk.hip: only falloff / PLOG reactions are handed over (a pre-pass evaluates them once per
     // state); everything else is rebuilt from T and the concentrations at every visit.
-    // slots: theta, c*kf, (c*kr: never, rebuilt from K_c), rp, bM, bcol
+    // slots: theta, c*kf, (c*kr: never, rebuilt from K_c; Chebyshev: eval_jacob's second k_f), rp, bM, bcol
     std::vector<int32_t> scq((size_t)nrxn * 6, -1);
     int nscq = 0, npre = 0;
     for (int i = 0; i < nrxn; ++i) {
@@ -791,6 +791,7 @@ std::string emit_rows_tables(const Programs& p, int budget)
         ++npre;
         scq[(size_t)i * 6 + 0] = nscq++;
         scq[(size_t)i * 6 + 1] = nscq++;
+        if (fl & F_CHEB) scq[(size_t)i * 6 + 2] = nscq++;      // the Jacobian's own k_f (pj_rows_rate.inc)
         if (fl & (F_THD | F_PDEP)) scq[(size_t)i * 6 + 3] = nscq++;
         if (fl & F_EFFTYPE) scq[(size_t)i * 6 + 4] = nscq++;
         if (fl & F_COLLIDER) scq[(size_t)i * 6 + 5] = nscq++;

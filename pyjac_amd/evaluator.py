@@ -70,9 +70,9 @@ class Evaluator:
     _SPEC_STEM = {'lane': 'libpj_spec_%016x.so', 'rows': 'libpj_rows_%016x.so', 'fused': 'libpj_fused_%016x.so',
                   'rblk': 'libpj_rblk_%016x.so'}
 
-    _SPEC_SOURCES = {'lane': ('pj_lane.hip',), 'rows': ('pj_rows.hip', 'pj_rows_rate.inc', 'pj_rows_block.inc'),
+    _SPEC_SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rows': ('pj_rows.hip', 'pj_rows_rate.inc', 'pj_rows_block.inc'),
                      'fused': ('pj_rows.hip', 'pj_rows_rate.inc', 'pj_rows_block.inc'),
-                     'rblk': ('pj_rblk.hip', 'pj_rows.hip', 'pj_rows_rate.inc')}
+                     'rblk': ('pj_rblk.hip', 'pj_math.h', 'pj_rows.hip', 'pj_rows_rate.inc')}
     _SPEC_ENV = ('PJ_LANE_FLAGS', 'PJ_ROWS_FLAGS', 'PJ_ROWS_RATES_FLAGS', 'PJ_ROWS_BUDGET', 'PJ_ROWS_FUSE',
                  'PJ_ROWS_RATES_PER_PART', 'PJ_ROWS_BLOCK', 'PJ_ROWS_RECOMPUTE_KR', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE',
                  'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES', 'PJ_RBLK_PAIR_MODES')

@@ -134,11 +134,7 @@ def test_kernel_phases_match_oracle(name, TS, NT, aos, tables):
     ref_j = o.batch_jacob(pres, np.ascontiguousarray(y.T))
     got_j = out['jac'].reshape(n, -1) if aos else out['jac'].reshape(-1, n).T
     mx, fro = thresholded_rel_err(got_j, ref_j)
-    # Chebyshev reactions: the reference's eval_jacob re-evaluates k_f for the dR/dY_j terms with reduced
-    # variables printed at 16 digits while the rates use 8 (create_jacobian.py:1647-1664 vs
-    # rate_subs.py:176-193); the oracle reproduces both, the kernels use the rate's k_f throughout
-    # (<= 1e-7 relative on those entries, inside the 1e-6 tolerance)
-    assert mx < (1e-8 if name != 'synth_srichb' else 1e-6) and fro < (1e-12 if name != 'synth_srichb' else 1e-9), (mx, fro)
+    assert mx < 1e-8 and fro < 1e-12, (mx, fro)
     ref_d = o.batch_dydt(pres, np.ascontiguousarray(y.T))
     mx, _ = thresholded_rel_err(out['dydt'].reshape(-1, n).T, ref_d)
     assert mx < 1e-10
