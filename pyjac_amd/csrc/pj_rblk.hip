@@ -61,13 +61,16 @@ using namespace pj;
 #define PJQ_PAIR 0          // 1: two Jacobian columns per 16-byte store (SoA output, whole workgroups)
 #endif
 #ifndef PJQ_SB_EVERY
-#define PJQ_SB_EVERY 1      // scheduling barrier after every n-th visit (0: none)
+#define PJQ_SB_EVERY 0      // scheduling barrier after every n-th visit (0: none)
 #endif
 #ifndef PJQ_DEPTH
 #define PJQ_DEPTH 4         // falloff / PLOG visits whose hand-over values are in flight
 #endif
 #ifndef PJQ_CONC_OPAQUE
 #define PJQ_CONC_OPAQUE 0
+#endif
+#ifndef PJQ_KC_AHEAD
+#define PJQ_KC_AHEAD 1      // K_c rows of the next visit are read while the current one is computed
 #endif
 #ifndef PJQ_SPLIT
 #define PJQ_SPLIT 0         // scheduling barrier between the two phases of a visit
@@ -371,6 +374,15 @@ struct KcList { int v[NKC > 0 ? NKC : 1]; };
 constexpr KcList make_list() { KcList l{}; for (int q = 0; q < NKC; ++q) l.v[q] = KCM.list[q]; return l; }
 __device__ const KcList KCL = make_list();
 
+constexpr int max_kc_cnt()
+{
+    int m = 1;
+    for (int i = 0; i < NRXN; ++i)
+        if ((pjs::RI[i][RI_FLAGS] & F_REV) && pjs::RI[i][RI_KC_CNT] > m) m = pjs::RI[i][RI_KC_CNT];
+    return m;
+}
+constexpr int MAXKC = max_kc_cnt();
+
 template <int i>
 constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
 
@@ -546,6 +558,23 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         PJQ_SCHED_BARRIER();
         if constexpr (b == B0_) PJQ_TICK(0)
 
+#if PJQ_KC_AHEAD
+        // The K_c polynomial rows of visit v + 1 are read from LDS while visit v is computed (software
+        // pipelining by hand: a visit's first consumer of LDS data are those rows, and at one wavefront
+        // per SIMD nothing else covers the ~120-cycle LDS round trip at the top of every visit)
+        double kab[2][MAXKC][7];
+        auto fetch_ka = [&](auto vc) PJR_INL {
+            constexpr int v = decltype(vc)::value;
+            constexpr int i = pjs::BLK_RX[v0 + v][0];
+            constexpr int KC = (pjs::RI[i][RI_FLAGS] & F_REV) ? pjs::RI[i][RI_KC_CNT] : 0;
+            static_for<KC>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value, g = pjs::RI[i][RI_KC_PTR] + c;
+                const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                static_for<7>([&](auto ec) PJR_INL { kab[v & 1][c][decltype(ec)::value] = a[decltype(ec)::value]; });
+            });
+        };
+        if constexpr (nv > 0) fetch_ka(std::integral_constant<int, 0>{});
+#endif
         static_for<nv>([&](auto vc) PJR_INL {
             constexpr int v = decltype(vc)::value;
             constexpr int i = pjs::BLK_RX[v0 + v][0];
@@ -566,11 +595,19 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             //      of the K_c polynomial rows) next to arithmetic that needs none of it (k_f) ----
             constexpr int KCNT = (fl & F_REV) ? pjs::RI[i][RI_KC_CNT] : 0;
             double ka[KCNT > 0 ? KCNT : 1][7];
+#if PJQ_KC_AHEAD
+            static_for<KCNT>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value;
+                static_for<7>([&](auto ec) PJR_INL { ka[c][decltype(ec)::value] = kab[v & 1][c][decltype(ec)::value]; });
+            });
+            if constexpr (v + 1 < nv) fetch_ka(std::integral_constant<int, v + 1>{});
+#else
             static_for<KCNT>([&](auto cc) PJR_INL {
                 constexpr int c = decltype(cc)::value, g = pjs::RI[i][RI_KC_PTR] + c;
                 const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
                 static_for<7>([&](auto ec) PJR_INL { ka[c][decltype(ec)::value] = a[decltype(ec)::value]; });
             });
+#endif
 #if PJQ_SPLIT
             PJQ_SCHED_BARRIER();
 #endif
@@ -879,6 +916,9 @@ double* g_scr[MAXSTREAMS] = {};
 long g_scr_ld[MAXSTREAMS] = {};
 hipStream_t g_streams[MAXSTREAMS] = {};
 hipEvent_t g_events[MAXSTREAMS + 1];
+int g_device = -1;
+hipEvent_t g_last_event = nullptr;      // recorded after every batch, on the caller's stream
+void* g_last_stream = nullptr;
 #endif
 
 }  // namespace
@@ -923,6 +963,20 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
     if (n <= 0) return 0;
     const bool jv = w != nullptr;
     if (jv && !g_rows_jv[0]) return -5;
+    // The hand-over arrays (and the AoS staging block) are per library instance, i.e. per process: one
+    // device per process (a second device is refused), and a batch on another stream is ordered behind
+    // the previous batch with an event instead of racing on them.
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return -3;
+        if (g_device < 0) g_device = dev;
+        else if (dev != g_device) return -6;
+        if (!g_last_event) {
+            if (hipEventCreateWithFlags(&g_last_event, hipEventDisableTiming) != hipSuccess) return -3;
+        } else if (g_last_stream != stream) {
+            (void)hipStreamWaitEvent((hipStream_t)stream, g_last_event, 0);
+        }
+    }
     int nstreams = PJQ_STREAMS;
     long chunk_env = 0;
     if (const char* e = getenv("PJ_RBLK_STREAMS")) nstreams = atoi(e);
@@ -974,12 +1028,69 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
             (void)hipEventRecord(g_events[b], g_streams[b]);
             (void)hipStreamWaitEvent(user, g_events[b], 0);
         }
+    (void)hipEventRecord(g_last_event, user);
+    g_last_stream = stream;
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// AoS Jacobians (pyJac's per-state C layout: state-major NSP x NSP blocks): a row block produces one row
+// of every column, i.e. 8-byte pieces NSP doubles apart inside a state's block and NSP^2 apart between
+// lanes -- nothing a wavefront could store contiguously.  So the row kernels write a chunk of SoA
+// Jacobians (their native, pair-store layout) into a temporary block and this kernel transposes it:
+// 64 x 64 tiles through LDS, 512-byte runs on both sides.
+__global__ void __launch_bounds__(256) k_soa2aos(const double* __restrict__ src, long m, double* __restrict__ dst)
+{
+    __shared__ double tile[64][65];
+    constexpr int NE = NSP * NSP;
+    const long s0 = (long)blockIdx.x * 64;
+    const int e0 = blockIdx.y * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;         // 4 rows of 64 per pass
+    for (int r = ly; r < 64; r += 4) {
+        const int e = e0 + r;
+        const long sidx = s0 + lx;
+        if (e < NE && sidx < m) tile[r][lx] = __builtin_nontemporal_load(&src[(long)e * m + sidx]);
+    }
+    __syncthreads();
+    for (int r = ly; r < 64; r += 4) {
+        const long sidx = s0 + r;
+        const int e = e0 + lx;
+        if (sidx < m && e < NE) __builtin_nontemporal_store(tile[lx][r], &dst[sidx * NE + e]);
+    }
+}
+
+double* g_aos_tmp = nullptr;
+long g_aos_tmp_states = 0;
+
+int pj_spec_fast_aos(void) { return 1; }   // AoS Jacobians: SoA chunks + transpose, not strided lane stores
 
 int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
                      long j_si, long j_ss, int sum_last, void* stream)
 {
+#ifndef PJR_HOST_EMU
+    constexpr long NE = (long)NSP * NSP;
+    if (n >= PJQ_BLOCK && j_si == 1 && j_ss == NE && g_rows[0] && !getenv("PJ_RBLK_AOS_DIRECT")) {
+        // chunks that fill the device once (one workgroup per CU): 256 workgroups
+        long chunk = 256L * PJQ_BLOCK;
+        if (chunk > n) chunk = n;
+        if (g_aos_tmp_states < chunk) {
+            if (g_aos_tmp) { (void)hipDeviceSynchronize(); (void)hipFree(g_aos_tmp); g_aos_tmp = nullptr; g_aos_tmp_states = 0; }
+            if (hipMalloc((void**)&g_aos_tmp, sizeof(double) * (size_t)NE * (size_t)chunk) != hipSuccess) return -4;
+            g_aos_tmp_states = chunk;
+        }
+        for (long s0 = 0; s0 < n; s0 += chunk) {
+            long m = s0 + chunk < n ? chunk : n - s0;
+            long sb = s0;
+            if (m < PJQ_BLOCK) { sb = n - PJQ_BLOCK; m = PJQ_BLOCK; }      // short tail: redo a whole workgroup's worth
+            const int rc = run_batch(m, pres + sb, y + sb * y_ss, y_si, y_ss, g_aos_tmp, m, 1, nullptr, 0, 0, nullptr, 0, 0,
+                                     sum_last, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_soa2aos, dim3((unsigned)((m + 63) / 64), (unsigned)((NE + 63) / 64)), dim3(256), 0,
+                               (hipStream_t)stream, (const double*)g_aos_tmp, m, jac + sb * NE);
+        }
+        (void)hipEventRecord(g_last_event, (hipStream_t)stream);      // the staging block is busy until here
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+#endif
     return run_batch(n, pres, y, y_si, y_ss, jac, j_si, j_ss, nullptr, 0, 0, nullptr, 0, 0, sum_last, stream);
 }
 
