@@ -536,7 +536,12 @@ int pj_mech_emit_rows_spec(const pj_mech* m, const char* header_path, int acc_bu
 
 int pj_mech_attach_spec(pj_mech* m, const char* library_path)
 {
-    void* lib = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
+    // RTLD_NODELETE: a specialisation library owns device state (hand-over arrays, internal streams,
+    // its registered code objects and their scratch); it stays resident when the last mechanism that
+    // uses it is destroyed, and the next one finds that state instead of a fresh, leaking copy
+    // (re-loading a library with MB-sized kernels made the next large launch fail with
+    // HSA_STATUS_ERROR_OUT_OF_RESOURCES).
+    void* lib = dlopen(library_path, RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);
     if (!lib) return fail(PJ_EIO, std::string("dlopen: ") + dlerror());
     auto hash = (unsigned long long (*)(void))dlsym(lib, "pj_spec_hash");
     auto jac = (decltype(m->spec_jac))dlsym(lib, "pj_spec_jacobian");

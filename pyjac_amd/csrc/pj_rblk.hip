@@ -78,6 +78,9 @@ using namespace pj;
 #ifndef PJQ_STREAMS
 #define PJQ_STREAMS 1       // internal streams the chunks of a batch are dealt to
 #endif
+#ifndef PJQ_SPLIT_TAIL
+#define PJQ_SPLIT_TAIL 1     // batches with a partially filled last round: two unequal parts on two streams
+#endif
 #ifndef PJQ_CHUNK
 #define PJQ_CHUNK (1L << 20) // states per chunk
 #endif
@@ -140,9 +143,17 @@ constexpr double RU_ = 8314.4621;
 constexpr double INV_LN10 = 0.434294481903251828;
 constexpr int NSP = pjs::NSP, NRXN = pjs::NRXN, LAST = pjs::NSP - 1, ONE = pjs::NSP;
 constexpr int S_TH = 0, S_KF = 1, S_KR = 2, S_RP = 3, S_BM = 4, S_BC = 5;
-constexpr int SUM_H = pjs::NSCQ, SUM_SCP = pjs::NSCQ + 1, SUM_SJT = pjs::NSCQ + 2;
-constexpr int SUM_E = pjs::NSCQ + 3;            // energy-row partial sums, LAST slots
-constexpr int NSLOTS = pjs::NSCQ + 3 + (pjs::NSP - 1);
+// Energy-row sums (H, SCP, SJT and LAST partial sums E_j) travel from row kernel to row kernel through
+// two sets of slots: kernel q reads set q % 2 and writes set (q + 1) % 2.  Never in place: a state that
+// two lanes evaluate (the shifted last workgroup of the pair-store kernels, the lanes past the end of
+// the general ones) is then read identically and written identically by both, whatever the order the
+// two workgroups run in (in place, the later one could pick up the earlier one's write-back and add this
+// kernel's share twice: seen once two parts of a batch ran on two streams).
+constexpr int NSUM = 3 + (pjs::NSP - 1);
+#ifdef PJQ_ID
+constexpr int SUM_IN = pjs::NSCQ + (PJQ_ID % 2) * NSUM, SUM_OUT = pjs::NSCQ + ((PJQ_ID + 1) % 2) * NSUM;
+#endif
+constexpr int NSLOTS = pjs::NSCQ + 2 * NSUM;
 
 // reactions evaluated once per state by k_pre and handed over
 constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG | F_CHEB)) != 0; }
@@ -491,11 +502,15 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         // kernel ever waits for a load behind its own Jacobian stores
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
-            E[j] = scr[(long)(SUM_E + j) * PJQ_TILE];
+#ifndef PJQ_NO_E
+            E[j] = scr[(long)(SUM_IN + 3 + j) * PJQ_TILE];
+#else
+            E[j] = 0.0;
+#endif
         });
-        H = scr[(long)SUM_H * PJQ_TILE];
-        SCP = scr[(long)SUM_SCP * PJQ_TILE];
-        SJT = scr[(long)SUM_SJT * PJQ_TILE];
+        H = scr[(long)SUM_IN * PJQ_TILE];
+        SCP = scr[(long)(SUM_IN + 1) * PJQ_TILE];
+        SJT = scr[(long)(SUM_IN + 2) * PJQ_TILE];
     }
     // Jacobian entry e of this lane's state: wavefront-uniform 64-bit base (entry offset e * j_si and
     // the wavefront's first state: scalar arithmetic) + a 32-bit per-lane byte offset, so that a store
@@ -780,7 +795,9 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
                 constexpr int si = pjs::SLOC[k][j];
                 double m = P[r] - pjs::SP[j][3] * Q[r];
                 if constexpr (si >= 0) m += S[si];
+#ifndef PJQ_NO_E      // experiment: what the energy-row partial sums cost (results wrong)
                 E[j] += hW[r] * m;
+#endif
                 return (pjs::SP[k][1] * pjs::SP[j][0]) * m;
             }
         };
@@ -826,12 +843,14 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
     //      loaded in the next kernel's prologue); the last kernel turns them into d(dT/dt)/d. ----
     double* const sw = scr_of(A, s);
     if constexpr (!LASTK_) {
-        sw[(long)SUM_H * PJQ_TILE] = H;
-        sw[(long)SUM_SCP * PJQ_TILE] = SCP;
-        sw[(long)SUM_SJT * PJQ_TILE] = SJT;
+        sw[(long)SUM_OUT * PJQ_TILE] = H;
+        sw[(long)(SUM_OUT + 1) * PJQ_TILE] = SCP;
+        sw[(long)(SUM_OUT + 2) * PJQ_TILE] = SJT;
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
-            sw[(long)(SUM_E + j) * PJQ_TILE] = E[j];
+#ifndef PJQ_NO_E
+            sw[(long)(SUM_OUT + 3 + j) * PJQ_TILE] = E[j];
+#endif
         });
     } else {
         // rate_subs.py:2171-2335 / create_jacobian.py:2940-3120: mass-fraction weighted c_p sums
@@ -985,6 +1004,29 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
     if (const char* c = getenv("PJ_RBLK_CHUNK")) chunk_env = atol(c);
     // chunks: a multiple of the tile, at least 2 per stream when the batch fills the device several times
     long chunk = chunk_env >= 256 ? chunk_env : PJQ_CHUNK;
+    // Every kernel of a step ends with a partially filled round of workgroups (one workgroup per CU is
+    // resident; GRI-shaped 1e6 states = 15.26 rounds, USC-shaped 2e5 = 6.1), and kernels of one stream
+    // do not overlap: 16 and 7 rounds are paid, per kernel.  Two unequal parts on two streams drift
+    // apart, so one part's kernel fills the CUs the other part's last round leaves idle (measured:
+    // 7.66 -> 7.37 ms and 10.56 -> 9.40 ms, tools/r02_tail.sh).  PJ_RBLK_SPLIT=0 switches it off;
+    // explicit PJ_RBLK_STREAMS / PJ_RBLK_CHUNK take precedence.
+    if (!getenv("PJ_RBLK_STREAMS") && chunk_env < 256 && PJQ_STREAMS == 1 && PJQ_SPLIT_TAIL) {
+        const char* e = getenv("PJ_RBLK_SPLIT");
+        if (!e || atoi(e) != 0) {
+            static int cus = 0;
+            if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device) != hipSuccess) cus = 256;
+            const long lds_wg = (long)NSP * PJQ_BLOCK * 8 + 4096;
+            long per_cu = 256 / PJQ_BLOCK;                          // one wavefront per SIMD (512 registers)
+            if (per_cu > (160L << 10) / lds_wg) per_cu = (160L << 10) / lds_wg;
+            if (per_cu < 1) per_cu = 1;
+            const long slots = (long)cus * per_cu, wgs = (n + PJQ_BLOCK - 1) / PJQ_BLOCK;
+            const long rounds = (wgs + slots - 1) / slots;
+            if (n <= PJQ_CHUNK && wgs >= 2 * slots && (double)(rounds * slots - wgs) > 0.02 * (double)(rounds * slots)) {
+                chunk = (long)(0.525 * (double)n);
+                nstreams = 2;
+            }
+        }
+    }
     chunk = (chunk + PJQ_TILE - 1) / PJQ_TILE * PJQ_TILE;
     if (chunk > n) chunk = (n + PJQ_TILE - 1) / PJQ_TILE * PJQ_TILE;
     const long nchunks = (n + chunk - 1) / chunk;

@@ -661,6 +661,11 @@ def test_full_size_large_mechanism_properties(name, n, tables, torch_cuda, monke
     print('%s full size: scaled %.3g, thresholded max rel %.3g, fro %.3g' % (name, sc, mx, fro))
     assert sc <= 1.0 and fro < 1e-9 and mx < MX_BIG[name]
     assert jac_scaled_err(small.cpu().numpy().T, got, ev.nsp) <= 1e-3       # same arithmetic, other kernel variant
+    # the end of the batch (a workgroup shifted back over its neighbour's states, the end of the second
+    # part when the batch runs as two parts on two streams) against the same states as their own batch
+    tail = ev.jacobian(d_p[n - 512:].contiguous(), d_y[:, n - 512:].contiguous())
+    assert torch.equal(tail, jac[:, n - 512:])
+    del tail
     # checksum of the batch, then the same batch in 3 x 131072-state chunks on three streams
     cs = jac.sum(dim=1).clone()
     del jac, small, sample
