@@ -149,7 +149,7 @@ constexpr int S_TH = 0, S_KF = 1, S_KR = 2, S_RP = 3, S_BM = 4, S_BC = 5;
 // the general ones) is then read identically and written identically by both, whatever the order the
 // two workgroups run in (in place, the later one could pick up the earlier one's write-back and add this
 // kernel's share twice: seen once two parts of a batch ran on two streams).
-constexpr int NSUM = 3 + (pjs::NSP - 1);
+constexpr int NSUM = 5 + (pjs::NSP - 1);   // H, SCP, SJT, HP, HQ, E_j
 #ifdef PJQ_ID
 constexpr int SUM_IN = pjs::NSCQ + (PJQ_ID % 2) * NSUM, SUM_OUT = pjs::NSCQ + ((PJQ_ID + 1) % 2) * NSUM;
 #endif
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
 #endif
     // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
     double E[LAST > 0 ? LAST : 1];
-    double H = 0.0, SCP = 0.0, SJT = 0.0;
+    double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
     const double* const scr = scr_of(A, s);
     if constexpr (FIRST_) {
         static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] = 0.0; });
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
-            E[j] = scr[(long)(SUM_IN + 3 + j) * PJQ_TILE];
+            E[j] = scr[(long)(SUM_IN + 5 + j) * PJQ_TILE];
 #else
             E[j] = 0.0;
 #endif
@@ -511,6 +511,8 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         H = scr[(long)SUM_IN * PJQ_TILE];
         SCP = scr[(long)(SUM_IN + 1) * PJQ_TILE];
         SJT = scr[(long)(SUM_IN + 2) * PJQ_TILE];
+        HP = scr[(long)(SUM_IN + 3) * PJQ_TILE];
+        HQ = scr[(long)(SUM_IN + 4) * PJQ_TILE];
     }
     // Jacobian entry e of this lane's state: wavefront-uniform 64-bit base (entry offset e * j_si and
     // the wavefront's first state: scalar arithmetic) + a 32-bit per-lane byte offset, so that a store
@@ -765,8 +767,14 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         });
         PJQ_SCHED_BARRIER();
 
-        // rows of this block: NASA properties of its species, outputs, energy-row partials
-        double hW[nrows];
+        // rows of this block: NASA properties of its species, outputs, energy-row partials.
+        // Row k of the species block is (W_k / W_j)(P_k - w_j Q_k + S_kj) with w_j = W_j / W_N, i.e.
+        //   J(k, j) = (1 / W_j) (W_k (P_k + S_kj)) - W_k Q_k / W_N:
+        // one literal per column (1 / W_j) instead of two, and where S_kj is structurally zero the entry
+        // is one fused multiply-add on row constants.  The energy row Sum_k hW_k (P_k - w_j Q_k + S_kj)
+        // travels as the scalars HP = Sum hW_k P_k, HQ = Sum hW_k Q_k and E_j = Sum_k hW_k S_kj
+        // (structural non-zeros only); the last kernel puts them together.
+        double hW[nrows], WP[nrows], WQN[nrows];
         static_for<nrows>([&](auto rc) PJR_INL {
             constexpr int r = decltype(rc)::value;
             constexpr int k = pjs::BLK_ROWS[r0 + r][0];
@@ -783,6 +791,10 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             SCP += om[r] * pjs::SP[k][1] * cpk;
             if constexpr (k == LAST) SJT += hW[r] * (A.sum_last ? JT[r] : JTQ);
             else SJT += hW[r] * JT[r];
+            HP += hW[r] * P[r];
+            HQ += hW[r] * Q[r];
+            WP[r] = pjs::SP[k][1] * P[r];
+            WQN[r] = (pjs::SP[k][1] * pjs::SP[LAST][0]) * Q[r];
         });
         // Jacobian column c of a row: c = 0 is the d/dT column, c = j + 1 belongs to species j
         auto col_val = [&](auto rc, auto cc) PJR_INL {
@@ -793,12 +805,14 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             } else {
                 constexpr int j = c - 1;
                 constexpr int si = pjs::SLOC[k][j];
-                double m = P[r] - pjs::SP[j][3] * Q[r];
-                if constexpr (si >= 0) m += S[si];
+                if constexpr (si >= 0) {
 #ifndef PJQ_NO_E      // experiment: what the energy-row partial sums cost (results wrong)
-                E[j] += hW[r] * m;
+                    E[j] += hW[r] * S[si];
 #endif
-                return (pjs::SP[k][1] * pjs::SP[j][0]) * m;
+                    return pjs::SP[j][0] * (WP[r] + pjs::SP[k][1] * S[si]) - WQN[r];
+                } else {
+                    return pjs::SP[j][0] * WP[r] - WQN[r];
+                }
             }
         };
         static_for<nrows>([&](auto rc) PJR_INL {
@@ -846,10 +860,12 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         sw[(long)SUM_OUT * PJQ_TILE] = H;
         sw[(long)(SUM_OUT + 1) * PJQ_TILE] = SCP;
         sw[(long)(SUM_OUT + 2) * PJQ_TILE] = SJT;
+        sw[(long)(SUM_OUT + 3) * PJQ_TILE] = HP;
+        sw[(long)(SUM_OUT + 4) * PJQ_TILE] = HQ;
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
-            sw[(long)(SUM_OUT + 3 + j) * PJQ_TILE] = E[j];
+            sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = E[j];
 #endif
         });
     } else {
@@ -885,7 +901,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             double cpm, dcpm;
             cp_of(jc, cpm, dcpm);
             const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
-            w0 += (-E[j] * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp) * V[j + 1];
+            w0 += (-((HP + E[j]) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp) * V[j + 1];
         });
         wp[0] = w0;
 #else
@@ -895,7 +911,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             double cpm, dcpm;
             cp_of(jc, cpm, dcpm);
             const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
-            PJQ_STORE(&J_(NSP * (j + 1)), -E[j] * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp);
+            PJQ_STORE(&J_(NSP * (j + 1)), -((HP + E[j]) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp);
         });
 #endif
     }

@@ -10,6 +10,12 @@ cd /tmp
 # the bench command itself under --kernel-trace --stats (kernel average durations)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/r02_kt_$W --output-format csv -- python $R/bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/r02_kt_$W.log 2>&1
 cp $(ls $O/r02_kt_$W/*/*kernel_stats.csv | head -1) $O/r02_rblk_${W}_kernel_stats.csv
+# the kernels of the two parts of a batch overlap (two streams): step time = union of their intervals
+python $R/tools/trace_span.py $(ls $O/r02_kt_$W/*/*kernel_trace.csv | head -1) 2 "$LBL, bench.py --steps 20" > $O/r02_rblk_${W}_step_span.json 2>&1
+# and the same command with the batch as one part on the caller's stream: kernels back to back
+PJ_RBLK_SPLIT=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/r02_kt1_$W --output-format csv -- python $R/bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/r02_kt1_$W.log 2>&1
+cp $(ls $O/r02_kt1_$W/*/*kernel_stats.csv | head -1) $O/r02_rblk_${W}_onepart_kernel_stats.csv
+tail -1 $O/r02_kt1_$W.log | cut -c1-300
 pass() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $O/r02_pmc_$name --output-format csv -- python $R/tools/one_step.py $MECH $NP 2 rblk > $O/r02_pmc_$name.log 2>&1; }
 pass a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 pass b SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS
@@ -21,4 +27,5 @@ python tools/traffic_pmc.py $O/r02_pmc_c $O/r02_pmc_d 2 $NP $BPS "$LBL" > $O/tra
 grep '"Name"\|k_rblk\|k_pre' $O/r02_rblk_${W}_kernel_stats.csv | cut -c1-200
 tail -3 $O/r02_kt_$W.log | cut -c1-600
 cat $O/traffic_$W.json | head -30
-rm -rf $O/r02_pmc_a $O/r02_pmc_b $O/r02_pmc_c $O/r02_pmc_d $O/r02_kt_$W
+cat $O/r02_rblk_${W}_step_span.json
+rm -rf $O/r02_pmc_a $O/r02_pmc_b $O/r02_pmc_c $O/r02_pmc_d $O/r02_kt_$W $O/r02_kt1_$W
