@@ -179,13 +179,19 @@ __device__ __forceinline__ void static_range(F&& f)
 
 #if PJQ_PAIR
 typedef double d2s __attribute__((ext_vector_type(2)));
-// value of the other lane of an (even, odd) lane pair
-__device__ __forceinline__ double swap_pair(const double v)
+// Pair stores: a lane writes 16 bytes, two neighbouring states of one Jacobian entry.  The lanes of a
+// wavefront are mapped to states so that one v_permlane32_swap per 32-bit half does the exchange: lane
+// l < 32 holds state 2 l, lane l + 32 holds state 2 l + 1.  Swapping the upper half of x (entry c) with
+// the lower half of y (entry c + 1) leaves the lower lanes with entry c of states (2 l, 2 l + 1) and the
+// upper lanes with entry c + 1 of the same two states: (x, y) is the 16-byte piece, no selects.
+// (An (even, odd) lane pairing needs 2 DPP moves and 6 selects for the same exchange.)
+__device__ __forceinline__ void swap_halves(double& x, double& y)
 {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
-    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0xB1, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    const unsigned long long ux = __builtin_bit_cast(unsigned long long, x), uy = __builtin_bit_cast(unsigned long long, y);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ux, (unsigned)uy, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ux >> 32), (unsigned)(uy >> 32), false, false);
+    x = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+    y = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
 }
 #endif
 
@@ -425,7 +431,8 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
     // also evaluates (n >= PJQ_BLOCK, host-checked)
     long s0_wg = (long)blockIdx.x * PJQ_BLOCK;
     if (s0_wg + PJQ_BLOCK > A.n) s0_wg = A.n - PJQ_BLOCK;
-    const long s = s0_wg + tid;
+    // lanes 0..31 of a wavefront: its even states, lanes 32..63: the odd ones (swap_halves)
+    const long s = s0_wg + (tid & ~63) + 2 * (tid & 31) + ((tid >> 5) & 1);
 #else
     long s = (long)blockIdx.x * PJQ_BLOCK + tid;
     if (s >= A.n) s = A.n - 1;
@@ -527,10 +534,10 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
     const unsigned jvo = (unsigned)((s - s_wave) * A.j_ss) * 8u;
 #define J_(e) (*(double*)((char*)(Jw + (long)(e) * A.j_si) + jvo))
 #if PJQ_PAIR
-    // pair stores (SoA only, host-checked: j_ss == 1, 8 * NSP * j_si < 2^32): the even lane of a pair
-    // addresses its own state in column c, the odd lane the even lane's state in column c + 1
-    const bool odd = (tid & 1) != 0;
-    const unsigned jvo2 = odd ? jvo - 8u + (unsigned)(NSP * A.j_si) * 8u : jvo;
+    // pair stores (SoA only, host-checked: j_ss == 1, 8 * NSP * j_si < 2^32): a lane of the lower half
+    // addresses its own (even) state in column c, its partner in the upper half that state in column c + 1
+    const bool upper = (tid & 32) != 0;
+    const unsigned jvo2 = upper ? jvo - 8u + (unsigned)(NSP * A.j_si) * 8u : jvo;
 #endif
 
     // hand-over values of the falloff / PLOG visits: those visits come last in a block
@@ -824,17 +831,17 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
                 static_for<NSP>([&](auto cc) PJR_INL { wk += col_val(rc, cc) * V[decltype(cc)::value]; });
                 wp[(k + 1) * A.w_si] = wk;
 #elif PJQ_PAIR
-                // two columns per store instruction: the lanes of a pair exchange one value each, the even
-                // lane then writes both states of column c, the odd lane both states of column c + 1
-                // (16 bytes per lane: half the store instructions in flight for the same bytes)
+                // two columns per store instruction: the halves of the wavefront exchange one value each,
+                // the lower half then writes two states of column c, the upper half the same two states of
+                // column c + 1 (16 bytes per lane: half the store instructions in flight for the same bytes)
                 static_for<NSP / 2>([&](auto hc) PJR_INL {
                     constexpr int c = 2 * decltype(hc)::value;
-                    const double v0 = col_val(rc, std::integral_constant<int, c>{});
-                    const double v1 = col_val(rc, std::integral_constant<int, c + 1>{});
-                    const double recv = swap_pair(odd ? v0 : v1);
+                    double v0 = col_val(rc, std::integral_constant<int, c>{});
+                    double v1 = col_val(rc, std::integral_constant<int, c + 1>{});
+                    swap_halves(v0, v1);
                     d2s out;
-                    out.x = odd ? recv : v0;
-                    out.y = odd ? v1 : recv;
+                    out.x = v0;
+                    out.y = v1;
                     PJQ_STORE2((d2s*)((char*)(Jw + (long)(k + 1 + NSP * c) * A.j_si) + jvo2), out);
                 });
                 if constexpr (NSP % 2 != 0)
