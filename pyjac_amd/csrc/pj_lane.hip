@@ -154,10 +154,14 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
           for (int k = 0; k < LAST; ++k) nxY[k] = y_[(k + 1) * A.y_si];
       }
   };
-  fetch_state(A.s0 + (long)blockIdx.x * PJL_BLOCK + threadIdx.x);
-  for (long sl = A.s0 + (long)blockIdx.x * PJL_BLOCK + threadIdx.x; (ST == 2 ? sl - threadIdx.x : sl) < A.n;
+  // pair stores (ST == 3): lanes 0..31 of a wavefront hold its even states, lanes 32..63 the odd ones, so
+  // that one v_permlane32_swap per 32-bit half exchanges what a 16-byte store of two neighbouring states
+  // needs (pair_store below); every other instance maps lane i to state i
+  const unsigned ltid = ST == 3 ? (threadIdx.x & ~63u) + 2u * (threadIdx.x & 31u) + ((threadIdx.x >> 5) & 1u) : threadIdx.x;
+  fetch_state(A.s0 + (long)blockIdx.x * PJL_BLOCK + ltid);
+  for (long sl = A.s0 + (long)blockIdx.x * PJL_BLOCK + ltid; (ST == 2 ? sl - threadIdx.x : sl) < A.n;
        sl += (long)gridDim.x * PJL_BLOCK) {
-    const long tb = sl - threadIdx.x;
+    const long tb = sl - ltid;
     const long s = (ST == 2 && sl >= A.n) ? A.n - 1 : sl;
     // Without global stores in the loop body the optimiser treats the LDS tables as loop invariant
     // and hoists hundreds of coefficient reads out of the persistent loop (spills).  An opaque zero
@@ -460,14 +464,14 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             __builtin_amdgcn_wave_barrier();
         }
     };
-    // SoA output from whole wavefronts goes out as PAIR stores (ST == 3): the lanes of an (even, odd) pair
-    // swap one value per two rows, then the even lane writes both states of row r1, the odd lane both
-    // states of row r2 > r1 -- 16 bytes per lane, half the store instructions in flight (a wavefront may
+    // SoA output from whole wavefronts goes out as PAIR stores (ST == 3): the halves of the wavefront
+    // swap one value per two rows, then a lower lane writes two states of row r1, its upper partner the
+    // same two states of row r2 > r1 -- 16 bytes per lane, half the store instructions in flight (a wavefront may
     // have 64 outstanding; the store phase is bound by that window, profiles/r02_micro_burst_bw.txt).
     // Rows are paired as they are produced: (1,2), (3,4), ... and the energy row 0, which needs the
     // whole column, with the last species row.
-    [[maybe_unused]] const unsigned jlo = (unsigned)(threadIdx.x & 63) * 8u;
-    [[maybe_unused]] const bool odd = (threadIdx.x & 1) != 0;
+    [[maybe_unused]] const unsigned jlo = (ltid & 63u) * 8u;
+    [[maybe_unused]] const bool upper = (threadIdx.x & 32u) != 0;
     // wavefront base: a scalar, so that a store is "SGPR base + 32-bit lane offset" with no 64-bit vector
     // address arithmetic; the strides are laundered per state (the optimiser would hoist every entry
     // offset e * j_si out of the persistent loop as an SGPR pair and spill them)
@@ -475,7 +479,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     [[maybe_unused]] long jsi = A.j_si;
 #ifndef PJL_HOST_EMU
     if constexpr (ST == 3 && !JV) {
-        const long sw = sl - (threadIdx.x & 63);
+        const long sw = sl - (ltid & 63u);
         const long swu = ((long)__builtin_amdgcn_readfirstlane((int)((unsigned long)sw >> 32)) << 32) |
                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sw);
         Jw = A.jac + (swu - A.s0) * A.j_ss;
@@ -487,15 +491,15 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         constexpr int e1 = decltype(e1c)::value, e2 = decltype(e2c)::value;
         static_assert(e2 > e1, "pair stores: second entry above the first");
         typedef double d2v __attribute__((ext_vector_type(2)));
-        const double give = odd ? v1 : v2;
-        const unsigned long long u = __builtin_bit_cast(unsigned long long, give);
-        const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
-        const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0xB1, 0xF, 0xF, true);
-        const double recv = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+        const unsigned long long u1 = __builtin_bit_cast(unsigned long long, v1), u2 = __builtin_bit_cast(unsigned long long, v2);
+        // upper half of v1 <-> lower half of v2: the lower lanes then hold entry e1 of states (2 l, 2 l + 1),
+        // the upper lanes entry e2 of the same two states
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)u1, (unsigned)u2, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(u1 >> 32), (unsigned)(u2 >> 32), false, false);
         d2v out;
-        out.x = odd ? recv : v1;
-        out.y = odd ? v2 : recv;
-        const unsigned off = odd ? jlo - 8u + (unsigned)(e2 - e1) * ((unsigned)jsi * 8u) : jlo;
+        out.x = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+        out.y = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+        const unsigned off = upper ? jlo - 8u + (unsigned)(e2 - e1) * ((unsigned)jsi * 8u) : jlo;
         __builtin_nontemporal_store(out, (d2v*)((char*)(Jw + (long)e1 * jsi) + off));
 #endif
     };
