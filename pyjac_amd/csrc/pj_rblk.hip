@@ -78,6 +78,9 @@ using namespace pj;
 #ifndef PJQ_STREAMS
 #define PJQ_STREAMS 1       // internal streams the chunks of a batch are dealt to
 #endif
+#ifndef PJQ_CONC_AHEAD
+#define PJQ_CONC_AHEAD 1    // 1: a visit's concentration reads are issued during the previous visit (-1 %)
+#endif
 #ifndef PJQ_SPLIT_TAIL
 #define PJQ_SPLIT_TAIL 1     // batches with a partially filled last round: two unequal parts on two streams
 #endif
@@ -599,6 +602,21 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         };
         if constexpr (nv > 0) fetch_ka(std::integral_constant<int, 0>{});
 #endif
+#if PJQ_CONC_AHEAD
+        // the six concentration reads of visit v + 1 likewise travel while visit v is computed
+        double cab[2][6];
+        auto fetch_c = [&](auto vc) PJR_INL {
+            constexpr int v = decltype(vc)::value;
+            constexpr int i = pjs::BLK_RX[v0 + v][0];
+            cab[v & 1][0] = conc(std::integral_constant<int, pjs::RI[i][RI_R0]>{});
+            cab[v & 1][1] = conc(std::integral_constant<int, pjs::RI[i][RI_R1]>{});
+            cab[v & 1][2] = conc(std::integral_constant<int, pjs::RI[i][RI_R2]>{});
+            cab[v & 1][3] = conc(std::integral_constant<int, pjs::RI[i][RI_P0]>{});
+            cab[v & 1][4] = conc(std::integral_constant<int, pjs::RI[i][RI_P1]>{});
+            cab[v & 1][5] = conc(std::integral_constant<int, pjs::RI[i][RI_P2]>{});
+        };
+        if constexpr (nv > 0) fetch_c(std::integral_constant<int, 0>{});
+#endif
         static_for<nv>([&](auto vc) PJR_INL {
             constexpr int v = decltype(vc)::value;
             constexpr int i = pjs::BLK_RX[v0 + v][0];
@@ -609,12 +627,18 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             // column into one load and keep the value live across the kernel (register pressure)
             asm volatile("" : "+v"(vzo));
 #endif
+#if PJQ_CONC_AHEAD
+            const double cr0 = cab[v & 1][0], cr1 = cab[v & 1][1], cr2 = cab[v & 1][2];
+            const double cp0 = cab[v & 1][3], cp1 = cab[v & 1][4], cp2 = cab[v & 1][5];
+            if constexpr (v + 1 < nv) fetch_c(std::integral_constant<int, v + 1>{});
+#else
             const double cr0 = conc(std::integral_constant<int, pjs::RI[i][RI_R0]>{}),
                          cr1 = conc(std::integral_constant<int, pjs::RI[i][RI_R1]>{}),
                          cr2 = conc(std::integral_constant<int, pjs::RI[i][RI_R2]>{});
             const double cp0 = conc(std::integral_constant<int, pjs::RI[i][RI_P0]>{}),
                          cp1 = conc(std::integral_constant<int, pjs::RI[i][RI_P1]>{}),
                          cp2 = conc(std::integral_constant<int, pjs::RI[i][RI_P2]>{});
+#endif
             // ---- phase A: everything that has to travel (LDS reads of the concentration columns and
             //      of the K_c polynomial rows) next to arithmetic that needs none of it (k_f) ----
             constexpr int KCNT = (fl & F_REV) ? pjs::RI[i][RI_KC_CNT] : 0;
