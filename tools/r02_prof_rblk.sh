@@ -11,7 +11,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/r02_kt_$W --output-format csv -- python $R/bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/r02_kt_$W.log 2>&1
 cp $(ls $O/r02_kt_$W/*/*kernel_stats.csv | head -1) $O/r02_rblk_${W}_kernel_stats.csv
 # the kernels of the two parts of a batch overlap (two streams): step time = union of their intervals
-python $R/tools/trace_span.py $(ls $O/r02_kt_$W/*/*kernel_trace.csv | head -1) 2 "$LBL, bench.py --steps 20" > $O/r02_rblk_${W}_step_span.json 2>&1
+python $R/tools/trace_span.py $(ls $O/r02_kt_$W/*/*kernel_trace.csv | head -1) 2 "$W-shaped, pj_rblk, bench.py --workload $W --steps 20 (full batch)" > $O/r02_rblk_${W}_step_span.json 2>&1
 # and the same command with the batch as one part on the caller's stream: kernels back to back
 PJ_RBLK_SPLIT=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/r02_kt1_$W --output-format csv -- python $R/bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/r02_kt1_$W.log 2>&1
 cp $(ls $O/r02_kt1_$W/*/*kernel_stats.csv | head -1) $O/r02_rblk_${W}_onepart_kernel_stats.csv
