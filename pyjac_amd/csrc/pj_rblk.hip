@@ -78,6 +78,10 @@ using namespace pj;
 #ifndef PJQ_STREAMS
 #define PJQ_STREAMS 1       // internal streams the chunks of a batch are dealt to
 #endif
+#ifndef PJQ_HALVES
+#define PJQ_HALVES 1        // 2: a workgroup is two groups of PJQ_BLOCK lanes that share the PJQ_BLOCK states'
+                            // concentration columns and run different row blocks ([B0,BM) and [BM,B1))
+#endif
 #ifndef PJQ_CONC_AHEAD
 #define PJQ_CONC_AHEAD 1    // 1: a visit's concentration reads are issued during the previous visit (-1 %)
 #endif
@@ -156,7 +160,7 @@ constexpr int NSUM = 5 + (pjs::NSP - 1);   // H, SCP, SJT, HP, HQ, E_j
 #ifdef PJQ_ID
 constexpr int SUM_IN = pjs::NSCQ + (PJQ_ID % 2) * NSUM, SUM_OUT = pjs::NSCQ + ((PJQ_ID + 1) % 2) * NSUM;
 #endif
-constexpr int NSLOTS = pjs::NSCQ + 2 * NSUM;
+constexpr int NSLOTS = pjs::NSCQ + 2 * PJQ_HALVES * NSUM;     // with two halves: a pair of sets per half
 
 // reactions evaluated once per state by k_pre and handed over
 constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG | F_CHEB)) != 0; }
@@ -257,22 +261,22 @@ constexpr void kcmap_add(KcMap& m, int i)
     }
 }
 // NQ 16-byte pieces per thread: rows of the listed groups -> registers (issue), registers -> LDS (land)
-template <int NQ, class M, class D2>
+template <int NQ, int NT = PJQ_BLOCK, class M, class D2>
 __device__ __forceinline__ void kc_issue(const M& list, int nrows, D2* lt)
 {
     static_for<NQ>([&](auto qc) PJR_INL {
         constexpr int q = decltype(qc)::value;
-        const int x = (int)threadIdx.x + q * PJQ_BLOCK;
+        const int x = (int)threadIdx.x + q * NT;
         const int row = x < nrows * 8 ? x >> 3 : 0;
         lt[q] = ((const D2*)(pjs::LTAB + pjs::LT_KC + (long)list[row] * 16))[x & 7];
     });
 }
-template <int NQ, class D2>
+template <int NQ, int NT = PJQ_BLOCK, class D2>
 __device__ __forceinline__ void kc_land(double* table, int nrows, const D2* lt)
 {
     static_for<NQ>([&](auto qc) PJR_INL {
         constexpr int q = decltype(qc)::value;
-        const int x = (int)threadIdx.x + q * PJQ_BLOCK;
+        const int x = (int)threadIdx.x + q * NT;
         if (x < nrows * 8) ((D2*)table)[x] = lt[q];
     });
 }
@@ -418,7 +422,20 @@ constexpr int n_pre_visits()
 __device__ long long g_tim[5][1024][4];
 #endif
 
-__global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
+// PJQ_HALVES == 2 (mechanisms whose concentration columns leave room for 128 lanes only): the workgroup
+// is 256 threads, two groups ("halves") of PJQ_BLOCK lanes.  Both hold the same PJQ_BLOCK states -- lane l
+// of either half is state l -- and share one set of concentration columns and K_c rows in LDS; half 0
+// runs the row blocks [B0, BM), half 1 the blocks [BM, B1).  All four SIMDs of a CU work instead of two,
+// for the same LDS.  Each half carries its own energy-row sums from kernel to kernel (own slot sets);
+// in the last kernel half 1 hands its sums to half 0 through the (then free) concentration columns.
+constexpr int NTHR = PJQ_BLOCK * PJQ_HALVES;
+#ifndef PJQ_BM
+#define PJQ_BM PJQ_B1
+#endif
+constexpr int BM_ = PJQ_HALVES == 2 ? PJQ_BM : PJQ_B1;
+static_assert(PJQ_HALVES == 1 || PJQ_HALVES == 2, "PJQ_HALVES: 1 or 2");
+static_assert(PJQ_HALVES == 1 || (BM_ > PJQ_B0 && BM_ < PJQ_B1), "PJQ_BM must split [B0, B1)");
+__global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 {
     // Concentrations live in LDS, one column per lane (bank-conflict free)
     __shared__ double CL[NSP][PJQ_BLOCK];
@@ -427,7 +444,9 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
 #ifdef PJQ_TIMING
     long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64();
 #endif
-    const int tid = threadIdx.x;
+    // half: wavefront-uniform; tid: the lane's index within its half = its state's index in the workgroup
+    const int half = PJQ_HALVES == 2 ? (int)(threadIdx.x >= PJQ_BLOCK) : 0;
+    const int tid = (int)threadIdx.x - half * PJQ_BLOCK;
     // lanes past the end repeat the last state (same values to the same addresses): no divergence
 #if PJQ_PAIR
     // pair stores need whole lane pairs: the last workgroup is shifted back over states its neighbour
@@ -448,15 +467,16 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         // one round trip for everything the prologue reads: the state and this thread's share of the
         // K_c table are requested before anything waits (a load behind other workgroups' Jacobian
         // stores takes microseconds)
-        constexpr int NQ = (NKC * 8 + PJQ_BLOCK - 1) / PJQ_BLOCK;     // 16-byte pieces per thread
+        constexpr int NQ = (NKC * 8 + NTHR - 1) / NTHR;     // 16-byte pieces per thread
         d2 lt[NQ > 0 ? NQ : 1];
-        kc_issue<NQ>(KCL.v, NKC, lt);
+        kc_issue<NQ, NTHR>(KCL.v, NKC, lt);
         State L;
-        load_state(A, s, L);        // all loads, scheduling barrier, sums
-        kc_land<NQ>(LTK, NKC, lt);
+        load_state(A, s, L);        // all loads, scheduling barrier, sums (both halves: each needs T, rho, ...)
+        kc_land<NQ, NTHR>(LTK, NKC, lt);
         to_conc(L);
         T = L.T; rho = L.rho; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
-        static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
+        if (PJQ_HALVES == 1 || half == 0)
+            static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
     }
     __syncthreads();
 #if defined(PJQ_STAGGER) && !defined(PJR_HOST_EMU)
@@ -505,6 +525,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
     double E[LAST > 0 ? LAST : 1];
     double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
     const double* const scr = scr_of(A, s);
+    const long hset = (long)half * (2 * NSUM) * PJQ_TILE;      // this half's pair of slot sets
     if constexpr (FIRST_) {
         static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] = 0.0; });
     } else {
@@ -513,16 +534,16 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
-            E[j] = scr[(long)(SUM_IN + 5 + j) * PJQ_TILE];
+            E[j] = scr[hset + (long)(SUM_IN + 5 + j) * PJQ_TILE];
 #else
             E[j] = 0.0;
 #endif
         });
-        H = scr[(long)SUM_IN * PJQ_TILE];
-        SCP = scr[(long)(SUM_IN + 1) * PJQ_TILE];
-        SJT = scr[(long)(SUM_IN + 2) * PJQ_TILE];
-        HP = scr[(long)(SUM_IN + 3) * PJQ_TILE];
-        HQ = scr[(long)(SUM_IN + 4) * PJQ_TILE];
+        H = scr[hset + (long)SUM_IN * PJQ_TILE];
+        SCP = scr[hset + (long)(SUM_IN + 1) * PJQ_TILE];
+        SJT = scr[hset + (long)(SUM_IN + 2) * PJQ_TILE];
+        HP = scr[hset + (long)(SUM_IN + 3) * PJQ_TILE];
+        HQ = scr[hset + (long)(SUM_IN + 4) * PJQ_TILE];
     }
     // Jacobian entry e of this lane's state: wavefront-uniform 64-bit base (entry offset e * j_si and
     // the wavefront's first state: scalar arithmetic) + a 32-bit per-lane byte offset, so that a store
@@ -561,7 +582,9 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         });
     };
 
-    static_range<B0_, B1_>([&](auto bc) PJR_INL {
+    auto run_blocks = [&](auto lo_c, auto hi_c) PJR_INL {
+    constexpr int LO_ = decltype(lo_c)::value, HI_ = decltype(hi_c)::value;
+    static_range<LO_, HI_>([&](auto bc) PJR_INL {
         constexpr int b = decltype(bc)::value;
         constexpr int r0 = pjs::BLK_ROW_PTR[b][0], nrows = pjs::BLK_ROW_PTR[b + 1][0] - r0;
         constexpr int v0 = pjs::BLK_RX_PTR[b][0], nv = pjs::BLK_RX_PTR[b + 1][0] - v0;
@@ -570,7 +593,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         // evaluates them at the first visit and keeps them for every later block of the kernel -- in
         // AGPRs while they last, then in scratch memory, whose loads queue behind the Jacobian
         // stores.  Opaque copies of T's functions every few blocks bound that cache.
-        if constexpr ((b - B0_) % PJQ_LAUNDER_EVERY == 0 && b != B0_)
+        if constexpr ((b - LO_) % PJQ_LAUNDER_EVERY == 0 && b != LO_)
             asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT), "+v"(T2), "+v"(T3), "+v"(T4), "+v"(T2d), "+v"(T3d), "+v"(T4d));
 #endif
         double om[nrows], P[nrows], Q[nrows], JT[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
@@ -583,7 +606,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         constexpr int npre = n_pre_visits<b>();
         static_for<(npre < PJQ_DEPTH ? npre : PJQ_DEPTH)>([&](auto pc) PJR_INL { issue_pre(bc, pc); });
         PJQ_SCHED_BARRIER();
-        if constexpr (b == B0_) PJQ_TICK(0)
+        if constexpr (b == LO_) PJQ_TICK(0)
 
 #if PJQ_KC_AHEAD
         // The K_c polynomial rows of visit v + 1 are read from LDS while visit v is computed (software
@@ -883,10 +906,17 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         PJQ_SCHED_BARRIER();
         PJQ_TICK(3)
     });
+    };      // run_blocks
+    if constexpr (PJQ_HALVES == 2) {
+        if (half == 0) run_blocks(std::integral_constant<int, B0_>{}, std::integral_constant<int, BM_>{});
+        else run_blocks(std::integral_constant<int, BM_>{}, std::integral_constant<int, B1_>{});
+    } else {
+        run_blocks(std::integral_constant<int, B0_>{}, std::integral_constant<int, B1_>{});
+    }
 
     // ---- energy row: partial sums travel from kernel to kernel through hand-over slots (stored here,
     //      loaded in the next kernel's prologue); the last kernel turns them into d(dT/dt)/d. ----
-    double* const sw = scr_of(A, s);
+    double* const sw = scr_of(A, s) + hset;
     if constexpr (!LASTK_) {
         sw[(long)SUM_OUT * PJQ_TILE] = H;
         sw[(long)(SUM_OUT + 1) * PJQ_TILE] = SCP;
@@ -925,6 +955,25 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
         });
         const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
         const double icp = 1.0 / cpavg;
+        if constexpr (PJQ_HALVES == 2) {
+            // half 1 hands its sums to half 0 through the concentration columns (nobody reads them any more)
+            static_assert(PJQ_HALVES == 1 || (NSP >= LAST + 1 && NKC * 16 >= 4 * PJQ_BLOCK), "exchange buffers");
+            __syncthreads();
+            if (half == 1) {
+                static_for<LAST>([&](auto jc) PJR_INL { CL[decltype(jc)::value][tid] = E[decltype(jc)::value]; });
+                CL[LAST][tid] = H;
+                LTK[0 * PJQ_BLOCK + tid] = SCP; LTK[1 * PJQ_BLOCK + tid] = SJT;
+                LTK[2 * PJQ_BLOCK + tid] = HP; LTK[3 * PJQ_BLOCK + tid] = HQ;
+            }
+            __syncthreads();
+            if (half == 0) {
+                static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] += CL[decltype(jc)::value][tid]; });
+                H += CL[LAST][tid];
+                SCP += LTK[0 * PJQ_BLOCK + tid]; SJT += LTK[1 * PJQ_BLOCK + tid];
+                HP += LTK[2 * PJQ_BLOCK + tid]; HQ += LTK[3 * PJQ_BLOCK + tid];
+            }
+        }
+        if (PJQ_HALVES == 1 || half == 0) {
 #if PJQ_JV
         double w0 = (-(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg)) * V[0];
         static_for<LAST>([&](auto jc) PJR_INL {
@@ -945,6 +994,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
             PJQ_STORE(&J_(NSP * (j + 1)), -((HP + E[j]) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp);
         });
 #endif
+        }
     }
 #ifdef PJQ_NO_STORE
     if (pjq_sink == 1.2345e-300) J_(0) = pjq_sink;
@@ -960,7 +1010,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_rblk(PjqArgs A)
 void launch_part(const PjqArgs& A, void* stream)
 {
     const long blocks = (A.n + PJQ_BLOCK - 1) / PJQ_BLOCK;
-    hipLaunchKernelGGL(k_rblk, dim3((unsigned)blocks), dim3(PJQ_BLOCK), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_rblk, dim3((unsigned)blocks), dim3(NTHR), 0, (hipStream_t)stream, A);
 }
 #ifdef PJQ_TIMING
 void read_timing(const PjqArgs& A, void*)   // A.scr: host buffer of 5 * 1024 * 4 long long
@@ -1063,7 +1113,7 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
             static int cus = 0;
             if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device) != hipSuccess) cus = 256;
             const long lds_wg = (long)NSP * PJQ_BLOCK * 8 + 4096;
-            long per_cu = 256 / PJQ_BLOCK;                          // one wavefront per SIMD (512 registers)
+            long per_cu = 256 / (PJQ_BLOCK * PJQ_HALVES);           // one wavefront per SIMD (512 registers)
             if (per_cu > (160L << 10) / lds_wg) per_cu = (160L << 10) / lds_wg;
             if (per_cu < 1) per_cu = 1;
             const long slots = (long)cus * per_cu, wgs = (n + PJQ_BLOCK - 1) / PJQ_BLOCK;

@@ -75,7 +75,7 @@ class Evaluator:
                      'rblk': ('pj_rblk.hip', 'pj_math.h', 'pj_rows.hip', 'pj_rows_rate.inc')}
     _SPEC_ENV = ('PJ_LANE_FLAGS', 'PJ_ROWS_FLAGS', 'PJ_ROWS_RATES_FLAGS', 'PJ_ROWS_BUDGET', 'PJ_ROWS_FUSE',
                  'PJ_ROWS_RATES_PER_PART', 'PJ_ROWS_BLOCK', 'PJ_ROWS_RECOMPUTE_KR', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE',
-                 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES', 'PJ_RBLK_PAIR_MODES')
+                 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES', 'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES')
 
     def spec_path(self, kind: str = None, **opts) -> str:
         """File name of a specialised library: mechanism hash + a digest of everything else that shapes the
@@ -250,25 +250,75 @@ class Evaluator:
         f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS',
                                  '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
                                  '-ffinite-math-only').split()
-        rblk = common + f_rows + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds] + list(defines) + \
-            os.environ.get('PJ_RBLK_DEFINES', '').split() + [os.path.join(here, 'csrc', 'pj_rblk.hip')]
+        # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on
+        # the same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
+        halves = int(os.environ.get('PJ_RBLK_HALVES', 2 if block == 128 else 1))
+        rblk = common + f_rows + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves] + \
+            list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [os.path.join(here, 'csrc', 'pj_rblk.hip')]
         rows = common + ['-DPJR_BLOCK=%d' % (256 if self.nsp * 256 * 8 <= 150 * 1024 else 128),
                          '-DPJR_C_LDS=%d' % c_lds, '-DPJR_RATES_LIB', os.path.join(here, 'csrc', 'pj_rows.hip')]
         jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o'), (rows + f_rows + ['-DPJR_PART=0'], 'rhost.o')]
         if npre:
             jobs.append((rblk + ['-DPJQ_PART=1'], 'pre.o'))
         # row kernels of (nearly) equal block counts, at most `fuse` blocks each
-        nker = (nblk + fuse - 1) // fuse
+        nker = (nblk + fuse * halves - 1) // (fuse * halves)
         bounds = [nblk * i // nker for i in range(nker + 1)]
+
+        def table(name):
+            m = re.search(r'constexpr int %s\[\d+\]\[1\] = \{(.*?)\};\n' % name, t, re.S)
+            return [int(x) for x in re.findall(r'\{(-?\d+),\}', m.group(1))]
+        if halves == 2:
+            # a kernel stages the K_c rows of all its blocks (128 bytes each) next to the concentration
+            # columns: kernels are cut where the rows of one more block would not fit the LDS any more
+            ri = [[int(x) for x in r.split(',') if x.strip()] for r in re.findall(
+                r'\{([^{}]*)\}', re.search(r'constexpr int RI\[\d+\]\[\d+\] = \{(.*?)\};\n', t, re.S).group(1))]
+            enum = re.search(r'enum \{ RI_FLAGS,(.*?)\};', open(os.path.join(here, 'csrc', 'pj_tables.h')).read(), re.S).group(1)
+            names = ['RI_FLAGS'] + [x.strip() for x in enum.replace('\n', ' ').split(',') if x.strip()]
+            kp, kc = names.index('RI_KC_PTR'), names.index('RI_KC_CNT')
+            rxp, brx = table('BLK_RX_PTR'), table('BLK_RX')
+            limit = (160 * 1024 - self.nsp * block * 8) // 128 - 2
+            bounds, cur = [0], set()
+            for b in range(nblk):
+                g = set()
+                for v in range(rxp[b], rxp[b + 1]):
+                    r = ri[brx[v]]
+                    if r[0] & 1:
+                        g.update(range(r[kp], r[kp] + r[kc]))
+                if b > bounds[-1] and (len(cur | g) > limit or b - bounds[-1] >= 2 * fuse):
+                    bounds.append(b)
+                    cur = set()
+                cur |= g
+            if nblk - bounds[-1] < 2 and len(bounds) > 1:        # a kernel needs a block per half
+                bounds.pop()
+            bounds.append(nblk)
+            nker = len(bounds) - 1
+        # two halves: the blocks of a kernel are cut where the halves' estimated times meet (a visit
+        # ~0.24 us, a Jacobian entry of the output phase ~0.06 us: DESIGN.md section 5c)
+        mids = []
+        if halves == 2:
+            rx, rw = table('BLK_RX_PTR'), table('BLK_ROW_PTR')
+            cost = [0.24 * (rx[b + 1] - rx[b]) + 0.06 * self.nsp * (rw[b + 1] - rw[b]) for b in range(nblk)]
+            for i in range(nker):
+                b0, b1 = bounds[i], bounds[i + 1]
+                tot, acc, bm = sum(cost[b0:b1]), 0.0, b0 + 1
+                for b in range(b0, b1 - 1):
+                    acc += cost[b]
+                    bm = b + 1
+                    if acc >= 0.5 * tot:
+                        if acc - 0.5 * tot > 0.5 * cost[b] and b > b0:
+                            bm = b
+                        break
+                mids.append(min(max(bm, b0 + 1), b1 - 1))
+        mid = lambda i: ['-DPJQ_BM=%d' % mids[i]] if halves == 2 else []
         # each row kernel twice: with pair stores (SoA output, whole workgroups: the fast path) and general
         pair_modes = [int(x) for x in os.environ.get('PJ_RBLK_PAIR_MODES', '1,0').split(',')]
         for i in range(nker):
             for pair in pair_modes:
-                jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
+                jobs.append((rblk + mid(i) + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
                                      '-DPJQ_B1=%d' % bounds[i + 1], '-DPJQ_FIRST=%d' % (i == 0),
                                      '-DPJQ_LAST=%d' % (i == nker - 1), '-DPJQ_PAIR=%d' % pair], 'rblk%d_%d.o' % (i, pair)))
             # ... and as w = J v (the Jacobian consumed in registers)
-            jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
+            jobs.append((rblk + mid(i) + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
                                  '-DPJQ_B1=%d' % bounds[i + 1], '-DPJQ_FIRST=%d' % (i == 0),
                                  '-DPJQ_LAST=%d' % (i == nker - 1), '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % i))
         for i, r0 in enumerate(range(0, self.n_fwd, rpp)):
