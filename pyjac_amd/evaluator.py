@@ -75,7 +75,7 @@ class Evaluator:
                      'rblk': ('pj_rblk.hip', 'pj_math.h', 'pj_rows.hip', 'pj_rows_rate.inc')}
     _SPEC_ENV = ('PJ_LANE_FLAGS', 'PJ_ROWS_FLAGS', 'PJ_ROWS_RATES_FLAGS', 'PJ_ROWS_BUDGET', 'PJ_ROWS_FUSE',
                  'PJ_ROWS_RATES_PER_PART', 'PJ_ROWS_BLOCK', 'PJ_ROWS_RECOMPUTE_KR', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE',
-                 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES', 'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES')
+                 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES', 'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST')
 
     def spec_path(self, kind: str = None, **opts) -> str:
         """File name of a specialised library: mechanism hash + a digest of everything else that shapes the
@@ -297,7 +297,8 @@ class Evaluator:
         mids = []
         if halves == 2:
             rx, rw = table('BLK_RX_PTR'), table('BLK_ROW_PTR')
-            cost = [0.24 * (rx[b + 1] - rx[b]) + 0.06 * self.nsp * (rw[b + 1] - rw[b]) for b in range(nblk)]
+            cv, co = (float(x) for x in os.environ.get('PJ_RBLK_HALF_COST', '0.24,0.06').split(','))
+            cost = [cv * (rx[b + 1] - rx[b]) + co * self.nsp * (rw[b + 1] - rw[b]) for b in range(nblk)]
             for i in range(nker):
                 b0, b1 = bounds[i], bounds[i + 1]
                 tot, acc, bm = sum(cost[b0:b1]), 0.0, b0 + 1
