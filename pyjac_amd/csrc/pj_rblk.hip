@@ -304,7 +304,15 @@ struct KcList { int v[NKC > 0 ? NKC : 1]; };
 constexpr KcList make_list() { KcList l{}; for (int q = 0; q < NKC; ++q) l.v[q] = KCM.list[q]; return l; }
 __device__ const KcList KCL = make_list();
 
-__global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
+// ordinal of reaction i among the hand-over reactions (PJQ_HALVES == 2: even ones to half 0, odd ones to half 1)
+constexpr int pre_ordinal(int i)
+{
+    int c = 0;
+    for (int q = 0; q < i; ++q) c += is_pre(q) ? 1 : 0;
+    return c;
+}
+constexpr int NTHR = PJQ_BLOCK * PJQ_HALVES;
+__global__ void __launch_bounds__(NTHR) k_pre(PjqArgs A)
 {
     // NASA row pairs of the K_c groups: the range select is per lane, so the rows are read from LDS
     __shared__ __attribute__((aligned(16))) double LT[(NKC > 0 ? NKC : 1) * 16];
@@ -312,14 +320,16 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
     __shared__ double CLr[NSP][PJQ_BLOCK];
 #endif
     {
-        constexpr int NQ = (NKC * 8 + PJQ_BLOCK - 1) / PJQ_BLOCK;
+        constexpr int NQ = (NKC * 8 + NTHR - 1) / NTHR;
         d2 lt[NQ > 0 ? NQ : 1];
-        kc_issue<NQ>(KCL.v, NKC, lt);
-        kc_land<NQ>(LT, NKC, lt);
+        kc_issue<NQ, NTHR>(KCL.v, NKC, lt);
+        kc_land<NQ, NTHR>(LT, NKC, lt);
     }
-    __syncthreads();
-    const long s = (long)blockIdx.x * PJQ_BLOCK + threadIdx.x;
-    if (s >= A.n) return;
+    // two halves (see k_rblk): both on the same PJQ_BLOCK states, each with every other hand-over reaction
+    const int half = PJQ_HALVES == 2 ? (int)(threadIdx.x >= PJQ_BLOCK) : 0;
+    const int tid = (int)threadIdx.x - half * PJQ_BLOCK;
+    const long s_nom = (long)blockIdx.x * PJQ_BLOCK + tid;
+    const long s = s_nom < A.n ? s_nom : A.n - 1;
 #if PJQ_C_LDS
     double T, p, invrho, Wbar, mconc;
     {
@@ -327,10 +337,15 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
         load_state(A, s, L);
         to_conc(L);
         T = L.T; p = L.p; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
-        static_for<NSP>([&](auto kc) PJR_INL { CLr[decltype(kc)::value][threadIdx.x] = L.C[decltype(kc)::value]; });
+        if (PJQ_HALVES == 1 || half == 0)
+            static_for<NSP>([&](auto kc) PJR_INL { CLr[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
     }
-#define CC(idx) ((idx) == ONE ? 1.0 : CLr[(idx) == ONE ? 0 : (idx)][threadIdx.x])
+    __syncthreads();
+    if (s_nom >= A.n) return;
+#define CC(idx) ((idx) == ONE ? 1.0 : CLr[(idx) == ONE ? 0 : (idx)][tid])
 #else
+    __syncthreads();
+    if (s_nom >= A.n) return;
     State L;
     load_state(A, s, L);
     to_conc(L);
@@ -349,9 +364,11 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
 #endif
     double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
     double jt[NSP], jtq = 0.0;          // d/dT sums are taken by the row kernels: dead here
+    auto run_pre = [&](auto hc) PJR_INL {
+    constexpr int HALF_ = decltype(hc)::value;
     static_for<NRXN>([&](auto ic) PJR_INL {
         constexpr int i = decltype(ic)::value;
-        if constexpr (is_pre(i)) {
+        if constexpr (is_pre(i) && (PJQ_HALVES == 1 || pre_ordinal(i) % 2 == HALF_)) {
 #define PJR_RD(i_) pjs::RD[i_]
 #define PJR_KCROW(g_) (LT + KCM.loc[g_] * 16)
 #define PJR_EFL(e_) pjs::EFF_AM1[e_][0]
@@ -365,6 +382,13 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
             PJQ_SCHED_BARRIER();
         }
     });
+    };
+    if constexpr (PJQ_HALVES == 2) {
+        if (half == 0) run_pre(std::integral_constant<int, 0>{});
+        else run_pre(std::integral_constant<int, 1>{});
+    } else {
+        run_pre(std::integral_constant<int, 0>{});
+    }
     (void)jt; (void)jtq;
 #undef SCR_ST
 #undef CC
@@ -373,7 +397,7 @@ __global__ void __launch_bounds__(PJQ_BLOCK) k_pre(PjqArgs A)
 void launch_pre(const PjqArgs& A, void* stream)
 {
     const long blocks = (A.n + PJQ_BLOCK - 1) / PJQ_BLOCK;
-    hipLaunchKernelGGL(k_pre, dim3((unsigned)blocks), dim3(PJQ_BLOCK), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_pre, dim3((unsigned)blocks), dim3(NTHR), 0, (hipStream_t)stream, A);
 }
 struct Reg { Reg() { pjq_register(0, 1, launch_pre); } } reg_;
 #endif  // PJQ_PART == 1
