@@ -253,7 +253,10 @@ class Evaluator:
         # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on
         # the same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
         halves = int(os.environ.get('PJ_RBLK_HALVES', 2 if block == 128 else 1))
+        # (the 111-species kernels are short of registers: without the one-visit look-ahead of the K_c rows and
+        # concentrations they spill half as much, and spill reloads queue behind the Jacobian stores: -3 %)
         rblk = common + f_rows + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves] + \
+            (['-DPJQ_CONC_AHEAD=0', '-DPJQ_KC_AHEAD=0'] if halves == 2 else []) + \
             list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [os.path.join(here, 'csrc', 'pj_rblk.hip')]
         rows = common + ['-DPJR_BLOCK=%d' % (256 if self.nsp * 256 * 8 <= 150 * 1024 else 128),
                          '-DPJR_C_LDS=%d' % c_lds, '-DPJR_RATES_LIB', os.path.join(here, 'csrc', 'pj_rows.hip')]
