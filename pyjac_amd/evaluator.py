@@ -246,7 +246,8 @@ class Evaluator:
         common = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr,
                   '-I', os.path.join(here, 'csrc')]
         f_rows = os.environ.get('PJ_RBLK_FLAGS',
-                                '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math').split()
+                                '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
+                                '-mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
         f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS',
                                  '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
                                  '-ffinite-math-only').split()
