@@ -21,13 +21,13 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
-def build(native: bool = False) -> str:
+def build(native: bool = False, quad: bool = False) -> str:
     """Compile oracle/pyjac_oracle.c (gcc) if missing or stale."""
-    name = 'libpyjac_oracle_native.so' if native else 'libpyjac_oracle.so'
+    name = 'libpyjac_oracle_quad.so' if quad else 'libpyjac_oracle_native.so' if native else 'libpyjac_oracle.so'
     out = os.path.join(HERE, '_build', name)
-    src = os.path.join(HERE, 'pyjac_oracle.c')
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call(['make', '-s', '-C', HERE, 'native' if native else 'all'])
+    srcs = [os.path.join(HERE, 'pyjac_oracle.c')] + ([os.path.join(HERE, 'pyjac_oracle_quad.c')] if quad else [])
+    if not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(['make', '-s', '-C', HERE, 'quad' if quad else 'native' if native else 'all'])
     return out
 
 
@@ -111,6 +111,63 @@ class Oracle:
         pres = np.ascontiguousarray(pres, dtype=np.float64)
         dy = np.empty((num, self.nsp))
         self.lib.pjo_batch_dydt(self.h, num, _p(pres), _p(y_aos), _p(dy), nthreads)
+        return dy
+
+
+class OracleQuad:
+    """binary128 build of the oracle's text (oracle/pyjac_oracle_quad.c): the reference's formulas and
+    constants with 113-bit intermediates, rounded to binary64 once at the end.  The "truth" that the
+    rounding error of an evaluation order is measured against (tests/test_conditioning.py)."""
+
+    def __init__(self, tables):
+        self.lib = L = ctypes.CDLL(build(quad=True))
+        L.pjq_create.restype = ctypes.c_void_p
+        L.pjq_create.argtypes = [_ip, ctypes.c_long, _dp, ctypes.c_long]
+        I = np.ascontiguousarray(tables.I, dtype=np.int32)
+        D = np.ascontiguousarray(tables.D, dtype=np.float64)
+        h = L.pjq_create(I.ctypes.data_as(_ip), I.size, _p(D), D.size)
+        if not h:
+            raise RuntimeError('oracle rejected the mechanism tables')
+        self.h = ctypes.c_void_p(h)
+        self.nsp, self.nrxn, self.nrev, self.npres = tables.nsp, tables.nrxn, tables.nrev, tables.npres
+        vp = ctypes.c_void_p
+        L.pjq_eval_all.argtypes = [vp, ctypes.c_double] + [_dp] * 8
+        L.pjq_batch_jacob.argtypes = [vp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
+        L.pjq_batch_dydt.argtypes = [vp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int]
+        L.pjq_destroy.argtypes = [vp]
+
+    def __del__(self):
+        try:
+            self.lib.pjq_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_sum_last_species(self, on: bool):
+        self.lib.pjq_set_sum_last_species(int(on))
+
+    def eval_all(self, pres: float, y: np.ndarray):
+        n = self.nsp
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        o = dict(conc=np.zeros(n), fwd=np.zeros(self.nrxn), rev=np.zeros(max(self.nrev, 1)),
+                 pres_mod=np.zeros(max(self.npres, 1)), spec_rates=np.zeros(n), dydt=np.zeros(n), jac=np.zeros(n * n))
+        self.lib.pjq_eval_all(self.h, float(pres), _p(y), *[_p(o[k]) for k in
+                                                          ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')])
+        return o
+
+    def batch_jacob(self, pres: np.ndarray, y_aos: np.ndarray, nthreads: int = 0) -> np.ndarray:
+        num = pres.shape[0]
+        y_aos = np.ascontiguousarray(y_aos, dtype=np.float64)
+        pres = np.ascontiguousarray(pres, dtype=np.float64)
+        jac = np.empty((num, self.nsp * self.nsp))
+        self.lib.pjq_batch_jacob(self.h, num, _p(pres), _p(y_aos), _p(jac), nthreads)
+        return jac
+
+    def batch_dydt(self, pres: np.ndarray, y_aos: np.ndarray, nthreads: int = 0) -> np.ndarray:
+        num = pres.shape[0]
+        y_aos = np.ascontiguousarray(y_aos, dtype=np.float64)
+        pres = np.ascontiguousarray(pres, dtype=np.float64)
+        dy = np.empty((num, self.nsp))
+        self.lib.pjq_batch_dydt(self.h, num, _p(pres), _p(y_aos), _p(dy), nthreads)
         return dy
 
 

@@ -114,3 +114,40 @@ def jac_scaled_err(test, ref, nsp, rtol=1e-6, ctol=1e-12):
     rowmax = a.max(axis=1, keepdims=True)
     tol = rtol * a + ctol * np.maximum(rowmax, colmax) + 1e-300
     return float((np.abs(t - r) / tol).max())
+
+
+def rel_err_entries(test, ref):
+    """Per-entry relative error under the reference tester's mask (|ref| > ||ref||_2 / 1e20 per state,
+    functional_tester/test.py:1446-1463); masked-out entries count as 0."""
+    test, ref = np.atleast_2d(test), np.atleast_2d(ref)
+    mask = np.abs(ref) > np.linalg.norm(ref, axis=1, keepdims=True) / 1e20
+    rel = np.zeros_like(ref)
+    rel[mask] = np.abs(test - ref)[mask] / np.abs(ref)[mask]
+    return rel
+
+
+def truth_report(test, ref, truth, nsp, label=''):
+    """Where `test` (a HIP kernel or its CPU emulation) and `ref` (pyJac's generated C or the oracle that keeps
+    its evaluation order) disagree by more than 1e-6 on a Jacobian entry, whose rounding error is it?
+    `truth` is the binary128 evaluation of the reference's formulas (oracle/pyjac_oracle_quad.c) rounded to
+    binary64.  Returns the figures DESIGN.md section 2 quotes and prints them (pytest -s / GPUTEST log)."""
+    n = np.atleast_2d(ref).shape[0]
+    r_tr, r_tt, r_rt = rel_err_entries(test, ref), rel_err_entries(test, truth), rel_err_entries(ref, truth)
+    bad = r_tr > 1e-6
+    rep = dict(test_vs_ref=float(r_tr.max()), test_vs_truth=float(r_tt.max()), ref_vs_truth=float(r_rt.max()),
+               n_bad=int(bad.sum()), bad_per_state=float(bad.sum()) / n, ref_over_1e6=int((r_rt > 1e-6).sum()),
+               test_over_1e6=int((r_tt > 1e-6).sum()))
+    if bad.any():
+        a = np.abs(np.atleast_2d(truth)).reshape(n, nsp, nsp)
+        scale = np.maximum(a.max(axis=1, keepdims=True), a.max(axis=2, keepdims=True)) * np.ones_like(a)
+        size = (a / (scale + 1e-300)).reshape(n, -1)[bad]
+        rep.update(bad_test_vs_truth=float(r_tt[bad].max()), bad_ref_vs_truth_median=float(np.median(r_rt[bad])),
+                   bad_size_max=float(size.max()), bad_size_median=float(np.median(size)),
+                   bad_explained=bool((r_tt[bad] <= 1e-3 * r_tr[bad]).all()))
+    print('%s entry-wise vs binary128 truth: kernel %.3g, reference %.3g (kernel vs reference %.3g); entries where '
+          'kernel and reference differ by > 1e-6: %d (%.3g per state)%s'
+          % (label, rep['test_vs_truth'], rep['ref_vs_truth'], rep['test_vs_ref'], rep['n_bad'], rep['bad_per_state'],
+             '' if not bad.any() else '; on those kernel-vs-truth <= %.3g, reference-vs-truth median %.3g, |J| / row-column '
+             'scale median %.3g max %.3g' % (rep['bad_test_vs_truth'], rep['bad_ref_vs_truth_median'],
+                                              rep['bad_size_median'], rep['bad_size_max'])))
+    return rep

@@ -5,16 +5,36 @@ relative error (functional_tester/test.py:1446-1463)."""
 import numpy as np
 import pytest
 
-from conftest import MECHS, jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err
+from conftest import MECHS, jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err, truth_report
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-6
-# Bound on the reference tester's thresholded relative error (its mask |J| > ||J||_2 / 1e20 keeps entries
-# that are 1e-13 of their row scale, i.e. differences of terms 1e13 larger) for the 53- / 111-species
-# mechanisms; the entry-wise tolerance proper is jac_scaled_err (rtol 1e-6 + 1e-12 of the row / column
-# scale).  Measured values are printed and recorded in DESIGN.md section 2.
-MX_BIG = {'gri30_shaped': 1e-4, 'usc2_shaped': 5e-2}
+# 53- / 111-species mechanisms: the entry-wise tolerance is checked against the TRUTH -- the reference's formulas
+# evaluated in binary128 (oracle/pyjac_oracle_quad.c, `_truth` below): every entry of the kernels' Jacobians is
+# within RTOL of it (measured <= 3e-9).  pyJac's own binary64 evaluation order is not (entries 1e-13 of their
+# row / column scale carry its rounding error: 4e-6 GRI-shaped, 2e-3 USC-shaped; tests/test_conditioning.py), so
+# kernel-vs-reference under the reference tester's metric is bounded by 3x those measured values, and every
+# entry where the two differ by more than RTOL must be explained by the reference's distance from the truth.
+MX_BIG = {'gri30_shaped': 1.2e-5, 'usc2_shaped': 7e-3}
+_truth_cache = {}
+
+
+def _truth(name, tables, pres, y_aos, key):
+    """binary128 Jacobians of the batch (test infrastructure, CPU)."""
+    from oracle.oracle import OracleQuad
+    if (name, key) not in _truth_cache:
+        _truth_cache[(name, key)] = OracleQuad(tables(name)).batch_jacob(pres, np.ascontiguousarray(y_aos))
+    return _truth_cache[(name, key)]
+
+
+def _check_vs_truth(label, name, jac, ref, truth, nsp):
+    rep = truth_report(jac, ref, truth, nsp, label=label)
+    assert rep['test_vs_truth'] < RTOL and rep['test_over_1e6'] == 0, rep      # north star: entry-wise rtol 1e-6
+    assert rep['test_vs_ref'] < MX_BIG[name], rep
+    if rep['n_bad']:
+        assert rep['bad_explained'], rep      # |kernel - truth| <= 1e-3 |kernel - reference| on each such entry
+    return rep
 # kernel families for mechanisms beyond the register-resident kernel: pj_rblk.hip (default) and its
 # predecessor pj_rows.hip
 BIG = ('pj_rblk', 'pj_rows')
@@ -219,6 +239,8 @@ def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda)
     sc = jac_scaled_err(jac, ref, ev.nsp)
     print('%s %s %s: scaled %.3g, thresholded max rel %.3g, fro %.3g' % (name, layout, kernel, sc, mx, fro))
     assert sc <= 1.0 and fro < 1e-9 and mx < MX_BIG[name], (name, layout, sc, mx, fro)
+    _check_vs_truth('%s %s %s n=%d' % (name, layout, kernel, n), name, jac, ref,
+                    _truth(name, tables, pres, y.T, ('dist_b21', n)), ev.nsp)
 
 
 @pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])
@@ -544,6 +566,8 @@ def test_large_mechanisms_vs_reference_golden(name, golden, tables, torch_cuda):
         assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0 and fro < 1e-9, (name, use, mx, fro)
         print('%s use_spec=%d: thresholded max rel %.3g, fro %.3g' % (name, use, mx, fro))
         assert mx < MX_BIG[name]
+        _check_vs_truth('%s golden use_spec=%d' % (name, use), name, jac, g['jac'],
+                        _truth(name, tables, g['pres'], g['y'], 'golden'), ev.nsp)
     # every rate output of both paths (state-per-lane rate kernels, table-driven kernel) against the
     # reference's vectors: net rates are judged against the gross rate they are the difference of
     gross, sdy = rate_scales(tables(name), g['pres'], g['y'], g['conc'], g['fwd'], g['rev'], g['pres_mod'])
@@ -660,6 +684,7 @@ def test_full_size_large_mechanism_properties(name, n, tables, torch_cuda, monke
     sc = jac_scaled_err(got, ref, ev.nsp)
     print('%s full size: scaled %.3g, thresholded max rel %.3g, fro %.3g' % (name, sc, mx, fro))
     assert sc <= 1.0 and fro < 1e-9 and mx < MX_BIG[name]
+    _check_vs_truth('%s full-size sample' % name, name, got, ref, _truth(name, tables, pres[ii], y[:, ii].T, 'full'), ev.nsp)
     assert jac_scaled_err(small.cpu().numpy().T, got, ev.nsp) <= 1e-3       # same arithmetic, other kernel variant
     # the end of the batch (a workgroup shifted back over its neighbour's states, the end of the second
     # part when the batch runs as two parts on two streams) against the same states as their own batch
