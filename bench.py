@@ -28,6 +28,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md chip table (spec); 6290 measured copy
+# Second roof (SURVEY.md 8(d) "report both"): fp64 vector issue.  A wavefront issues one VALU instruction per
+# 4 shader clocks at best (64 lanes over a 16-lane SIMD); measured with every CU busy on fp64 FMAs: 2.34 ns per
+# instruction and wavefront (profiles/r02_micro_fma_latency.txt, 1.85 GHz sustained) x 256 CUs x 4 SIMDs
+VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 / 2.341e-9
 
 WORKLOADS = {
     'h2': dict(mech=os.path.join(ROOT, 'pyjac_amd', 'data', 'h2o2_n2.inp'), ref='h2o2_n2',
@@ -117,7 +121,7 @@ def end_to_end(ev, w, n_sample, np):
 def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0):
     """Evaluator with its mechanism-specific kernels attached.  Prebuilt libraries
     (__graft_entry__.build()) are used as they are; a missing register-resident (pj_lane)
-    library is compiled here (seconds), by local rank 0 only.  The row-block (pj_rows) libraries
+    library is compiled here (seconds), by local rank 0 only.  The row-block (pj_rblk) libraries
     of the larger mechanisms take minutes to build and are never compiled inside the bench:
     without one the table-driven kernel runs."""
     ev = pyjac_amd.Evaluator(mech, specialize='auto')
@@ -134,8 +138,7 @@ def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0):
 def kernel_label(ev):
     return {'pj_lane': 'pj_lane (register-resident state-per-lane kernel)',
             'pj_rblk': 'pj_rblk (state-per-lane row-block kernels that rebuild their rates + falloff/PLOG pre-pass)',
-            'pj_rows': 'pj_rows (state-per-lane rate + row-block kernels)',
-            'pj_fused': 'pj_rows fused (4 wavefronts per 64-state tile, one kernel)'}.get(
+            }.get(
                 ev.spec_kernel if ev.has_spec else '', 'k_eval (table-driven)')
 
 
@@ -287,6 +290,18 @@ def main():
             # a launch over n states moves n / states_per_launch times the profiled bytes
             tj = json.load(open(tpath))
             traffic = tj['hbm_bytes_per_launch'] * n / tj.get('states_per_launch', n)
+        # the instruction roof of the same step: VALU instructions per state and the share of wave-cycles that
+        # issue, from the committed SQ-counter summary of this workload (profiles/valu_<wl>.json, tools/valu_roof.py)
+        valu = None
+        vpath = os.path.join(ROOT, 'profiles', 'valu_%s.json' % wl)
+        if os.path.exists(vpath):
+            vj = json.load(open(vpath))
+            wave_instr_per_s = vj['valu_instr_per_state'] * n / 64.0 / (ms_kernel * 1e-3)
+            valu = {'instr_per_state': vj['valu_instr_per_state'], 'issue_frac': vj['issue_frac'],
+                    'wait_frac': vj.get('wait_frac'), 'achieved_wave_instr_per_s': wave_instr_per_s,
+                    'fp64_peak_wave_instr_per_s': VALU_PEAK_WAVE_INSTR_PER_S,
+                    'frac': wave_instr_per_s / VALU_PEAK_WAVE_INSTR_PER_S, 'source': vj.get('source')}
+        hbm_frac = achieved / HBM_PEAK_GBPS
         line = {
             'metric': 'fp64 analytical Jacobians/s', 'value': value, 'unit': 'Jacobians/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -296,9 +311,10 @@ def main():
                        'n_rxn': ev.n_fwd, 'layout': lay, 'launch': ev.get_launch(),
                        'parallelism': 'states sharded over %d GPU(s), no data-path collective' % world,
                        'finite': finite},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'bytes_per_state': bj, 'kernel_ms': ms_kernel},
+            # `frac` is the HBM fraction the metric asks for; `bound` names the roof the kernel is closer to
+            'roofline': {'bound': 'valu' if (valu and valu['frac'] > hbm_frac) else 'hbm', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': hbm_frac, 'traffic': traffic,
+                         'bytes_per_state': bj, 'kernel_ms': ms_kernel, 'valu': valu},
         }
         if validation:
             line['validation_allgather'] = validation

@@ -75,11 +75,22 @@ int pj_mech_get_launch(const pj_mech* m, int* tile_states, int* threads, int* ld
 unsigned long long pj_mech_spec_hash(const pj_mech* m);
 /* write the constexpr header consumed by pj_lane.hip (-DPJS_HEADER='"path"') */
 int pj_mech_emit_spec(const pj_mech* m, const char* header_path);
-/* same header plus the row-block partition consumed by pj_rows.hip: the state-per-lane
+/* same header plus the row-block partition consumed by pj_rblk.hip: the state-per-lane
  * kernels for mechanisms whose sparse Jacobian block exceeds the register file; acc_budget =
  * accumulator doubles a row block may hold in registers */
 int pj_mech_emit_rows_spec(const pj_mech* m, const char* header_path, int acc_budget);
-/* dlopen a library built from pj_lane.hip / pj_rows.hip for this mechanism (hash-checked) and
+/* ... plus the kernel plan of a pj_rblk.hip library (NKER / KER_B / KER_BM: row blocks [B0, B1) of each row kernel
+ * and where its two lane groups meet; NRATE / RATE_R: reactions of each rate kernel).  fuse: row blocks per
+ * kernel and lane group at most; block, halves: states per workgroup and lane groups (1 | 2) of the row
+ * kernels; rate_block, rate_c_lds: states per workgroup of the rate kernels and whether they keep the
+ * concentrations in LDS; rate_groups: K_c groups per rate kernel at most (0: what fits the LDS); cost_visit /
+ * cost_entry (<= 0: defaults): balance of the two lane groups.  counts (may be null): [0] row kernels,
+ * [1] rate kernels, [2] reactions evaluated by the pre-pass, [3] row blocks, [4] reaction visits.
+ * (pyJac's counterpart: the generation step, python -m pyjac; libgen/libgen.py:330-420 compiles its output) */
+int pj_mech_emit_rblk_spec(const pj_mech* m, const char* header_path, int acc_budget, int fuse, int block, int halves,
+                           int rate_block, int rate_c_lds, int rate_groups, double cost_visit, double cost_entry,
+                           int* counts);
+/* dlopen a library built from pj_lane.hip / pj_rblk.hip for this mechanism (hash-checked) and
  * route pj_eval_jacobian_dev / pj_run / pj_eval_jacob through it */
 int pj_mech_attach_spec(pj_mech* m, const char* library_path);
 /* 1 if a specialised kernel is attached */

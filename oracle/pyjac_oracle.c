@@ -245,11 +245,15 @@ static double eval_Kc(const pjo_mech *m, int i, double T, double logT)
     return m->kcpref[i] * exp(Kc);
 }
 
+/* concentration product of one reaction side, rate_subs.py:634-658 / 811-840: whole-number coefficients by
+ * repeated multiplication, fractional ones through pow() */
 static double conc_prod(const int32_t *sp, const double *nu, int p0, int p1, const double *C)
 {
     double r = 1.0;
-    for (int p = p0; p < p1; ++p)
-        for (int q = 0; q < (int)nu[p]; ++q) r *= C[sp[p]];
+    for (int p = p0; p < p1; ++p) {
+        if (nu[p] == floor(nu[p])) { for (int q = 0; q < (int)nu[p]; ++q) r *= C[sp[p]]; }
+        else r *= pow(C[sp[p]], nu[p]);
+    }
     return r;
 }
 
@@ -433,10 +437,16 @@ static double s_term(const int32_t *sp, const double *nu, int p0, int p1, int j,
     double v = k;
     double n = nu[found];
     if (n != 1.0) v *= n;
-    for (int q = 0; q < (int)n - 1; ++q) v *= C[j];
+    /* reference quirk kept for parity: the power of C_j is only written "if (nu - 1) > 0"
+     * (create_jacobian.py:417-427), so a coefficient below one loses its C_j^(nu-1) factor */
+    if (n - 1.0 > 0.0) {
+        if (n == floor(n)) { for (int q = 0; q < (int)n - 1; ++q) v *= C[j]; }
+        else v *= pow(C[j], n - 1.0);
+    }
     for (int p = p0; p < p1; ++p) {
         if (p == found) continue;
-        for (int q = 0; q < (int)nu[p]; ++q) v *= C[sp[p]];
+        if (nu[p] == floor(nu[p])) { for (int q = 0; q < (int)nu[p]; ++q) v *= C[sp[p]]; }
+        else v *= pow(C[sp[p]], nu[p]);
     }
     return v;
 }

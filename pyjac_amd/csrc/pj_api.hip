@@ -534,6 +534,30 @@ int pj_mech_emit_rows_spec(const pj_mech* m, const char* header_path, int acc_bu
     return ok ? PJ_OK : fail(PJ_EIO, "short write");
 }
 
+int pj_mech_emit_rblk_spec(const pj_mech* m, const char* header_path, int acc_budget, int fuse, int block, int halves,
+                           int rate_block, int rate_c_lds, int rate_groups, double cost_visit, double cost_entry,
+                           int* counts)
+{
+    if (acc_budget < 8) return fail(PJ_EINVAL, "accumulator budget too small");
+    if (block < 1 || rate_block < 1 || fuse < 1 || (halves != 1 && halves != 2)) return fail(PJ_EINVAL, "kernel plan options");
+    RblkPlanOpts O;
+    O.fuse = fuse; O.block = block; O.halves = halves; O.rate_block = rate_block; O.rate_c_lds = rate_c_lds;
+    O.rate_groups = rate_groups;
+    if (cost_visit > 0.0) O.cost_visit = cost_visit;
+    if (cost_entry > 0.0) O.cost_entry = cost_entry;
+    RblkPlan plan;
+    const std::string h = emit_spec_header(m->P) + emit_rows_tables(m->P, acc_budget, &O, &plan);
+    FILE* f = fopen(header_path, "w");
+    if (!f) return fail(PJ_EIO, std::string("cannot write ") + header_path);
+    const bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
+    fclose(f);
+    if (counts) {
+        counts[0] = plan.n_row_kernels; counts[1] = plan.n_rate_kernels; counts[2] = plan.n_pre;
+        counts[3] = plan.n_blocks; counts[4] = plan.n_visits;
+    }
+    return ok ? PJ_OK : fail(PJ_EIO, "short write");
+}
+
 int pj_mech_attach_spec(pj_mech* m, const char* library_path)
 {
     // RTLD_NODELETE: a specialisation library owns device state (hand-over arrays, internal streams,

@@ -29,7 +29,7 @@
 
 using namespace pj;
 
-// SRI falloff and Chebyshev rate expressions live in pj_rows_rate.inc / pj_kernel.h only: such mechanisms
+// SRI falloff and Chebyshev rate expressions live in pj_rate_pre.inc / pj_kernel.h only: such mechanisms
 // are served by the row-block family (Evaluator.spec_kind) or the table-driven kernel
 constexpr bool lane_supported()
 {

@@ -1,8 +1,8 @@
 // pj_rblk.hip -- state-per-lane Jacobian kernels for MEDIUM / LARGE mechanisms, second generation:
 // row blocks that REBUILD the reaction rates they need instead of reading them back.
 //
-// pj_rows.hip evaluates every reaction once (k_rates), hands c*k_f (and more) to the row-block
-// kernels through an HBM scratch array and reads it back ~3.6 times: 2.2x the algorithmic bytes, a
+// Round 1's family (pj_rows.hip, retired) evaluated every reaction once, handed c*k_f (and more) to row-block
+// kernels through an HBM scratch array and read it back ~3.6 times: 2.2x the algorithmic bytes, a
 // load queue that sits behind the Jacobian stores of the previous block (vmcnt is one in-order
 // counter on gfx9), and a compute-bound rate kernel that cannot share a SIMD with the row kernels.
 // Measured (profiles/r02_*): the row kernels wait 55 % and issue 24 % of their wave-cycles, the
@@ -31,11 +31,13 @@
 // The mechanism is injected as constexpr tables (pj::emit_spec_header + pj::emit_rows_tables ->
 // PJS_HEADER); every loop is a compile-time loop.  One translation unit per kernel (PJQ_PART).
 //
-// Same formulation as pj_lane.hip / pj_rows.hip / pj_kernel.h; reference emitters:
+// Same formulation as pj_lane.hip / pj_kernel.h; reference emitters:
 // pyjac/core/rate_subs.py:254-2335, pyjac/core/create_jacobian.py:2189-3298.
 //
-// PJQ_PART = 0: host entry points;  1: k_pre;  2: k_rblk<PJQ_B0,PJQ_B1> (PJQ_FIRST / PJQ_LAST: first /
-// last row kernel of the library).  PJQ_ID is the launch-order index of a row kernel.
+// PJQ_PART = 0: host entry points;  1: k_pre;  2: k_rblk, row blocks [PJQ_B0, PJQ_B1) (PJQ_FIRST / PJQ_LAST: first /
+// last row kernel of the library);  3: k_rate, reactions [PJQ_R0, PJQ_R1).  PJQ_ID is the launch-order index of
+// a kernel; the ranges come from the kernel plan in the header (pj::emit_rows_tables: KER_B, KER_BM, RATE_R)
+// unless given explicitly (tests).
 #ifdef PJR_HOST_EMU
 #include "hip_shim.h"
 #else
@@ -140,6 +142,13 @@ struct PjqArgs {
     // PJQ_JV kernels (w = J v per state): chunk bases, element (i, s) at base[i*si + s*ss]
     const double* v; long v_si, v_ss;
     double* w; long w_si, w_ss;
+    // k_rate (rate outputs of pyJac's k_dydt pass): SoA arrays with leading dimension o_ld, any may be null;
+    // sr: omega_k between the rate kernels of a library that has several (leading dimension sr_ld)
+    // (k_rate with per-reaction outputs stores unconditionally: an array the caller does not want is pointed at
+    // a dummy row with row stride 0 -- fwd_ld / rev_ld / pm_ld)
+    double *conc, *fwd, *rev, *pres_mod, *spec_rates, *dy; long o_ld;
+    long fwd_ld, rev_ld, pm_ld;
+    double* sr; long sr_ld;
 };
 typedef void (*pjq_launch_fn)(const PjqArgs&, void* stream);
 extern "C" void pjq_register(int id, int kind, pjq_launch_fn fn);
@@ -374,7 +383,7 @@ __global__ void __launch_bounds__(NTHR) k_pre(PjqArgs A)
 #define PJR_EFL(e_) pjs::EFF_AM1[e_][0]
 #define PJR_KC_FIRST(i_) true
 #define PJR_SCHED_BARRIER() PJQ_SCHED_BARRIER()
-#include "pj_rows_rate.inc"
+#include "pj_rate_pre.inc"
 #undef PJR_RD
 #undef PJR_KCROW
 #undef PJR_EFL
@@ -406,6 +415,13 @@ struct Reg { Reg() { pjq_register(0, 1, launch_pre); } } reg_;
 // ------------------------------------------------------------------------------------------
 // k_rblk<B0,B1>
 // ------------------------------------------------------------------------------------------
+#ifndef PJQ_B0      // from the kernel plan
+#define PJQ_B0 pjs::KER_B[PJQ_ID][0]
+#define PJQ_B1 pjs::KER_B[PJQ_ID + 1][0]
+#define PJQ_BM pjs::KER_BM[PJQ_ID][0]
+#define PJQ_FIRST (PJQ_ID == 0)
+#define PJQ_LAST (PJQ_ID == pjs::NKER - 1)
+#endif
 constexpr int B0_ = PJQ_B0, B1_ = PJQ_B1;
 constexpr bool FIRST_ = PJQ_FIRST != 0, LASTK_ = PJQ_LAST != 0;
 constexpr KcMap make_kcmap()
@@ -464,7 +480,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     // Concentrations live in LDS, one column per lane (bank-conflict free)
     __shared__ double CL[NSP][PJQ_BLOCK];
     // NASA row pairs of every K_c group (the low / high range select is per lane)
-    __shared__ __attribute__((aligned(16))) double LTK[(NKC > 0 ? NKC : 1) * 16];
+    // (the last kernel of a two-half build also passes four sums per state from half 1 to half 0 through it)
+    constexpr int LTK_X = (PJQ_HALVES == 2 && LASTK_) ? 4 * PJQ_BLOCK : 1;
+    __shared__ __attribute__((aligned(16))) double LTK[(NKC * 16 > LTK_X ? NKC * 16 : LTK_X)];
 #ifdef PJQ_TIMING
     long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64();
 #endif
@@ -729,7 +747,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             else if constexpr ((fl & F_REV) != 0) ekc = exp_one(-lnKc);
             if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
             double ckf, ckr = 0.0, theta = 0.0, rp, bM = 0.0, bcol = 0.0;
-            double kf_slot = 0.0;       // Chebyshev: the k_f eval_jacob uses in its dR/dY_j terms (pj_rows_rate.inc)
+            double kf_slot = 0.0;       // Chebyshev: the k_f eval_jacob uses in its dR/dY_j terms (pj_rate_pre.inc)
             if constexpr (is_pre(i)) {
                 // falloff / PLOG: handed over by k_pre
                 constexpr int pp = v - (nv - npre);
@@ -981,7 +999,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         const double icp = 1.0 / cpavg;
         if constexpr (PJQ_HALVES == 2) {
             // half 1 hands its sums to half 0 through the concentration columns (nobody reads them any more)
-            static_assert(PJQ_HALVES == 1 || (NSP >= LAST + 1 && NKC * 16 >= 4 * PJQ_BLOCK), "exchange buffers");
+            static_assert(!(PJQ_HALVES == 2 && LASTK_) || sizeof(LTK) >= sizeof(double) * 4 * PJQ_BLOCK, "exchange buffer");
             __syncthreads();
             if (half == 1) {
                 static_for<LAST>([&](auto jc) PJR_INL { CL[decltype(jc)::value][tid] = E[decltype(jc)::value]; });
@@ -1048,9 +1066,262 @@ struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_JV ? 6 : PJQ_PAIR ? 2 : 4, launch_
 #endif
 #endif  // PJQ_PART == 2
 
+#if PJQ_PART == 3
+// ------------------------------------------------------------------------------------------
+// k_rate: the rate outputs of pyJac's k_dydt pass (pyjacob.cu:18-25, 153: eval_conc, eval_rxn_rates,
+// get_rxn_pres_mod, eval_spec_rates, dydt) in one pass over the reactions [R0, R1)
+// ------------------------------------------------------------------------------------------
+// One state per lane, every reaction visited ONCE: k_f and exp(-ln K_c) side by side (exp_pair), the
+// third-body concentration, q_f, q_r; omega_k accumulates in registers with compile-time indices and dydt is
+// finished in the same kernel -- no hand-over through memory when one kernel covers the mechanism (a kernel
+// per reaction range otherwise: omega_k then travels through `sr`).  Concentrations sit in registers
+// (PJQ_C_LDS = 0: up to ~64 species) or in LDS columns; the K_c polynomial rows of the range in LDS (the low /
+// high range select is per lane).  Falloff / PLOG / Chebyshev reactions take the shared body pj_rate_pre.inc.
+// PJQ_FULL = 1: also fwd / rev / pres_mod (per reaction stores); 0: conc, spec_rates, dydt only.
+#ifndef PJQ_FULL
+#define PJQ_FULL 0
+#endif
+#define PJR_RECOMPUTE_KF 0
+#define PJR_RECOMPUTE_KR 1
+#define PJR_SLOT(i_, c_) (-1)
+constexpr bool kf_plain(int) { return false; }
+#ifndef PJQ_R0      // from the kernel plan
+#define PJQ_R0 pjs::RATE_R[PJQ_ID][0]
+#define PJQ_R1 pjs::RATE_R[PJQ_ID + 1][0]
+#define PJQ_FIRST (PJQ_ID == 0)
+#define PJQ_LAST (PJQ_ID == pjs::NRATE - 1)
+#endif
+constexpr int R0_ = PJQ_R0, R1_ = PJQ_R1;
+constexpr bool FIRST_ = PJQ_FIRST != 0, LASTK_ = PJQ_LAST != 0;
+constexpr KcMap make_kcmap()
+{
+    KcMap m{};
+    for (int g = 0; g < NKC_ALL; ++g) m.loc[g] = -1;
+    for (int i = R0_; i < R1_; ++i) kcmap_add(m, i);
+    return m;
+}
+constexpr KcMap KCM = make_kcmap();
+constexpr int NKC = KCM.n;
+struct KcList { int v[NKC > 0 ? NKC : 1]; };
+constexpr KcList make_list() { KcList l{}; for (int q = 0; q < NKC; ++q) l.v[q] = KCM.list[q]; return l; }
+__device__ const KcList KCL = make_list();
+constexpr int NTHR = PJQ_BLOCK * PJQ_HALVES;
+
+__global__ void __launch_bounds__(NTHR) k_rate(PjqArgs A)
+{
+    __shared__ __attribute__((aligned(16))) double LTK[(NKC > 0 ? NKC : 1) * 16];
+#if PJQ_C_LDS
+    __shared__ double CL[NSP][PJQ_BLOCK];
+#endif
+    // two halves (PJQ_HALVES == 2, see k_rblk): both on the same PJQ_BLOCK states, every other reaction each
+    const int half = PJQ_HALVES == 2 ? (int)(threadIdx.x >= PJQ_BLOCK) : 0;
+    const int tid = (int)threadIdx.x - half * PJQ_BLOCK;
+    // lanes past the end repeat the last state (same values to the same addresses): no divergence
+    long s = (long)blockIdx.x * PJQ_BLOCK + tid;
+    if (s >= A.n) s = A.n - 1;
+    double om[NSP];
+    double T, p, rho, invrho, Wbar, mconc;
+#if !PJQ_C_LDS
+    State L;
+#endif
+    {
+        constexpr int NQ = (NKC * 8 + NTHR - 1) / NTHR;
+        d2 lt[NQ > 0 ? NQ : 1];
+        kc_issue<NQ, NTHR>(KCL.v, NKC, lt);
+#if PJQ_C_LDS
+        State L;
+#endif
+        // omega_k of the reactions before R0: requested with the state, before anything waits
+        if constexpr (!FIRST_) {
+            if (PJQ_HALVES == 1 || half == 0)
+                static_for<NSP>([&](auto kc) PJR_INL { om[decltype(kc)::value] = A.sr[decltype(kc)::value * A.sr_ld + s]; });
+        }
+        load_state(A, s, L);
+        kc_land<NQ, NTHR>(LTK, NKC, lt);
+        to_conc(L);
+        T = L.T; p = L.p; rho = L.rho; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
+#if PJQ_C_LDS
+        if (PJQ_HALVES == 1 || half == 0)
+            static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
+#endif
+    }
+    if (FIRST_ || (PJQ_HALVES == 2 && half == 1))
+        static_for<NSP>([&](auto kc) PJR_INL { om[decltype(kc)::value] = 0.0; });
+    __syncthreads();
+#if PJQ_C_LDS
+#define CC(idx) ((idx) == ONE ? 1.0 : CL[(idx) == ONE ? 0 : (idx)][tid])
+#else
+#define CC(idx) L.C[idx]
+#endif
+    const double logT = log(T), invT = 1.0 / T, logp = log(p);
+    const double T2 = T * T, T3 = T2 * T, T4 = T2 * T2;
+    // output addresses: wavefront-uniform 64-bit base (row offset + the wavefront's first state: scalar
+    // arithmetic) + a 32-bit per-lane byte offset
+#ifdef PJR_HOST_EMU
+    const long s_wave = s;
+#else
+    const long s_wave = ((long)__builtin_amdgcn_readfirstlane((int)((unsigned long)s >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s);
+#endif
+    const unsigned lvo = (unsigned)(s - s_wave) * 8u;
+#define OUT_(base, row) (*(double*)((char*)((base) + (long)(row) * A.o_ld + s_wave) + lvo))
+#define OUTL_(base, row, ld) (*(double*)((char*)((base) + (long)(row) * (ld) + s_wave) + lvo))
+    if constexpr (FIRST_) {
+        // eval_conc (rate_subs.py:1625-1710)
+        if (A.conc && (PJQ_HALVES == 1 || half == 0))
+            static_for<NSP>([&](auto kc) PJR_INL { PJQ_STORE(&OUT_(A.conc, decltype(kc)::value), CC(decltype(kc)::value)); });
+    }
+    constexpr bool RATES_OUT = true;
+    auto rate_out = [&](auto ic, const double Rf, const double Rr, const double c) PJR_INL {
+        constexpr int i = decltype(ic)::value;
+        (void)Rf; (void)Rr; (void)c;
+#if PJQ_FULL
+        // rate_subs.py:634-658, 811-840, 1076-1283: indices are positions in the mechanism file
+        // (no branches around the stores: ~700 of them would cut the kernel into as many scheduling regions)
+        PJQ_STORE(&OUTL_(A.fwd, pjs::RI[i][RI_ORIG], A.fwd_ld), Rf);
+        if constexpr (pjs::RI[i][RI_REV_IDX] >= 0) PJQ_STORE(&OUTL_(A.rev, pjs::RI[i][RI_REV_IDX], A.rev_ld), Rr);
+        if constexpr (pjs::RI[i][RI_PRES_IDX] >= 0) PJQ_STORE(&OUTL_(A.pres_mod, pjs::RI[i][RI_PRES_IDX], A.pm_ld), c);
+#endif
+    };
+    double (&jt)[NSP] = om;         // pj_rate_pre.inc accumulates omega_k into jt[] when RATES_OUT
+    double jtq = 0.0;
+    double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
+#define SCR_ST(slot, val) ((void)0)
+    auto run_rx = [&](auto hc) PJR_INL {
+    constexpr int HALF_ = decltype(hc)::value;
+    static_range<R0_, R1_>([&](auto ic) PJR_INL {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (PJQ_HALVES == 1 || (i - R0_) % 2 == HALF_) {
+        if constexpr (is_pre(i)) {
+#define PJR_RD(i_) pjs::RD[i_]
+#define PJR_KCROW(g_) (LTK + KCM.loc[g_] * 16)
+#define PJR_EFL(e_) pjs::EFF_AM1[e_][0]
+#define PJR_KC_FIRST(i_) true
+#define PJR_SCHED_BARRIER() PJQ_SCHED_BARRIER()
+#include "pj_rate_pre.inc"
+#undef PJR_RD
+#undef PJR_KCROW
+#undef PJR_EFL
+#undef PJR_KC_FIRST
+#undef PJR_SCHED_BARRIER
+        } else {
+            // Arrhenius (+ optional third body): rate_subs.py:113-147, 634-658, 660-840, 1076-1134
+            constexpr int fl = pjs::RI[i][RI_FLAGS];
+            const double cr0 = CC(pjs::RI[i][RI_R0]), cr1 = CC(pjs::RI[i][RI_R1]), cr2 = CC(pjs::RI[i][RI_R2]);
+            const double lnk = pjs::RD[i][RD_LNA] + pjs::RD[i][RD_B] * logT - pjs::RD[i][RD_TA] * invT;
+            double kf, Rr = 0.0;
+            if constexpr ((fl & F_REV) != 0) {
+                const double cp0 = CC(pjs::RI[i][RI_P0]), cp1 = CC(pjs::RI[i][RI_P1]), cp2 = CC(pjs::RI[i][RI_P2]);
+                double lnKc = pjs::RD[i][RD_LNPREF];
+                static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJR_INL {
+                    constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
+                    const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                    lnKc += a[0] + a[1] * logT + a[2] * T + a[3] * T2 + a[4] * T3 + a[5] * T4 - a[6] * invT;
+                });
+                double ekc_;
+                exp_pair(lnk, -lnKc, kf, ekc_);
+                if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
+                Rr = (kf * ekc_) * (cp0 * cp1 * cp2);
+            } else {
+                kf = exp_one(lnk);
+                if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
+            }
+            const double Rf = kf * (cr0 * cr1 * cr2);
+            double c = 1.0;
+            if constexpr ((fl & F_THD) != 0) {
+                c = mconc;
+                static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
+                    constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                    c += pjs::EFF_AM1[e][0] * CC(pjs::EFF_SP[e][0]);
+                });
+            }
+            rate_out(ic, Rf, Rr, c);
+            const double q_ = c * (Rf - Rr);
+            static_for<pjs::RI[i][RI_NET_CNT]>([&](auto qc) PJR_INL {
+                constexpr int q = pjs::RI[i][RI_NET_PTR] + decltype(qc)::value;
+                om[pjs::NET_SP[q][0]] += pjs::NET_NU[q][0] * q_;
+            });
+#if PJQ_SB_EVERY
+            if constexpr ((i - R0_ + 1) % PJQ_SB_EVERY == 0) PJQ_SCHED_BARRIER();
+#endif
+        }
+        }
+    });
+    };
+    if constexpr (PJQ_HALVES == 2) {
+        if (half == 0) run_rx(std::integral_constant<int, 0>{});
+        else run_rx(std::integral_constant<int, 1>{});
+    } else {
+        run_rx(std::integral_constant<int, 0>{});
+    }
+    (void)jtq; (void)ekc; (void)tdk; (void)logp; (void)p; (void)Wbar;
+
+    // mass-fraction weighted c_p sum from the concentrations (Y_k c_p,k = C_k R (a0 + ...) / rho): taken before
+    // the halves reuse the concentration columns
+    double cpa = 0.0;
+    if constexpr (LASTK_) {
+        static_for<NSP>([&](auto kc) PJR_INL {
+            constexpr int k = decltype(kc)::value;
+            const bool lo = T <= pjs::SP[k][2];
+            double a[5];
+            static_for<5>([&](auto cc) PJR_INL { a[decltype(cc)::value] = lo ? pjs::SP[k][4 + decltype(cc)::value] : pjs::SP[k][11 + decltype(cc)::value]; });
+            cpa += CC(k) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+        });
+    }
+#if PJQ_HALVES == 2
+    // half 1 hands its share of omega_k to half 0 through the concentration columns (nobody reads them any more)
+    static_assert(PJQ_C_LDS, "two lane groups share the concentration columns");
+    __syncthreads();
+    if (half == 1) static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = om[decltype(kc)::value]; });
+    __syncthreads();
+    if (half == 1) return;
+    static_for<NSP>([&](auto kc) PJR_INL { om[decltype(kc)::value] += CL[decltype(kc)::value][tid]; });
+#endif
+    if constexpr (!LASTK_) {
+        static_for<NSP>([&](auto kc) PJR_INL { A.sr[decltype(kc)::value * A.sr_ld + s] = om[decltype(kc)::value]; });
+    } else {
+        // eval_spec_rates output (rate_subs.py:1297-1542: the last species through dy_N = sp_rates[NSP - 1]) and
+        // dydt (rate_subs.py:2171-2335): dT/dt = -sum_k h_k W_k omega_k / (rho c_p), dY_k/dt = omega_k W_k / rho
+        if (A.spec_rates)
+            static_for<NSP>([&](auto kc) PJR_INL { PJQ_STORE(&OUT_(A.spec_rates, decltype(kc)::value), om[decltype(kc)::value]); });
+        if (A.dy) {
+            const double cpavg = cpa * (RU_ * invrho);
+            double Hs = 0.0;
+            static_for<NSP>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                const bool lo = T <= pjs::SP[k][2];
+                double a[6];
+                static_for<6>([&](auto cc) PJR_INL { a[decltype(cc)::value] = lo ? pjs::SP[k][4 + decltype(cc)::value] : pjs::SP[k][11 + decltype(cc)::value]; });
+                const double hW = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                                         T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+                Hs += hW * om[k];
+                if constexpr (k < LAST) PJQ_STORE(&OUT_(A.dy, k + 1), om[k] * pjs::SP[k][1] * invrho);
+            });
+            PJQ_STORE(&OUT_(A.dy, 0), -Hs / (rho * cpavg));
+        }
+    }
+#undef OUT_
+#undef OUTL_
+#undef CC
+#undef SCR_ST
+}
+
+void launch_rate(const PjqArgs& A, void* stream)
+{
+    const long blocks = (A.n + PJQ_BLOCK - 1) / PJQ_BLOCK;
+    hipLaunchKernelGGL(k_rate, dim3((unsigned)blocks), dim3(NTHR), 0, (hipStream_t)stream, A);
+}
+struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_FULL ? 8 : 7, launch_rate); } } reg_;   // 7: conc / spec_rates / dydt, 8: every rate output
+#endif  // PJQ_PART == 3
+
 #if PJQ_PART == 0
 constexpr int MAXPARTS = 256;
 pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_rows_gen[MAXPARTS], g_rows_jv[MAXPARTS], g_timing[MAXPARTS];
+pjq_launch_fn g_rate_lean[MAXPARTS], g_rate_full[MAXPARTS];
+double* g_rate_scr = nullptr;           // omega_k between the rate kernels of a library that has several
+long g_rate_scr_ld = 0;
+double* g_rate_dummy = nullptr;         // one row that takes the per-reaction outputs the caller does not want
+long g_rate_dummy_ld = 0;
 constexpr int MAXSTREAMS = 8;
 double* g_scr[MAXSTREAMS] = {};
 long g_scr_ld[MAXSTREAMS] = {};
@@ -1069,7 +1340,8 @@ extern "C" {
 void pjq_register(int id, int kind, pjq_launch_fn fn)
 {
     if (kind == 1) g_pre = fn;
-    else if (id >= 0 && id < MAXPARTS) (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : kind == 6 ? g_rows_jv : g_rows)[id] = fn;
+    else if (id >= 0 && id < MAXPARTS)
+        (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : kind == 6 ? g_rows_jv : kind == 7 ? g_rate_lean : kind == 8 ? g_rate_full : g_rows)[id] = fn;
 }
 
 // debug builds (-DPJQ_TIMING): cycles per phase of row kernel `part`, [5][1024 workgroups][4 wavefronts]
@@ -1084,7 +1356,7 @@ int pj_spec_debug_timing(int part, long long* out)
 
 unsigned long long pj_spec_hash(void) { return PJS_HASH; }
 int pj_spec_nsp(void) { return NSP; }
-int pj_spec_kind(void) { return 4; }   // 1: pj_lane.hip, 2: pj_rows.hip, 3: pj_rows.hip fused, 4: pj_rblk.hip
+int pj_spec_kind(void) { return 4; }   // 1: pj_lane.hip, 4: pj_rblk.hip (2, 3: retired families)
 long pj_spec_scratch_doubles_per_state(void) { return NSLOTS; }
 
 // layouts as in include/pyjac_amd.h: element (i, s) at base[i*si + s*ss].  One batch at a time per
@@ -1096,6 +1368,28 @@ long pj_spec_scratch_doubles_per_state(void) { return NSLOTS; }
 // different chunks are out of step with each other.  The internal streams are forked from and joined
 // to the caller's stream with events: the call is asynchronous and ordered like one kernel launch on
 // `stream`.  PJ_RBLK_STREAMS=1: everything on the caller's stream.
+// The hand-over arrays (and the AoS staging block) are per library instance, i.e. per process: one device per
+// process (a second device is refused), and a batch on another stream is ordered behind the previous batch
+// with an event instead of racing on them.
+static int enter_batch(void* stream)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -3;
+    if (g_device < 0) g_device = dev;
+    else if (dev != g_device) return -6;
+    if (!g_last_event) {
+        if (hipEventCreateWithFlags(&g_last_event, hipEventDisableTiming) != hipSuccess) return -3;
+    } else if (g_last_stream != stream) {
+        (void)hipStreamWaitEvent((hipStream_t)stream, g_last_event, 0);
+    }
+    return 0;
+}
+static void leave_batch(void* stream)
+{
+    (void)hipEventRecord(g_last_event, (hipStream_t)stream);
+    g_last_stream = stream;
+}
+
 static int run_batch(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac, long j_si,
                      long j_ss, const double* v, long v_si, long v_ss, double* w, long w_si, long w_ss, int sum_last,
                      void* stream)
@@ -1103,20 +1397,7 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
     if (n <= 0) return 0;
     const bool jv = w != nullptr;
     if (jv && !g_rows_jv[0]) return -5;
-    // The hand-over arrays (and the AoS staging block) are per library instance, i.e. per process: one
-    // device per process (a second device is refused), and a batch on another stream is ordered behind
-    // the previous batch with an event instead of racing on them.
-    {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess) return -3;
-        if (g_device < 0) g_device = dev;
-        else if (dev != g_device) return -6;
-        if (!g_last_event) {
-            if (hipEventCreateWithFlags(&g_last_event, hipEventDisableTiming) != hipSuccess) return -3;
-        } else if (g_last_stream != stream) {
-            (void)hipStreamWaitEvent((hipStream_t)stream, g_last_event, 0);
-        }
-    }
+    if (const int rc = enter_batch(stream)) return rc;
     int nstreams = PJQ_STREAMS;
     long chunk_env = 0;
     if (const char* e = getenv("PJ_RBLK_STREAMS")) nstreams = atoi(e);
@@ -1191,8 +1472,7 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
             (void)hipEventRecord(g_events[b], g_streams[b]);
             (void)hipStreamWaitEvent(user, g_events[b], 0);
         }
-    (void)hipEventRecord(g_last_event, user);
-    g_last_stream = stream;
+    leave_batch(stream);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -1264,6 +1544,52 @@ int pj_spec_jacvec(long n, const double* pres, const double* y, long y_si, long 
 {
     if (!v || !w) return -1;
     return run_batch(n, pres, y, y_si, y_ss, nullptr, 0, 0, v, v_si, v_ss, w, w_si, w_ss, sum_last, stream);
+}
+
+// Rate outputs of one pass (pyjacob.cu:18-35 k_dydt): conc, fwd, rev, pres_mod, spec_rates, dydt; any pointer
+// may be null; SoA, leading dimension n.  One k_rate kernel per reaction range of the library (one for
+// mechanisms whose K_c rows fit the LDS): omega_k stays in registers, or travels from kernel to kernel through
+// the caller's spec_rates array (a chunk-sized scratch array when the caller does not want it).
+int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y_ss, double* conc, double* fwd,
+                  double* rev, double* pres_mod, double* spec_rates, double* dy, void* stream)
+{
+    if (n <= 0) return 0;
+    const bool full = fwd || rev || pres_mod;
+    pjq_launch_fn* parts = full ? g_rate_full : g_rate_lean;
+    if (!parts[0]) return -5;
+    if (const int rc = enter_batch(stream)) return rc;
+    if (full && !(fwd && rev && pres_mod) && g_rate_dummy_ld < n) {
+        if (g_rate_dummy) { (void)hipDeviceSynchronize(); (void)hipFree(g_rate_dummy); g_rate_dummy = nullptr; g_rate_dummy_ld = 0; }
+        if (hipMalloc((void**)&g_rate_dummy, sizeof(double) * (size_t)n) != hipSuccess) return -4;
+        g_rate_dummy_ld = n;
+    }
+    int nparts = 0;
+    while (nparts < MAXPARTS && parts[nparts]) ++nparts;
+    long chunk = n;
+    if (nparts > 1 && !spec_rates) {
+        chunk = n < 262144 ? n : 262144;
+        if (g_rate_scr_ld < chunk) {
+            if (g_rate_scr) { (void)hipDeviceSynchronize(); (void)hipFree(g_rate_scr); g_rate_scr = nullptr; g_rate_scr_ld = 0; }
+            if (hipMalloc((void**)&g_rate_scr, sizeof(double) * (size_t)NSP * (size_t)chunk) != hipSuccess) return -4;
+            g_rate_scr_ld = chunk;
+        }
+    }
+    for (long s0 = 0; s0 < n; s0 += chunk) {
+        PjqArgs A{};
+        A.n = s0 + chunk < n ? chunk : n - s0;
+        A.pres = pres + s0; A.y = y + s0 * y_ss; A.y_si = y_si; A.y_ss = y_ss;
+        A.conc = conc ? conc + s0 : nullptr; A.spec_rates = spec_rates ? spec_rates + s0 : nullptr;
+        if (full) {
+            A.fwd = fwd ? fwd + s0 : g_rate_dummy + s0; A.fwd_ld = fwd ? n : 0;
+            A.rev = rev ? rev + s0 : g_rate_dummy + s0; A.rev_ld = rev ? n : 0;
+            A.pres_mod = pres_mod ? pres_mod + s0 : g_rate_dummy + s0; A.pm_ld = pres_mod ? n : 0;
+        }
+        A.dy = dy ? dy + s0 : nullptr; A.o_ld = n;
+        A.sr = spec_rates ? spec_rates + s0 : g_rate_scr; A.sr_ld = spec_rates ? n : g_rate_scr_ld;
+        for (int i = 0; i < nparts; ++i) parts[i](A, stream);
+    }
+    leave_batch(stream);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 }  // extern "C"

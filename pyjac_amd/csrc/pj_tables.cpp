@@ -665,7 +665,7 @@ std::string emit_spec_header(const Programs& p)
         std::vector<double> spc;
         for (int k = 0; k < nsp; ++k) for (int c = 0; c < 4; ++c) spc.push_back(p.sp[(size_t)k * SPW + c]);
         dev_arr("SPT", spc, 4);
-        dev_arr("SPF", p.sp, SPW);      // full species records (pj_rows.hip fused kernel)
+        dev_arr("SPF", p.sp, SPW);      // full species records (kept for tools)
     }
     o += "#endif\n";
     o += "#ifdef __HIPCC__\n__device__ __attribute__((aligned(16))) const double LTAB[LT_SIZE] = {\n";
@@ -682,13 +682,13 @@ std::string emit_spec_header(const Programs& p)
     return o;
 }
 
-// Row-block partition for pj_rows.hip (state-per-lane kernels for mechanisms whose sparse
+// Row-block partition for pj_rblk.hip (state-per-lane kernels for mechanisms whose sparse
 // block does not fit the register file at once): species rows are grouped greedily so that a
 // group's accumulators (4 dense + its structurally non-zero S entries per row) fit `budget`
 // doubles, preferring rows that share reactions (each group visits every reaction that
 // touches one of its rows).  Also numbers the per-reaction values the rate kernel hands to
 // the row kernels through the HBM scratch array.
-std::string emit_rows_tables(const Programs& p, int budget)
+std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* plan_opts, RblkPlan* plan_out)
 {
     const int nsp = p.nsp, nrxn = p.nrxn;
     std::string o;
@@ -791,7 +791,7 @@ std::string emit_rows_tables(const Programs& p, int budget)
         ++npre;
         scq[(size_t)i * 6 + 0] = nscq++;
         scq[(size_t)i * 6 + 1] = nscq++;
-        if (fl & F_CHEB) scq[(size_t)i * 6 + 2] = nscq++;      // the Jacobian's own k_f (pj_rows_rate.inc)
+        if (fl & F_CHEB) scq[(size_t)i * 6 + 2] = nscq++;      // the Jacobian's own k_f (pj_rate_pre.inc)
         if (fl & (F_THD | F_PDEP)) scq[(size_t)i * 6 + 3] = nscq++;
         if (fl & F_EFFTYPE) scq[(size_t)i * 6 + 4] = nscq++;
         if (fl & F_COLLIDER) scq[(size_t)i * 6 + 5] = nscq++;
@@ -837,6 +837,96 @@ std::string emit_rows_tables(const Programs& p, int budget)
     arr_i("SCQ", scq, 6);
     arr_i("ARM_BLK_PTR", arm_ptr, 1);
     arr_i("ARM_BLKS", arm_list, 1);
+    if (plan_opts) {
+        // ---- kernel plan of a pj_rblk.hip library (which row blocks / reactions each kernel takes) ----
+        const RblkPlanOpts& O = *plan_opts;
+        const int halves = O.halves == 2 ? 2 : 1, fuse = O.fuse > 0 ? O.fuse : 13;
+        // K_c groups a row block / a reaction needs (a kernel stages their polynomial rows in LDS, 128 bytes each)
+        auto groups_of_rxn = [&](int i, std::vector<char>& g) {
+            const int32_t* ri = &p.ri[(size_t)i * RIW];
+            if (ri[RI_FLAGS] & F_REV)
+                for (int c = 0; c < ri[RI_KC_CNT]; ++c) g[ri[RI_KC_PTR] + c] = 1;
+        };
+        const int ngrp = (int)(p.kcg.size() / KCW);
+        auto count = [](const std::vector<char>& g) { int c = 0; for (char x : g) c += x; return c; };
+        std::vector<int32_t> kb{0}, km;
+        if (halves == 1) {
+            // row kernels of (nearly) equal block counts, at most `fuse` blocks each
+            const int nker = (nblk + fuse - 1) / fuse;
+            kb.clear();
+            for (int i = 0; i <= nker; ++i) kb.push_back((int32_t)((long)nblk * i / nker));
+        } else {
+            // two lane groups per workgroup: a kernel spans up to 2 * fuse blocks, and the K_c rows of all of
+            // them sit next to the concentration columns -- kernels are cut where one more block's rows would not fit
+            const long limit = (160L * 1024 - (long)nsp * O.block * 8) / 128 - 2;
+            std::vector<char> cur(ngrp + 1, 0);
+            for (int b = 0; b < nblk; ++b) {
+                std::vector<char> both = cur;
+                for (int v = brx_ptr[b]; v < brx_ptr[b + 1]; ++v) groups_of_rxn(brx[v], both);
+                if (b > kb.back() && (count(both) > limit || b - kb.back() >= 2 * fuse)) {
+                    kb.push_back(b);
+                    std::fill(cur.begin(), cur.end(), 0);
+                    for (int v = brx_ptr[b]; v < brx_ptr[b + 1]; ++v) groups_of_rxn(brx[v], cur);
+                } else {
+                    cur = both;
+                }
+            }
+            if (nblk - kb.back() < 2 && kb.size() > 1) kb.pop_back();      // a kernel needs a block per half
+            kb.push_back(nblk);
+        }
+        const int nker = (int)kb.size() - 1;
+        // two halves: the blocks of a kernel are cut where the halves' estimated times meet
+        // (a visit ~ cost_visit, a Jacobian entry of the output phase ~ cost_entry)
+        for (int i = 0; i < nker; ++i) {
+            const int b0 = kb[i], b1 = kb[i + 1];
+            int bm = b1;
+            if (halves == 2) {
+                std::vector<double> cost;
+                double tot = 0.0;
+                for (int b = b0; b < b1; ++b) {
+                    cost.push_back(O.cost_visit * (brx_ptr[b + 1] - brx_ptr[b]) + O.cost_entry * nsp * (brow_ptr[b + 1] - brow_ptr[b]));
+                    tot += cost.back();
+                }
+                double acc = 0.0;
+                bm = b0 + 1;
+                for (int b = b0; b < b1 - 1; ++b) {
+                    acc += cost[b - b0];
+                    bm = b + 1;
+                    if (acc >= 0.5 * tot) {
+                        if (acc - 0.5 * tot > 0.5 * cost[b - b0] && b > b0) bm = b;
+                        break;
+                    }
+                }
+                bm = std::min(std::max(bm, b0 + 1), b1 - 1);
+            }
+            km.push_back(bm);
+        }
+        // rate kernels: reaction ranges whose K_c rows fit the LDS (next to the concentration columns, if those
+        // are in LDS), at most rate_groups groups each
+        long rlimit = (160L * 1024 - (O.rate_c_lds ? (long)nsp * O.rate_block * 8 : 0) - 2048) / 128;
+        if (O.rate_groups > 0 && O.rate_groups < rlimit) rlimit = O.rate_groups;
+        std::vector<int32_t> rb{0};
+        {
+            std::vector<char> cur(ngrp + 1, 0);
+            for (int i = 0; i < nrxn; ++i) {
+                std::vector<char> both = cur;
+                groups_of_rxn(i, both);
+                if (i > rb.back() && count(both) > rlimit) {
+                    rb.push_back(i);
+                    std::fill(cur.begin(), cur.end(), 0);
+                    groups_of_rxn(i, cur);
+                } else {
+                    cur = both;
+                }
+            }
+            rb.push_back(nrxn);
+        }
+        o += "constexpr int NKER = " + std::to_string(nker) + ", NRATE = " + std::to_string(rb.size() - 1) + ";\n";
+        arr_i("KER_B", kb, 1);
+        arr_i("KER_BM", km, 1);
+        arr_i("RATE_R", rb, 1);
+        if (plan_out) { plan_out->n_row_kernels = nker; plan_out->n_rate_kernels = (int)rb.size() - 1; plan_out->n_pre = npre; plan_out->n_blocks = nblk; plan_out->n_visits = (int)brx.size(); }
+    }
     o += "}  // namespace pjs\n";
     return o;
 }

@@ -22,7 +22,11 @@ enum { F_REV = 1, F_THD = 2, F_PDEP = 4, F_LOW = 8, F_HIGH = 16, F_TROE = 32,
        F_EFFTYPE = 4096,   // [M] carries enhanced efficiencies -> b_i acts on every column
        F_COLLIDER = 8192,  // falloff with a specific collider species
        F_LASTQ = 16384,    // the one reaction whose d/dT survives in J_nplusone (quirk)
-       F_CHEB = 32768 };   // blob flag again: Chebyshev rate expression (rate_subs.py:149-251)
+       F_CHEB = 32768,     // blob flag again: Chebyshev rate expression (rate_subs.py:149-251)
+       // derived on the host: general stoichiometry -- a fractional coefficient (mech_interpret.py:300-318,
+       // 398-416; rate form pow(C, nu), rate_subs.py:634-658) or more than three molecules on a side: the
+       // reaction carries (species, nu) factor lists instead of molecule slots
+       F_GEN = 65536 };
 enum { IA_FLAGS, IA_REAC_PTR, IA_REAC_SP, IA_PROD_PTR, IA_PROD_SP, IA_NET_PTR,
        IA_NET_SP, IA_EFF_PTR, IA_EFF_SP, IA_PLOG_PTR, IA_KC_PTR, IA_PDEP_SP,
        IA_REV_IDX, IA_PRES_IDX, IA_SEEN, IA_CHEB_PTR, IA_COUNT };
@@ -32,11 +36,12 @@ enum { DA_MW, DA_TMID, DA_LO, DA_HI, DA_A, DA_B, DA_E, DA_REAC_NU, DA_PROD_NU,
 
 // ---- record widths ----
 constexpr int SPW = 18;   // species: invW, W, tmid, w=W/W_N, lo[7], hi[7]
-constexpr int RIW = 20;   // reaction ints
+constexpr int RIW = 23;   // reaction ints
 constexpr int RDW = 16;   // reaction doubles
 enum { RI_FLAGS, RI_R0, RI_R1, RI_R2, RI_P0, RI_P1, RI_P2, RI_EFF_PTR, RI_EFF_CNT,
        RI_COLLIDER, RI_KC_PTR, RI_KC_CNT, RI_PLOG_PTR, RI_PLOG_CNT, RI_GBASE,
-       RI_NET_PTR, RI_NET_CNT, RI_ORIG, RI_REV_IDX, RI_PRES_IDX };
+       RI_NET_PTR, RI_NET_CNT, RI_ORIG, RI_REV_IDX, RI_PRES_IDX,
+       RI_GEN_PTR, RI_GEN_NR, RI_GEN_NP };   // F_GEN: factors gen_sp/gen_nu[GEN_PTR ..], NR reactant then NP product factors
 enum { RD_LNA, RD_B, RD_TA, RD_SGN, RD_NR, RD_NP, RD_LNPREF, RD_LNAR, RD_B0, RD_E0,
        RD_B04, RD_TRA, RD_T3, RD_T1, RD_T2, RD_ANM1 };
 constexpr int EFF_INL = 8;  // enhanced colliders held inline in the field-major tables
@@ -81,7 +86,10 @@ struct VMap {
 enum { SC_H, SC_HP, SC_HQ, SC_SCP, SC_SJT, SC_COUNT };
 
 // one term of the scatter phase: tile[tgt] += nu * V[src]
-struct Contrib { int src, tgt, nu; bool dense; };
+struct Contrib { int src, tgt; double nu; bool dense; };
+// nu of a scatter term as a 4-bit code: whole numbers -4..3 are codes 0..7 (value = code - 4), anything else
+// (fractional or larger net coefficients) is one of up to NUTAB_N table entries, codes 8..15
+constexpr int NUTAB_N = 8;
 
 // Conflict-free scatter schedule for NW wavefronts x IL item lanes: every tile
 // target is owned by one wavefront; within a round the IL lanes of a wavefront
@@ -89,7 +97,7 @@ struct Contrib { int src, tgt, nu; bool dense; };
 // no barrier.  Dense-vector terms come first (rates-only launches stop there).
 struct Schedule {
     int NW = 0, IL = 0;
-    std::vector<uint32_t> codes;       // [wave][round][il]: src | tgt << 13 | (nu + 4) << 29
+    std::vector<uint32_t> codes;       // [wave][round][il]: src | tgt << 13 | nu code << 28
     int off[16] = {0}, rounds[16] = {0}, rounds_dense[16] = {0};
     // split targets: final slot, first partial slot, number of partials (consecutive slots)
     std::vector<int32_t> fin_tgt, fin_part, fin_cnt;
@@ -109,16 +117,13 @@ struct Programs {
     std::vector<double> cheb;      // Chebyshev records, back to back
     std::vector<int32_t> net_sp;   // per-reaction net list
     std::vector<double> net_nu;
+    std::vector<int32_t> gen_sp;   // F_GEN reactions: (species, nu) factors, reactants then products
+    std::vector<double> gen_nu;
+    double nutab[NUTAB_N] = {0, 0, 0, 0, 0, 0, 0, 0};   // net coefficients outside -4..3 / fractional (scatter codes 8..)
+    int n_nutab = 0;
     // P3: per species gather over reactions (global copy: k_spec_rates)
     std::vector<int32_t> sp_ptr, sp_rxn;
     std::vector<double> sp_nu;
-    // LDS-resident program (staged once per workgroup), 32-bit words:
-    //   p4en[nsp*(nsp-1)]  entry (k + nsp*j, k < nsp incl. last species): (first_batch << 8) | n_batches
-    //   p4c [2*batches]    4 codes per batch, code = (V slot << 3) | (nu + 4), pad = (ONE << 3) | 4
-    //   p3en[nsp]          species: (first_batch << 8) | n_batches
-    //   p3c [2*batches]    code = (reaction << 3) | (nu + 4), pad = reaction 0, nu 0
-    std::vector<uint32_t> prog;
-    int p4en = 0, p4c = 0, p3en = 0, p3c = 0;
     int lastq_rxn = -1;            // device index of the F_LASTQ reaction
     std::vector<Contrib> contribs;
     // field-major ("SoA") copies of the reaction records for the table-driven kernel:
@@ -145,8 +150,20 @@ bool build_schedule(Programs& p, int NW, int IL, Schedule& out);
 uint64_t programs_hash(const Programs& p);
 // Mechanism constants as a C++ header (constexpr arrays) for pj_lane.hip.
 std::string emit_spec_header(const Programs& p);
-// Row-block partition + scratch numbering for pj_rows.hip, appended to that header.
-std::string emit_rows_tables(const Programs& p, int budget);
+// Row-block partition + hand-over numbering for pj_rblk.hip, appended to that header.
+// plan_opts: also append the kernel plan of a pj_rblk.hip library (NKER, KER_B, KER_BM, NRATE, RATE_R): which
+// row blocks each row kernel takes (and where its two lane groups meet), which reactions each rate kernel takes.
+struct RblkPlanOpts {
+    int fuse = 13;              // row blocks per kernel and lane group at most
+    int block = 256;            // states per workgroup of the row kernels
+    int halves = 1;             // lane groups per workgroup (2: on the same states, different row blocks)
+    int rate_block = 256;       // states per workgroup of the rate kernels
+    int rate_c_lds = 0;         // rate kernels keep the concentrations in LDS columns
+    int rate_groups = 0;        // K_c groups per rate kernel at most (0: whatever fits the LDS)
+    double cost_visit = 0.24, cost_entry = 0.06;    // halves balance: time of a visit / of a Jacobian entry (us)
+};
+struct RblkPlan { int n_row_kernels = 0, n_rate_kernels = 0, n_pre = 0, n_blocks = 0, n_visits = 0; };
+std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* plan_opts = nullptr, RblkPlan* plan_out = nullptr);
 
 // Returns false (and sets p.error) when the blob is malformed or uses a
 // feature outside the hot-path scope.

@@ -50,13 +50,8 @@ class Evaluator:
 
     # ---- mechanism-specific state-per-lane kernels ----
     # csrc/pj_lane.hip: the whole Jacobian in one lane's registers (small mechanisms);
-    # csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (the rest);
-    # csrc/pj_rows.hip: its predecessor (rate kernel + row-block kernels through an HBM scratch array),
-    # still the source of the rate-output kernels (pj_spec_rates) of the pj_rblk libraries
+    # csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need + one-pass rate-output kernels (the rest)
     SPEC_MAX_NSP, SPEC_MAX_RXN = 16, 64
-    ROWS_BUDGET = 64          # accumulator doubles per row block (stays inside 256 VGPRs)
-    ROWS_FUSE = 16            # row blocks per kernel
-    ROWS_RATES_PER_PART = 128  # reactions per rate kernel (its coefficient tables sit in LDS)
 
     def spec_kind(self) -> str:
         """Which specialised kernel family specialize(build=True) compiles for this mechanism."""
@@ -67,288 +62,39 @@ class Evaluator:
         small = self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN
         return 'lane' if small and not any(int(f) & (F_SRI | F_CHEB) for f in flags) else 'rblk'
 
-    _SPEC_STEM = {'lane': 'libpj_spec_%016x.so', 'rows': 'libpj_rows_%016x.so', 'fused': 'libpj_fused_%016x.so',
-                  'rblk': 'libpj_rblk_%016x.so'}
-
-    _SPEC_SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rows': ('pj_rows.hip', 'pj_rows_rate.inc', 'pj_rows_block.inc'),
-                     'fused': ('pj_rows.hip', 'pj_rows_rate.inc', 'pj_rows_block.inc'),
-                     'rblk': ('pj_rblk.hip', 'pj_math.h', 'pj_rows.hip', 'pj_rows_rate.inc')}
-    _SPEC_ENV = ('PJ_LANE_FLAGS', 'PJ_ROWS_FLAGS', 'PJ_ROWS_RATES_FLAGS', 'PJ_ROWS_BUDGET', 'PJ_ROWS_FUSE',
-                 'PJ_ROWS_RATES_PER_PART', 'PJ_ROWS_BLOCK', 'PJ_ROWS_RECOMPUTE_KR', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE',
-                 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES', 'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST')
-
     def spec_path(self, kind: str = None, **opts) -> str:
         """File name of a specialised library: mechanism hash + a digest of everything else that shapes the
-        binary (the kernel sources, pj_tables.{h,cpp}, this file with its flags, the build options and
-        the PJ_* environment overrides), so a library built from other sources or with other options is
-        never attached by accident."""
-        import hashlib
-        kind = kind or self.spec_kind()
-        here = os.path.dirname(os.path.abspath(__file__))
-        d = hashlib.sha1(repr((kind, sorted((k, v) for k, v in opts.items() if v is not None),
-                               [(e, os.environ.get(e)) for e in self._SPEC_ENV if os.environ.get(e)])).encode())
-        for f in self._SPEC_SOURCES[kind] + ('pj_tables.h', 'pj_tables.cpp'):
-            with open(os.path.join(here, 'csrc', f), 'rb') as fh:
-                d.update(fh.read())
-        with open(os.path.abspath(__file__).replace('.pyc', '.py'), 'rb') as fh:
-            d.update(fh.read())
-        h = _lib.lib().pj_mech_spec_hash(self._h)
-        stem = self._SPEC_STEM[kind] % h
-        return os.path.join(here, 'spec', stem[:-3] + '_' + d.hexdigest()[:10] + '.so')
+        binary (specbuild.library_path).  None: no sources installed and no prebuilt library of this kind."""
+        from . import specbuild
+        return specbuild.library_path(kind or self.spec_kind(), _lib.lib().pj_mech_spec_hash(self._h), opts)
 
-    def specialize(self, build: bool = False, kind: str = None, **rows_opts) -> bool:
+    def specialize(self, build: bool = False, kind: str = None, **opts) -> bool:
         """Attach (and with build=True compile if missing) the mechanism-specific kernels.
-        kind: 'lane' | 'rows' | 'fused' | None (whatever is there, else the default for the size).
-        'fused' is the single-kernel variant of pj_rows.hip (one translation unit: minutes to
-        compile for a 53-species mechanism; coefficient tables of all reactions must fit the LDS)."""
+        kind: 'lane' | 'rblk' | None (whatever is there, else the default for the size)."""
+        from . import specbuild
         L = _lib.lib()
-        kinds = [kind] if kind else [self.spec_kind()] + [k for k in ('lane', 'rblk', 'fused', 'rows') if k != self.spec_kind()]
-        so = next((self.spec_path(k, **rows_opts) for k in kinds if os.path.exists(self.spec_path(k, **rows_opts))), None)
+        if kind not in (None, 'lane', 'rblk'):
+            raise ValueError("kind: 'lane' or 'rblk'")
+        kinds = [kind] if kind else [self.spec_kind()] + [k for k in ('lane', 'rblk') if k != self.spec_kind()]
+        paths = [self.spec_path(k, **opts) for k in kinds]
+        so = next((q for q in paths if q and os.path.exists(q)), None)
         if so is None:
-            if not build:
+            if not build or paths[0] is None:
                 return False
-            so = self.spec_path(kinds[0], **rows_opts)
+            so = paths[0]
             if kinds[0] == 'lane':
-                self._build_lane(so)
-            elif kinds[0] == 'fused':
-                self._build_fused(so, **rows_opts)
-            elif kinds[0] == 'rblk':
-                self._build_rblk(so, **rows_opts)
+                specbuild.build_lane(L, self._h, so)
             else:
-                self._build_rows(so, **rows_opts)
+                specbuild.build_rblk(L, self._h, self.nsp, so, **opts)
         check(L.pj_mech_attach_spec(self._h, so.encode()))
         self.attached_spec = so
         return True
 
-    def _build_lane(self, so: str):
-        import subprocess
-        L = _lib.lib()
-        here = os.path.dirname(os.path.abspath(__file__))
-        os.makedirs(os.path.dirname(so), exist_ok=True)
-        hdr = so[:-3] + '.h'
-        check(L.pj_mech_emit_spec(self._h, hdr.encode()))
-        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        # reciprocal instead of IEEE division sequences, contraction, no NaN/Inf/-0 special-casing;
-        # NO reassociation (it keeps every product of an accumulation chain live: +40 AGPRs, -5 %);
-        # measured on MI355X against -ffast-math and plain -O3 (DESIGN.md section 6)
-        flags = os.environ.get('PJ_LANE_FLAGS',
-                               '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
-                               '-ffinite-math-only -mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
-        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
-                              ['-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
-                               '-o', so + '.tmp.%d' % os.getpid(), os.path.join(here, 'csrc', 'pj_lane.hip')])
-        os.replace(so + '.tmp.%d' % os.getpid(), so)     # other ranks / processes never see a half-written library
-
-    def _build_fused(self, so: str, budget: int = None, **_):
-        """csrc/pj_rows.hip as ONE kernel (PJR_PART=3): a workgroup of 4 wavefronts per 64-state
-        tile, scratch region per resident workgroup."""
-        import subprocess
-        L = _lib.lib()
-        here = os.path.dirname(os.path.abspath(__file__))
-        os.makedirs(os.path.dirname(so), exist_ok=True)
-        hdr = so[:-3] + '.h'
-        check(L.pj_mech_emit_rows_spec(self._h, hdr.encode(), int(budget or os.environ.get('PJ_ROWS_BUDGET', self.ROWS_BUDGET))))
-        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        flags = os.environ.get('PJ_ROWS_FLAGS',
-                               '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math').split()
-        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
-                              ['-DPJR_PART=3', '-DPJS_HEADER="%s"' % hdr, '-I', os.path.join(here, 'csrc'),
-                               '-o', so + '.tmp.%d' % os.getpid(), os.path.join(here, 'csrc', 'pj_rows.hip')])
-        os.replace(so + '.tmp.%d' % os.getpid(), so)
-
-    def _build_rows(self, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None):
-        """One translation unit per kernel of csrc/pj_rows.hip, compiled in parallel."""
-        import re
-        import shutil
-        import subprocess
-        from concurrent.futures import ThreadPoolExecutor
-        L = _lib.lib()
-        here = os.path.dirname(os.path.abspath(__file__))
-        os.makedirs(os.path.dirname(so), exist_ok=True)
-        hdr = so[:-3] + '.h'
-        budget = int(budget or os.environ.get('PJ_ROWS_BUDGET', self.ROWS_BUDGET))
-        fuse = int(fuse or os.environ.get('PJ_ROWS_FUSE', self.ROWS_FUSE))
-        rpp = int(rates_per_part or os.environ.get('PJ_ROWS_RATES_PER_PART', self.ROWS_RATES_PER_PART))
-        check(L.pj_mech_emit_rows_spec(self._h, hdr.encode(), budget))
-        nblk = int(re.search(r'NBLK = (\d+)', open(hdr).read()).group(1))
-        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        work = so[:-3] + '.obj'
-        os.makedirs(work, exist_ok=True)
-        # lanes per workgroup: the concentration columns (8 NSP bytes per lane) must fit the LDS
-        block = 256 if self.nsp * 256 * 8 <= 150 * 1024 else 128 if self.nsp * 128 * 8 <= 150 * 1024 else 64
-        block = int(os.environ.get('PJ_ROWS_BLOCK', block))
-        # Row kernels rebuild c*k_r from c*k_f and K_c(T) instead of reading it back from the scratch
-        # array (-17 % HBM bytes, +3..6 % on MI355X) when the K_c polynomial table fits the LDS next
-        # to the concentration columns
-        lt_sp = int(re.search(r'LT_SP = (\d+)', open(hdr).read()).group(1))
-        recompute = int(os.environ.get('PJ_ROWS_RECOMPUTE_KR', int(lt_sp * 8 + self.nsp * block * 8 <= 156 * 1024)))
-        base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c',
-                '-DPJS_HEADER="%s"' % hdr, '-DPJR_BLOCK=%d' % block, '-DPJR_C_LDS=%d' % int(self.nsp > 64),
-                '-DPJR_RECOMPUTE_KR=%d' % recompute,
-                '-I', os.path.join(here, 'csrc'), os.path.join(here, 'csrc', 'pj_rows.hip')]
-        # no reassociation anywhere: it makes the compiler keep every product of an accumulation
-        # chain live (AGPR traffic in the row kernels, 0.6 KB of spills per lane in the rate kernels)
-        f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS',
-                                 '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
-                                 '-ffinite-math-only').split()
-        f_rows = os.environ.get('PJ_ROWS_FLAGS',
-                                '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math').split()
-        jobs = [(f_rows + ['-DPJR_PART=0'], 'host.o')]
-        for i, r0 in enumerate(range(0, self.n_fwd, rpp)):
-            jobs.append((f_rates + ['-DPJR_PART=1', '-DPJR_ID=%d' % i, '-DPJR_R0=%d' % r0,
-                                    '-DPJR_R1=%d' % min(self.n_fwd, r0 + rpp)], 'rates%d.o' % i))
-        for i, b0 in enumerate(range(0, nblk, fuse)):
-            jobs.append((f_rows + ['-DPJR_PART=2', '-DPJR_ID=%d' % i, '-DPJR_B0=%d' % b0,
-                                   '-DPJR_B1=%d' % min(nblk, b0 + fuse)], 'rows%d.o' % i))
-        # longest first so the pool drains evenly
-        jobs.sort(key=lambda j: 0 if j[1].startswith('rates') else 1)
-
-        def run(job):
-            subprocess.check_call(base + job[0] + ['-o', os.path.join(work, job[1])])
-        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
-            list(ex.map(run, jobs))
-        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so + '.tmp.%d' % os.getpid()] +
-                              [os.path.join(work, j[1]) for j in jobs])
-        os.replace(so + '.tmp.%d' % os.getpid(), so)
-        shutil.rmtree(work, ignore_errors=True)
-
-    RBLK_BUDGET = 56          # accumulator doubles per row block of pj_rblk.hip (4 dense + non-zero S per row)
-    RBLK_FUSE = 13            # row blocks per kernel (at most)
-    RBLK_FUSE_LARGE = 13      # ... for mechanisms whose concentration columns leave little LDS for the K_c rows
-
-    def _build_rblk(self, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=()):
-        """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the
-        falloff / PLOG reactions), linked with the rate-output kernels of csrc/pj_rows.hip
-        (-DPJR_RATES_LIB: pj_spec_rates).  One translation unit per kernel, compiled in parallel."""
-        import re
-        import shutil
-        import subprocess
-        from concurrent.futures import ThreadPoolExecutor
-        L = _lib.lib()
-        here = os.path.dirname(os.path.abspath(__file__))
-        os.makedirs(os.path.dirname(so), exist_ok=True)
-        hdr = so[:-3] + '.h'
-        budget = int(budget or os.environ.get('PJ_RBLK_BUDGET', self.RBLK_BUDGET))
-        fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', self.RBLK_FUSE if self.nsp <= 64 else self.RBLK_FUSE_LARGE))
-        rpp = int(rates_per_part or os.environ.get('PJ_ROWS_RATES_PER_PART', self.ROWS_RATES_PER_PART))
-        check(L.pj_mech_emit_rows_spec(self._h, hdr.encode(), budget))
-        t = open(hdr).read()
-        nblk = int(re.search(r'NBLK = (\d+)', t).group(1))
-        npre = int(re.search(r'NPRE = (\d+)', t).group(1))
-        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        work = so[:-3] + '.obj'
-        os.makedirs(work, exist_ok=True)
-        # lanes per workgroup: the concentration columns (8 NSP bytes per lane) + the K_c table must fit the LDS
-        # (a kernel stages only the K_c rows of its own reactions: at most 16 doubles per visit)
-        block = 256 if self.nsp * 256 * 8 <= 112 * 1024 else 128 if self.nsp * 128 * 8 <= 120 * 1024 else 64
-        block = int(os.environ.get('PJ_RBLK_BLOCK', block))
-        c_lds = int(self.nsp > 64)
-        common = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr,
-                  '-I', os.path.join(here, 'csrc')]
-        f_rows = os.environ.get('PJ_RBLK_FLAGS',
-                                '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
-                                '-mllvm -amdgpu-schedule-relaxed-occupancy=1').split()
-        f_rates = os.environ.get('PJ_ROWS_RATES_FLAGS',
-                                 '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math '
-                                 '-ffinite-math-only').split()
-        # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on
-        # the same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
-        halves = int(os.environ.get('PJ_RBLK_HALVES', 2 if block == 128 else 1))
-        # (the 111-species kernels are short of registers: without the one-visit look-ahead of the K_c rows and
-        # concentrations they spill half as much, and spill reloads queue behind the Jacobian stores: -3 %)
-        rblk = common + f_rows + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves] + \
-            (['-DPJQ_CONC_AHEAD=0', '-DPJQ_KC_AHEAD=0'] if halves == 2 else []) + \
-            list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [os.path.join(here, 'csrc', 'pj_rblk.hip')]
-        rows = common + ['-DPJR_BLOCK=%d' % (256 if self.nsp * 256 * 8 <= 150 * 1024 else 128),
-                         '-DPJR_C_LDS=%d' % c_lds, '-DPJR_RATES_LIB', os.path.join(here, 'csrc', 'pj_rows.hip')]
-        jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o'), (rows + f_rows + ['-DPJR_PART=0'], 'rhost.o')]
-        if npre:
-            jobs.append((rblk + ['-DPJQ_PART=1'], 'pre.o'))
-        # row kernels of (nearly) equal block counts, at most `fuse` blocks each
-        nker = (nblk + fuse * halves - 1) // (fuse * halves)
-        bounds = [nblk * i // nker for i in range(nker + 1)]
-
-        def table(name):
-            m = re.search(r'constexpr int %s\[\d+\]\[1\] = \{(.*?)\};\n' % name, t, re.S)
-            return [int(x) for x in re.findall(r'\{(-?\d+),\}', m.group(1))]
-        if halves == 2:
-            # a kernel stages the K_c rows of all its blocks (128 bytes each) next to the concentration
-            # columns: kernels are cut where the rows of one more block would not fit the LDS any more
-            ri = [[int(x) for x in r.split(',') if x.strip()] for r in re.findall(
-                r'\{([^{}]*)\}', re.search(r'constexpr int RI\[\d+\]\[\d+\] = \{(.*?)\};\n', t, re.S).group(1))]
-            enum = re.search(r'enum \{ RI_FLAGS,(.*?)\};', open(os.path.join(here, 'csrc', 'pj_tables.h')).read(), re.S).group(1)
-            names = ['RI_FLAGS'] + [x.strip() for x in enum.replace('\n', ' ').split(',') if x.strip()]
-            kp, kc = names.index('RI_KC_PTR'), names.index('RI_KC_CNT')
-            rxp, brx = table('BLK_RX_PTR'), table('BLK_RX')
-            limit = (160 * 1024 - self.nsp * block * 8) // 128 - 2
-            bounds, cur = [0], set()
-            for b in range(nblk):
-                g = set()
-                for v in range(rxp[b], rxp[b + 1]):
-                    r = ri[brx[v]]
-                    if r[0] & 1:
-                        g.update(range(r[kp], r[kp] + r[kc]))
-                if b > bounds[-1] and (len(cur | g) > limit or b - bounds[-1] >= 2 * fuse):
-                    bounds.append(b)
-                    cur = set()
-                cur |= g
-            if nblk - bounds[-1] < 2 and len(bounds) > 1:        # a kernel needs a block per half
-                bounds.pop()
-            bounds.append(nblk)
-            nker = len(bounds) - 1
-        # two halves: the blocks of a kernel are cut where the halves' estimated times meet (a visit
-        # ~0.24 us, a Jacobian entry of the output phase ~0.06 us: DESIGN.md section 5c)
-        mids = []
-        if halves == 2:
-            rx, rw = table('BLK_RX_PTR'), table('BLK_ROW_PTR')
-            cv, co = (float(x) for x in os.environ.get('PJ_RBLK_HALF_COST', '0.24,0.06').split(','))
-            cost = [cv * (rx[b + 1] - rx[b]) + co * self.nsp * (rw[b + 1] - rw[b]) for b in range(nblk)]
-            for i in range(nker):
-                b0, b1 = bounds[i], bounds[i + 1]
-                tot, acc, bm = sum(cost[b0:b1]), 0.0, b0 + 1
-                for b in range(b0, b1 - 1):
-                    acc += cost[b]
-                    bm = b + 1
-                    if acc >= 0.5 * tot:
-                        if acc - 0.5 * tot > 0.5 * cost[b] and b > b0:
-                            bm = b
-                        break
-                mids.append(min(max(bm, b0 + 1), b1 - 1))
-        mid = lambda i: ['-DPJQ_BM=%d' % mids[i]] if halves == 2 else []
-        # each row kernel twice: with pair stores (SoA output, whole workgroups: the fast path) and general
-        pair_modes = [int(x) for x in os.environ.get('PJ_RBLK_PAIR_MODES', '1,0').split(',')]
-        for i in range(nker):
-            for pair in pair_modes:
-                jobs.append((rblk + mid(i) + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
-                                     '-DPJQ_B1=%d' % bounds[i + 1], '-DPJQ_FIRST=%d' % (i == 0),
-                                     '-DPJQ_LAST=%d' % (i == nker - 1), '-DPJQ_PAIR=%d' % pair], 'rblk%d_%d.o' % (i, pair)))
-            # ... and as w = J v (the Jacobian consumed in registers)
-            jobs.append((rblk + mid(i) + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_B0=%d' % bounds[i],
-                                 '-DPJQ_B1=%d' % bounds[i + 1], '-DPJQ_FIRST=%d' % (i == 0),
-                                 '-DPJQ_LAST=%d' % (i == nker - 1), '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % i))
-        for i, r0 in enumerate(range(0, self.n_fwd, rpp)):
-            jobs.append((rows + f_rates + ['-DPJR_PART=1', '-DPJR_ID=%d' % i, '-DPJR_R0=%d' % r0,
-                                           '-DPJR_R1=%d' % min(self.n_fwd, r0 + rpp)], 'rates%d.o' % i))
-        # longest first so the pool drains evenly
-        jobs.sort(key=lambda j: 0 if j[1].startswith('rates') else 1 if j[1].startswith('rblk') else 2)
-
-        def run(job):
-            subprocess.check_call(job[0] + ['-o', os.path.join(work, job[1])])
-        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
-            list(ex.map(run, jobs))
-        tmp = so + '.tmp.%d' % os.getpid()
-        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] +
-                              [os.path.join(work, j[1]) for j in jobs])
-        os.replace(tmp, so)
-        shutil.rmtree(work, ignore_errors=True)
-
     @property
     def spec_kernel(self) -> str:
-        """'pj_lane' / 'pj_rows' for the attached specialisation, '' if none."""
+        """'pj_lane' / 'pj_rblk' for the attached specialisation, '' if none."""
         so = os.path.basename(self.attached_spec or '')
-        return ('pj_lane' if so.startswith('libpj_spec_') else 'pj_rows' if so.startswith('libpj_rows_')
-                else 'pj_rblk' if so.startswith('libpj_rblk_')
-                else 'pj_fused' if so.startswith('libpj_fused_') else '')
+        return 'pj_lane' if so.startswith('libpj_spec_') else 'pj_rblk' if so.startswith('libpj_rblk_') else ''
 
     @property
     def has_spec(self) -> bool:

@@ -1,0 +1,161 @@
+"""Build recipes of the mechanism-specific kernel libraries (hipcc; the counterpart of pyJac's libgen,
+pyjac/libgen/libgen.py:330-420, with the difference that what is compiled is one fixed source per kernel
+family against a header of constexpr tables, not emitted code).
+
+The text of this file, of the kernel sources and of pj_tables.{h,cpp} is part of a library's file name
+(source_digest): a library built from other sources or with other flags is never attached by accident.
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SPEC_DIR = os.path.join(HERE, 'spec')
+
+STEM = {'lane': 'libpj_spec_%016x', 'rblk': 'libpj_rblk_%016x'}
+SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rblk': ('pj_rblk.hip', 'pj_math.h', 'pj_rate_pre.inc')}
+# environment overrides that shape a binary (experiments): part of the digest
+ENV = ('PJ_LANE_FLAGS', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE', 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES',
+       'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST', 'PJ_RBLK_RATE_GROUPS', 'PJ_RBLK_RATE_DEFINES')
+
+# reciprocal instead of IEEE division sequences, contraction, no -0 special-casing; NO reassociation (it keeps
+# every product of an accumulation chain live: +40 AGPRs, -5 %); measured on MI355X against -ffast-math and
+# plain -O3
+LANE_FLAGS = ('-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math -ffinite-math-only '
+              '-mllvm -amdgpu-schedule-relaxed-occupancy=1')
+RBLK_FLAGS = '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math -mllvm -amdgpu-schedule-relaxed-occupancy=1'
+
+RBLK_BUDGET = 56          # accumulator doubles per row block of pj_rblk.hip (4 dense + non-zero S per row)
+RBLK_FUSE = 13            # row blocks per kernel and lane group (at most)
+
+_src_digest = {}
+
+
+def source_digest(kind: str):
+    """sha1 of everything but the mechanism and the options that shapes a library of `kind`; None when the
+    kernel sources are not installed (a deployment that ships prebuilt libraries only)."""
+    if kind not in _src_digest:
+        d = hashlib.sha1()
+        try:
+            for f in SOURCES[kind] + ('pj_tables.h', 'pj_tables.cpp'):
+                with open(os.path.join(CSRC, f), 'rb') as fh:
+                    d.update(fh.read())
+            with open(os.path.abspath(__file__).replace('.pyc', '.py'), 'rb') as fh:
+                d.update(fh.read())
+            _src_digest[kind] = d.hexdigest()
+        except OSError:
+            _src_digest[kind] = None
+    return _src_digest[kind]
+
+
+def library_path(kind: str, mech_hash: int, opts: dict):
+    """File name of the library of a mechanism: hash of the mechanism tables + digest of the sources, this
+    file, the options and the PJ_* overrides.  Without the sources: the newest prebuilt library of the
+    mechanism and kind (or None)."""
+    stem = STEM[kind] % mech_hash
+    src = source_digest(kind)
+    if src is None:
+        import glob
+        found = sorted(glob.glob(os.path.join(SPEC_DIR, stem + '_*.so')), key=os.path.getmtime)
+        return found[-1] if found else None
+    d = hashlib.sha1(repr((kind, src, sorted((k, v) for k, v in opts.items() if v is not None),
+                           [(e, os.environ.get(e)) for e in ENV if os.environ.get(e)])).encode())
+    return os.path.join(SPEC_DIR, stem + '_' + d.hexdigest()[:10] + '.so')
+
+
+def _hipcc():
+    return os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+def _finish(tmp_so, tmp_hdr, work, so):
+    """Publish a finished build: header first, library last, both by rename (other ranks / processes never see
+    a half-written file; every process builds in its own work directory)."""
+    os.replace(tmp_hdr, so[:-3] + '.h')
+    os.replace(tmp_so, so)
+    if work:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def build_lane(L, handle, so: str):
+    """csrc/pj_lane.hip: the whole Jacobian in one lane's registers (small mechanisms); seconds."""
+    from ._lib import check
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    hdr = so[:-3] + '.%d.h' % os.getpid()
+    check(L.pj_mech_emit_spec(handle, hdr.encode()))
+    flags = os.environ.get('PJ_LANE_FLAGS', LANE_FLAGS).split()
+    tmp = so + '.tmp.%d' % os.getpid()
+    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
+                          ['-DPJS_HEADER="%s"' % hdr, '-I', CSRC, '-o', tmp, os.path.join(CSRC, 'pj_lane.hip')])
+    _finish(tmp, hdr, None, so)
+
+
+def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=()):
+    """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the falloff / PLOG
+    reactions) and the one-pass rate-output kernels (k_rate: pj_spec_rates).  One translation unit per kernel,
+    compiled in parallel; which row blocks / reactions a kernel takes is planned by the C side
+    (pj_mech_emit_rblk_spec) and travels in the header.  rates_per_part: K_c groups per rate kernel at most."""
+    from ._lib import check
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    pid = os.getpid()
+    hdr = so[:-3] + '.%d.h' % pid
+    work = so[:-3] + '.%d.obj' % pid
+    os.makedirs(work, exist_ok=True)
+    budget = int(budget or os.environ.get('PJ_RBLK_BUDGET', RBLK_BUDGET))
+    fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', RBLK_FUSE))
+    # states per workgroup of the row kernels: the concentration columns (8 NSP bytes per lane) + the K_c rows of
+    # the kernel's reactions must fit the LDS
+    block = 256 if nsp * 256 * 8 <= 112 * 1024 else 128 if nsp * 128 * 8 <= 120 * 1024 else 64
+    block = int(os.environ.get('PJ_RBLK_BLOCK', block))
+    # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on the
+    # same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
+    halves = int(os.environ.get('PJ_RBLK_HALVES', 2 if block == 128 else 1))
+    c_lds = int(nsp > 64)
+    # rate kernels: concentrations in registers up to 64 species (256 states per workgroup), in LDS columns beyond
+    # (128 states, two lane groups)
+    r_clds = int(nsp > 64)
+    r_block, r_halves = (128, 2) if r_clds else (256, 1)
+    cv, ce = (float(x) for x in os.environ.get('PJ_RBLK_HALF_COST', '0,0').split(','))
+    counts = (ctypes.c_int * 5)()
+    check(L.pj_mech_emit_rblk_spec(handle, hdr.encode(), budget, fuse, block, halves, r_block, r_clds,
+                                   int(rates_per_part or os.environ.get('PJ_RBLK_RATE_GROUPS', 0)), cv, ce, counts))
+    nker, nrate, npre = counts[0], counts[1], counts[2]
+    common = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr, '-I', CSRC]
+    flags = os.environ.get('PJ_RBLK_FLAGS', RBLK_FLAGS).split()
+    src = os.path.join(CSRC, 'pj_rblk.hip')
+    # (the 111-species kernels are short of registers: without the one-visit look-ahead of the K_c rows and
+    # concentrations they spill half as much, and spill reloads queue behind the Jacobian stores: -3 %)
+    rblk = common + flags + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves] + \
+        (['-DPJQ_CONC_AHEAD=0', '-DPJQ_KC_AHEAD=0'] if halves == 2 else []) + \
+        list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [src]
+    rate = common + flags + ['-DPJQ_BLOCK=%d' % r_block, '-DPJQ_C_LDS=%d' % r_clds, '-DPJQ_HALVES=%d' % r_halves] + \
+        list(defines) + os.environ.get('PJ_RBLK_RATE_DEFINES', '').split() + [src]
+    jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
+    if npre:
+        jobs.append((rblk + ['-DPJQ_PART=1'], 'pre.o'))
+    # each row kernel three times: with pair stores (SoA output, whole workgroups: the fast path), general,
+    # and as w = J v (the Jacobian consumed in registers)
+    pair_modes = [int(x) for x in os.environ.get('PJ_RBLK_PAIR_MODES', '1,0').split(',')]
+    for i in range(nker):
+        for pair in pair_modes:
+            jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=%d' % pair], 'rblk%d_%d.o' % (i, pair)))
+        jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % i))
+    for i in range(nrate):
+        for full in (0, 1):
+            jobs.append((rate + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % i, '-DPJQ_FULL=%d' % full], 'rate%d_%d.o' % (i, full)))
+    # longest first so the pool drains evenly
+    jobs.sort(key=lambda j: 0 if j[1].startswith('rate') else 1 if j[1].startswith('rblk') else 2)
+
+    def run(job):
+        subprocess.check_call(job[0] + ['-o', os.path.join(work, job[1])])
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    tmp = so + '.tmp.%d' % pid
+    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] +
+                          [os.path.join(work, j[1]) for j in jobs])
+    _finish(tmp, hdr, work, so)

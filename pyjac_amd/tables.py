@@ -173,8 +173,6 @@ def build_tables(mech: Mechanism) -> MechTables:
                 raise ValueError('Chebyshev reaction combined with another pressure dependence')
         if rx.thd_body_eff:
             fl |= F_HAS_EFF
-        if any(not float(n).is_integer() for n in rx.reac_nu + rx.prod_nu):
-            raise NotImplementedError('fractional stoichiometric coefficients')
         ia[IA_FLAGS].append(fl)
         da[DA_A].append(rx.A)
         da[DA_B].append(rx.b)

@@ -1,0 +1,51 @@
+"""Compile csrc/pj_rblk.hip with g++ through tests/emu/hip_shim.h (one "thread" per workgroup)
+so the CPU suite can run the state-per-lane row-block kernels against the oracle.
+Test infrastructure only."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
+
+
+def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int = 128, c_lds: int = 0,
+               opt: str = '-O1', defines=()) -> str:
+    """csrc/pj_rblk.hip for the host: row blocks that rebuild their rates + falloff / PLOG pre-pass (k_pre,
+    k_rblk, also as w = J v) and the rate-output kernels (k_rate, one per `rates_per_part` reactions, with and
+    without the per-reaction outputs), the way Evaluator._build_rblk links them."""
+    work = out + '.obj'
+    os.makedirs(work, exist_ok=True)
+    t = open(hdr).read()
+    nblk = int(re.search(r'NBLK = (\d+)', t).group(1))
+    nrxn = int(re.search(r'NRXN = (\d+)', t).group(1))
+    npre = int(re.search(r'NPRE = (\d+)', t).group(1))
+    common = ['g++', opt, '-std=c++17', '-fPIC', '-c', '-x', 'c++', '-DPJR_HOST_EMU', '-DPJS_HEADER="%s"' % hdr] + \
+        list(defines) + ['-I', HERE, '-I', CSRC]
+    rblk = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % c_lds, os.path.join(CSRC, 'pj_rblk.hip')]
+    jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
+    if npre:
+        jobs.append((rblk + ['-DPJQ_PART=1'], 'pre.o'))
+    starts = list(range(0, nblk, blocks_per_part))
+    for n, b0 in enumerate(starts):
+        jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % n, '-DPJQ_B0=%d' % b0,
+                             '-DPJQ_B1=%d' % min(nblk, b0 + blocks_per_part), '-DPJQ_FIRST=%d' % (n == 0),
+                             '-DPJQ_LAST=%d' % (n == len(starts) - 1), '-DPJQ_PAIR=0'], 'rblk%d.o' % n))
+        jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % n, '-DPJQ_B0=%d' % b0,
+                             '-DPJQ_B1=%d' % min(nblk, b0 + blocks_per_part), '-DPJQ_FIRST=%d' % (n == 0),
+                             '-DPJQ_LAST=%d' % (n == len(starts) - 1), '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % n))
+    rstarts = list(range(0, nrxn, rates_per_part))
+    for n, r0 in enumerate(rstarts):
+        for full in (0, 1):
+            jobs.append((rblk + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % n, '-DPJQ_R0=%d' % r0, '-DPJQ_R1=%d' % min(nrxn, r0 + rates_per_part),
+                                 '-DPJQ_FIRST=%d' % (n == 0), '-DPJQ_LAST=%d' % (n == len(rstarts) - 1),
+                                 '-DPJQ_FULL=%d' % full], 'rate%d_%d.o' % (n, full)))
+
+    def run(j):
+        subprocess.check_call(j[0] + ['-o', os.path.join(work, j[1])])
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, jobs))
+    subprocess.check_call(['g++', '-shared', '-o', out] + [os.path.join(work, j[1]) for j in jobs])
+    return out

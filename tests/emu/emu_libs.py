@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-import build_rows_emu
+import build_emu
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _cache = {}
@@ -23,7 +23,7 @@ def rblk_emu_lib(name, budget, tmp, **kw):
         ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
         hdr = os.path.join(d, '%s_q%d.h' % (name, budget))
         _lib.check(_lib.lib().pj_mech_emit_rows_spec(ev._h, hdr.encode(), budget))
-        so = build_rows_emu.build_rblk(hdr, os.path.join(d, 'lib%s_q%d_%d.so' % (name, budget, len(_cache))), **kw)
+        so = build_emu.build_rblk(hdr, os.path.join(d, 'lib%s_q%d_%d.so' % (name, budget, len(_cache))), **kw)
         L = ctypes.CDLL(so)
         L.pj_spec_jacobian.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp,
                                        ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]

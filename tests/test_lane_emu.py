@@ -14,7 +14,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'emu'))
 from conftest import MECHS, jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err  # noqa: E402
-import build_rows_emu  # noqa: E402
+import build_emu  # noqa: E402
 import pyjac_amd  # noqa: E402
 from pyjac_amd import _lib, synth  # noqa: E402
 
@@ -28,8 +28,8 @@ def _lane_emu(mech, tmp, tag):
     _lib.check(_lib.lib().pj_mech_emit_spec(ev._h, hdr.encode()))
     so = os.path.join(tmp, 'liblane_%s.so' % tag)
     subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-x', 'c++', '-DPJL_HOST_EMU',
-                           '-DPJL_BLOCK=1', '-DPJS_HEADER="%s"' % hdr, '-I', build_rows_emu.HERE,
-                           '-I', build_rows_emu.CSRC, os.path.join(build_rows_emu.CSRC, 'pj_lane.hip'), '-o', so])
+                           '-DPJL_BLOCK=1', '-DPJS_HEADER="%s"' % hdr, '-I', build_emu.HERE,
+                           '-I', build_emu.CSRC, os.path.join(build_emu.CSRC, 'pj_lane.hip'), '-o', so])
     L = ctypes.CDLL(so)
     cl, ci, vp = ctypes.c_long, ctypes.c_int, ctypes.c_void_p
     L.pj_spec_jacobian.argtypes = [cl, _dp, _dp, cl, cl, _dp, cl, cl, ci, vp]
@@ -104,7 +104,7 @@ def test_random_mechanisms_lane_and_rows(seed, tmp_path):
     # the row-block kernels on the same mechanism, fine partition
     hdr = os.path.join(str(tmp_path), 'rows%d.h' % seed)
     _lib.check(_lib.lib().pj_mech_emit_rows_spec(ev._h, hdr.encode(), 14))
-    so = build_rows_emu.build(hdr, os.path.join(str(tmp_path), 'librows%d.so' % seed), blocks_per_part=3,
+    so = build_emu.build(hdr, os.path.join(str(tmp_path), 'librows%d.so' % seed), blocks_per_part=3,
                               rates_per_part=9, defines=('-DPJR_RECOMPUTE_KR=1',))
     R = ctypes.CDLL(so)
     R.pj_spec_jacobian.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp, ctypes.c_long,

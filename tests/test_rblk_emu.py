@@ -1,0 +1,160 @@
+"""CPU checks of the state-per-lane row-block kernels (csrc/pj_rblk.hip): the kernel source is compiled with
+g++ through tests/emu/hip_shim.h (one thread per workgroup) and compared with the oracle and the committed
+golden vectors.  Covers the pre-pass / row-kernel split, the hand-over numbering, the row-block partition at
+several budgets, the rate-output kernels (one and several reaction ranges) and the fused w = J v -- everything
+but the GPU's memory system."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'emu'))
+from conftest import jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err  # noqa: E402
+from emu_libs import rblk_emu_lib, run_jacobian as _run  # noqa: E402
+from pyjac_amd import synth  # noqa: E402
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _rblk_emu_lib(name, budget, tmp, **kw):
+    return rblk_emu_lib(name, budget, tmp, **kw)
+
+
+@pytest.mark.parametrize('name,budget,kw', [
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=1000)),
+    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
+])
+def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
+    """k_rate (pj_spec_rates of the row-block library): conc, fwd, rev, pres_mod, spec_rates handed from
+    rate kernel to rate kernel, dydt -- with every array requested (the kernels with per-reaction outputs) and
+    with dydt only (the lean kernels; omega_k then travels through the library's scratch array)."""
+    from oracle.oracle import Oracle
+    ev, L = _rblk_emu_lib(name, budget, str(tmp_path), **kw)
+    L.pj_spec_rates.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long] + [_dp] * 6 + [ctypes.c_void_p]
+    tab = tables(name)
+    orc = Oracle(tab)
+    n, nsp = 300, ev.nsp
+    pres, y = synth.dist_b(n, nsp, seed=9, Tlo=600, Thi=2600)
+    y = np.ascontiguousarray(y)
+    y_aos = np.ascontiguousarray(y.T)
+    o = [orc.eval_all(float(pres[s]), y_aos[s]) for s in range(n)]
+    g = {k: np.array([x[k] for x in o]) for k in ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt')}
+    rows = dict(conc=nsp, fwd=ev.n_fwd, rev=max(ev.n_rev, 1), pres_mod=max(ev.n_pres_mod, 1), spec_rates=nsp, dy=nsp)
+    bufs = {k: np.full((r, n), np.nan) for k, r in rows.items()}
+    P = lambda a: a.ctypes.data_as(_dp)
+    assert L.pj_spec_rates(n, P(pres), P(y), n, 1, *[P(bufs[k]) for k in rows], None) == 0
+    for k, cols in (('conc', nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
+        if cols:
+            assert not np.isnan(bufs[k][:cols]).any(), k
+            mx, _ = thresholded_rel_err(bufs[k].T[:, :cols], g[k][:, :cols])
+            assert mx < 1e-9, (k, mx)
+    gross, sdy = rate_scales(tab, pres, y_aos, g['conc'], g['fwd'], g['rev'], g['pres_mod'])
+    assert mixed_err(bufs['spec_rates'].T, g['spec_rates'], gross[:, None]) <= 1.0
+    assert mixed_err(bufs['dy'].T, g['dydt'], sdy) <= 1.0
+    dy2 = np.full((nsp, n), np.nan)
+    assert L.pj_spec_rates(n, P(pres), P(y), n, 1, None, None, None, None, None, P(dy2), None) == 0
+    assert np.array_equal(dy2, bufs['dy'])
+    # layouts: AoS states (y_si = 1, y_ss = NSP)
+    dy3 = np.full((nsp, n), np.nan)
+    assert L.pj_spec_rates(n, P(pres), P(y_aos), 1, nsp, None, None, None, None, None, P(dy3), None) == 0
+    assert np.array_equal(dy3, bufs['dy'])
+
+
+@pytest.mark.parametrize('name,budget,kw', [
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1)),
+    ('synth_alltypes', 200, dict(blocks_per_part=1, rates_per_part=1000)),
+    ('h2o2', 24, dict(blocks_per_part=3, rates_per_part=10)),
+    ('h2o2_n2', 12, dict(blocks_per_part=100, rates_per_part=5)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_DEPTH=1',))),
+    # SRI falloff (3 / 5 parameters, LOW / HIGH, collider) and Chebyshev reactions: evaluated by the pre-pass
+    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
+])
+def test_rblk_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
+    """Row blocks that rebuild their rates (Arrhenius, K_c, third body, theta per visit), the falloff /
+    PLOG pre-pass with its register ring, the d/dT column finished per block, energy-row partials handed
+    from kernel to kernel: against the oracle, both layouts, with and without the J_nplusone quirk."""
+    from oracle.oracle import Oracle
+    ev, L = _rblk_emu_lib(name, budget, str(tmp_path), **kw)
+    orc = Oracle(tables(name))
+    n = 300                               # crosses a 256-state hand-over tile
+    pres, y = synth.dist_b(n, ev.nsp)
+    ref = orc.batch_jacob(pres, np.ascontiguousarray(y.T))
+    for aos in (False, True):
+        jac = _run(L, ev.nsp, pres, y, aos=aos)
+        assert not np.isnan(jac).any()    # every entry written
+        assert jac_scaled_err(jac, ref, ev.nsp) <= 1.0
+    orc.lib.pjo_set_sum_last_species(1)
+    try:
+        ref1 = orc.batch_jacob(pres, np.ascontiguousarray(y.T))
+    finally:
+        orc.lib.pjo_set_sum_last_species(0)
+    assert jac_scaled_err(_run(L, ev.nsp, pres, y, sum_last=1), ref1, ev.nsp) <= 1.0
+
+
+def test_rblk_kernels_chunked(tmp_path, tables, monkeypatch):
+    """Batches larger than the chunk run chunk by chunk through the hand-over arrays of the internal streams."""
+    from oracle.oracle import Oracle
+    monkeypatch.setenv('PJ_RBLK_CHUNK', '256')
+    monkeypatch.setenv('PJ_RBLK_STREAMS', '2')
+    ev, L = _rblk_emu_lib('synth_alltypes', 16, str(tmp_path), blocks_per_part=2, rates_per_part=10)
+    n = 256 * 3 + 17
+    pres, y = synth.dist_b(n, ev.nsp, seed=5)
+    ref = Oracle(tables('synth_alltypes')).batch_jacob(pres, np.ascontiguousarray(y.T))
+    jac = _run(L, ev.nsp, pres, y)
+    assert not np.isnan(jac).any() and jac_scaled_err(jac, ref, ev.nsp) <= 1.0
+
+
+def test_rblk_kernels_vs_reference_golden(tmp_path_factory, golden):
+    """53-species mechanism at the shipping budget against vectors from pyJac's generated C; the library's
+    rate outputs (k_rate, one kernel for the whole mechanism) against the same vectors."""
+    ev, L = _rblk_emu_lib('gri30_shaped', 56, tmp_path_factory, blocks_per_part=13, c_lds=0)
+    g = golden('gri30_shaped')
+    pres, y = g['pres'], np.ascontiguousarray(g['y'].T)
+    jac = _run(L, ev.nsp, pres, y)
+    assert jac_scaled_err(jac, g['jac'], ev.nsp) <= 1.0
+    fro = np.linalg.norm(jac - g['jac']) / np.linalg.norm(g['jac'])
+    assert fro < 1e-9
+    mx, _ = thresholded_rel_err(jac, g['jac'])
+    assert mx < 1e-4
+    L.pj_spec_rates.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long] + [_dp] * 6 + [ctypes.c_void_p]
+    n, nsp = pres.size, ev.nsp
+    rows = dict(conc=nsp, fwd=ev.n_fwd, rev=max(ev.n_rev, 1), pres_mod=max(ev.n_pres_mod, 1), spec_rates=nsp, dy=nsp)
+    bufs = {k: np.full((r, n), np.nan) for k, r in rows.items()}
+    P = lambda a: a.ctypes.data_as(_dp)
+    assert L.pj_spec_rates(n, P(pres), P(y), n, 1, *[P(bufs[k]) for k in rows], None) == 0
+    for k, cols in (('conc', nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
+        mx, _ = thresholded_rel_err(bufs[k].T[:, :cols], g[k][:, :cols])
+        assert mx < 1e-9, (k, mx)
+
+
+@pytest.mark.parametrize('name,budget,kw', [
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+])
+def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
+    """N2 for the row-block family: w = J v per state with the Jacobian consumed in registers
+    (pj_spec_jacvec, PJQ_JV kernels) against the oracle's Jacobian times the same vectors, both layouts."""
+    from oracle.oracle import Oracle
+    ev, L = _rblk_emu_lib(name, budget, str(tmp_path), **kw)
+    L.pj_spec_jacvec.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp, ctypes.c_long, ctypes.c_long,
+                                 _dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    n, nsp = 300, ev.nsp
+    pres, y = synth.dist_b(n, nsp, seed=12, Tlo=700, Thi=2500)
+    v = np.random.default_rng(3).standard_normal((nsp, n))
+    v[0] *= 100.0
+    J = Oracle(tables(name)).batch_jacob(pres, np.ascontiguousarray(y.T)).reshape(n, nsp, nsp)   # [s][col][row]
+    ref = np.einsum('scr,cs->sr', J, v)
+    scale = np.einsum('scr,cs->sr', np.abs(J), np.abs(v)) + 1e-300
+    P = lambda a: a.ctypes.data_as(_dp)
+    ys, vs, ws = np.ascontiguousarray(y), np.ascontiguousarray(v), np.full((nsp, n), np.nan)
+    assert L.pj_spec_jacvec(n, P(pres), P(ys), n, 1, P(vs), n, 1, P(ws), n, 1, 0, None) == 0
+    assert (np.abs(ws.T - ref) / scale).max() < 1e-9
+    ya, va, wa = np.ascontiguousarray(y.T), np.ascontiguousarray(v.T), np.full((n, nsp), np.nan)
+    assert L.pj_spec_jacvec(n, P(pres), P(ya), 1, nsp, P(va), 1, nsp, P(wa), 1, nsp, 0, None) == 0
+    assert (np.abs(wa - ref) / scale).max() < 1e-9

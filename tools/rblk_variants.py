@@ -25,7 +25,8 @@ def main():
             ev = pyjac_amd.Evaluator(mech, specialize='off')
             so = os.path.join(VDIR, '%s_%s.so' % (stem, tag))
             t0 = time.time()
-            ev._build_rblk(so, defines=defines, **opts)
+            from pyjac_amd import specbuild, _lib
+            specbuild.build_rblk(_lib.lib(), ev._h, ev.nsp, so, defines=defines, **opts)
             print('built %s in %.0f s' % (so, time.time() - t0), flush=True)
         return
     import numpy as np, torch
@@ -41,7 +42,7 @@ def main():
     ref = None
     for tag in tags:
         ev = pyjac_amd.Evaluator(mech, specialize='off')
-        if tag in ('rows', 'rblk'):      # whatever prebuilt library of that family exists (any build digest)
+        if tag == 'rblk':      # whatever prebuilt library of that family exists (any build digest)
             pat = os.path.basename(ev.spec_path(tag)).rsplit('_', 1)[0] + '_*.so'
             so = sorted(glob.glob(os.path.join(ROOT, 'pyjac_amd', 'spec', pat)))[-1]
         else:
@@ -54,9 +55,42 @@ def main():
         sample = jac[:, ::4999].cpu().numpy().T
         if ref is None:
             ref = sample
-        print('%-14s %8.3f ms  %.3g Jac/s  frac %.3f   vs first: %.2g  nan=%d' % (
-            tag, ms, n / ms * 1e3, n * bj / ms / 1e6 / 8000, jac_scaled_err(sample, ref, ev0.nsp), int(np.isnan(sample).sum())), flush=True)
+        line = '%-14s %8.3f ms  %.3g Jac/s  frac %.3f   vs first: %.2g  nan=%d' % (
+            tag, ms, n / ms * 1e3, n * bj / ms / 1e6 / 8000, jac_scaled_err(sample, ref, ev0.nsp), int(np.isnan(sample).sum()))
+        if os.environ.get('PJ_VAR_RATES', '1') != '0':
+            line += ' | rates' + rates_ms(ev, d_p, d_y, n, torch)
+        print(line, flush=True)
         ev.close()
+
+
+_bufs = {}
+
+
+def rates_ms(ev, d_p, d_y, n, torch):
+    """ms per launch of the rate pass (pj_eval_rates_dev): every array, dydt only."""
+    import ctypes
+    from pyjac_amd import _lib
+    rows = dict(conc=ev.nsp, fwd=ev.n_fwd, rev=max(ev.n_rev, 1), pres_mod=max(ev.n_pres_mod, 1), spec_rates=ev.nsp, dy=ev.nsp)
+    if not _bufs:
+        _bufs.update({k: torch.empty((r, n), dtype=torch.float64, device='cuda') for k, r in rows.items()})
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = ''
+    for label, which in (('all', tuple(rows)), ('dydt', ('dy',))):
+        p = lambda k: _bufs[k].data_ptr() if k in which else None
+        run = lambda: _lib.check(_lib.lib().pj_eval_rates_dev(ev._h, n, d_p.data_ptr(), d_y.data_ptr(), 0, p('conc'), p('fwd'),
+                                                              p('rev'), p('pres_mod'), p('spec_rates'), p('dy'), stream))
+        for _ in range(2):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        by = 8 * (ev.nsp + 1) + 8 * sum(rows[k] for k in which)
+        out += ' %s %.3f ms (%.3f)' % (label, ms, n * by / ms / 1e6 / 8000)
+    return out
 
 
 if __name__ == '__main__':
