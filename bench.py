@@ -193,25 +193,25 @@ def main():
     import torch
     import torch.distributed as dist
     import pyjac_amd
-    from pyjac_amd.dist import gather_shards, shard_checksums
+    from pyjac_amd.dist import iter_gathered, shard_checksums
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    # PJ_BENCH_STUB=1 (tests/test_bench_gloo.py only): the multi-rank control flow of this file --
-    # partition, barriers, MAX-reduce of the elapsed time, validation gather and checksums -- on CPU
-    # tensors over gloo with a stand-in for the evaluator; never a measurement
-    stub = os.environ.get('PJ_BENCH_STUB') == '1'
-    backend = os.environ.get('PJ_DIST_BACKEND', 'gloo' if stub else 'nccl')
-    if not stub:
+    # PJ_BENCH_EVALUATOR=module:factory (tests/test_bench_gloo.py only): THIS function -- partition, barriers,
+    # MAX-reduce of the elapsed time, validation gather, cross-rank recomputation, checksums -- on CPU tensors
+    # over gloo with a stand-in for the evaluator that the test supplies; never a measurement
+    inject = os.environ.get('PJ_BENCH_EVALUATOR')
+    backend = os.environ.get('PJ_DIST_BACKEND', 'gloo' if inject else 'nccl')
+    dev = 'cpu' if inject else 'cuda'
+    sync = (lambda: None) if inject else torch.cuda.synchronize
+    if not inject:
         assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
         torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, 'launch with --nproc-per-node equal to --gpus'
-    if stub:
-        return stub_main(a, world, rank, torch, dist, np)
 
     wl = a.workload
     if wl == 'auto':
@@ -219,7 +219,12 @@ def main():
         # Jacobian); GRI-Mech 3.0 itself is not available offline: same-shape synthetic mechanism
         wl = 'gri'
     w = WORKLOADS[wl]
-    ev = open_mechanism(pyjac_amd, w['mech'], dist if world > 1 else None, local_rank)
+    if inject:
+        import importlib
+        mod, fn = inject.split(':')
+        ev = getattr(importlib.import_module(mod), fn)(w['mech'])
+    else:
+        ev = open_mechanism(pyjac_amd, w['mech'], dist if world > 1 else None, local_rank)
     n = a.states or w['n']
     # every rank owns n states (weak scaling); global batch = world * n
     pres, y = make_states(w, ev.nsp, n, seed=20240901 + rank)
@@ -227,36 +232,37 @@ def main():
     if lay == 'auto':
         lay = 'soa' if (ev.has_spec or ev.get_launch()['tile_states'] >= 16) else 'aos'
     L = pyjac_amd.LAYOUT_SOA if lay == 'soa' else pyjac_amd.LAYOUT_AOS
-    d_p = torch.from_numpy(pres).cuda()
-    d_y = torch.from_numpy(y if L == pyjac_amd.LAYOUT_SOA else np.ascontiguousarray(y.T)).cuda()
+    d_p = torch.from_numpy(pres).to(dev)
+    d_y = torch.from_numpy(y if L == pyjac_amd.LAYOUT_SOA else np.ascontiguousarray(y.T)).to(dev)
     shape = (ev.nsp * ev.nsp, n) if L == pyjac_amd.LAYOUT_SOA else (n, ev.nsp * ev.nsp)
-    jac = torch.empty(shape, dtype=torch.float64, device='cuda')
+    jac = torch.empty(shape, dtype=torch.float64, device=dev)
 
     def step():
         ev.jacobian(d_p, d_y, y_layout=L, out=jac, jac_layout=L)
 
     # untimed: bring clocks and caches to steady state (>= 0.2 s of launches), then the W warm-up steps
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.2:
+    while time.perf_counter() - t_pre < (0.0 if inject else 0.2):
         step()
-        torch.cuda.synchronize()
+        sync()
     for _ in range(a.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) >= elapsed
         elapsed = float(t.item())
 
     # kernel-only duration, HIP events on the launch stream (roofline.achieved)
@@ -265,17 +271,45 @@ def main():
     finite = bool(torch.isfinite(jac[:, ::997] if L == pyjac_amd.LAYOUT_SOA else jac[::997]).all())
     validation = None
     if world > 1:
-        # the single RCCL all-gather of the path: reassemble a validation batch
+        # The single RCCL all-gather of the path (outside the timed region): reassemble a validation batch of the
+        # first nv states of every rank, a chunk at a time through one receive buffer (dist.iter_gathered).
+        #  * every chunk: what arrived from rank r is finite, this rank's own piece came back bit-identical, and
+        #    the sums of the received pieces add up to the checksums the ranks computed locally;
+        #  * a strided sample of the states of the NEXT rank (a remote one) is evaluated again HERE, from that
+        #    rank's seeded inputs, and compared with the gathered columns: the bytes that crossed
+        #    xGMI are the Jacobians of those states, not merely self-consistent.
         nv = min(a.validate_states, n)
-        shard = (jac[:, :nv] if L == pyjac_amd.LAYOUT_SOA else jac[:nv].T).contiguous()
+        soa = L == pyjac_amd.LAYOUT_SOA
+        shard = (jac[:, :nv] if soa else jac[:nv].T).contiguous()
         t0 = time.perf_counter()
-        g = gather_shards(shard)
-        torch.cuda.synchronize()
         cs = shard_checksums(shard)
-        ok = bool(torch.equal(g[rank], shard)) and bool(torch.isfinite(g).all())
+        sums = torch.zeros(world, dtype=torch.float64, device=dev)
+        ok, nbytes = True, 0
+        peer = (rank + 1) % world
+        p_pres, p_y = make_states(w, ev.nsp, n, seed=20240901 + peer)
+        sample = torch.arange(0, nv, max(1, nv // 64))
+        pj = ev.jacobian(torch.from_numpy(np.ascontiguousarray(p_pres[sample.numpy()])).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(p_y[:, sample.numpy()] if soa else p_y[:, sample.numpy()].T)).to(dev),
+                         y_layout=L, jac_layout=L)
+        pj = pj if soa else pj.T
+        sync()
+        remote_err = 0.0
+        for c0, g in iter_gathered(shard, int(os.environ.get('PJ_VALIDATE_CHUNK', 1024))):
+            cols = g.shape[2]
+            ok &= bool(torch.equal(g[rank], shard[:, c0:c0 + cols])) and bool(torch.isfinite(g).all())
+            sums += g.sum(dim=(1, 2))
+            nbytes += int(g.numel() * 8)
+            inside = (sample >= c0) & (sample < c0 + cols)
+            if bool(inside.any()):
+                got = g[peer][:, (sample[inside] - c0).to(g.device)]
+                ref = pj[:, inside.to(pj.device)]
+                remote_err = max(remote_err, float(((got - ref).abs() / (ref.abs() + 1e-300)).max()))
         for r in range(world):
-            ok &= bool(torch.allclose(cs[r, 0], g[r].sum()))
-        validation = dict(states_per_rank=nv, gathered_bytes=int(g.numel() * 8), ok=ok,
+            ok &= bool(torch.allclose(cs[r, 0], sums[r], rtol=1e-9))
+        # same kernels on the same inputs: bit-identical unless the two ranks run different kernel variants
+        ok &= remote_err <= 1e-9
+        validation = dict(states_per_rank=nv, gathered_bytes=nbytes, ok=bool(ok), remote_rank_checked=peer,
+                          remote_states_recomputed=int(sample.numel()), remote_max_rel_diff=remote_err,
                           seconds=round(time.perf_counter() - t0, 4))
 
     if rank == 0:
@@ -386,49 +420,6 @@ def main():
             except Exception as ex:   # the baseline is reported, never required
                 line['cpu_baseline'] = {'error': repr(ex)}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
-
-
-def stub_main(a, world, rank, torch, dist, np):
-    """The N > 1 branch of main() with a CPU stand-in for the evaluator (see PJ_BENCH_STUB above)."""
-    from pyjac_amd.dist import gather_shards, shard_checksums
-    rows, n = 9, 4096
-    lo = rank * n                         # every rank owns n states (weak scaling)
-    st = torch.arange(lo, lo + n, dtype=torch.float64)
-    jac = torch.empty((rows, n), dtype=torch.float64)
-
-    def step():
-        jac.copy_(torch.sin(1e-3 * st)[None, :] * torch.arange(1, rows + 1, dtype=torch.float64)[:, None])
-    for _ in range(a.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert float(t.item()) >= elapsed
-        elapsed = float(t.item())
-    validation = None
-    if world > 1:
-        nv = min(a.validate_states, n)
-        shard = jac[:, :nv].contiguous()
-        g = gather_shards(shard)
-        cs = shard_checksums(shard)
-        ok = bool(torch.equal(g[rank], shard)) and bool(torch.isfinite(g).all())
-        for r in range(world):
-            ok &= bool(torch.allclose(cs[r, 0], g[r].sum()))
-        validation = dict(states_per_rank=nv, gathered_bytes=int(g.numel() * 8), ok=ok)
-    if rank == 0:
-        print(json.dumps({'metric': 'stub (control flow only)', 'value': world * n * a.steps / elapsed, 'unit': 'states/s',
-                          'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3,
-                          'scaling': 'weak', 'validation_allgather': validation}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -62,6 +62,11 @@ int pj_mech_pres_mod_rates(const pj_mech* m);
 /* 0 (default): keep the reference's J_nplusone assignment quirk
  * (create_jacobian.py:2786-2818) so jac[0] equals pyJac's; 1: sum all reactions. */
 int pj_mech_set_sum_last_species(pj_mech* m, int on);
+/* 1: pj_eval_jacobian_dev / pj_eval_jacobian_vec_dev / pj_eval_rates_dev first verify the preconditions the
+ * reference leaves to its caller (T > 0 -- log T is taken --, p > 0, every input finite: docs/faqs.rst:92-103) and
+ * return PJ_EINVAL naming the first offending state; costs one pass over the inputs and a stream
+ * synchronisation.  0 (default): no check, as in the reference (undefined results for such states). */
+int pj_mech_set_check_inputs(pj_mech* m, int on);
 /* launch tuning: states per workgroup tile (power of two <= 64, 0 = auto),
  * threads per workgroup (multiple of 64, 0 = auto) */
 int pj_mech_set_launch(pj_mech* m, int tile_states, int threads);

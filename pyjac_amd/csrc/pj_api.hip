@@ -152,6 +152,22 @@ __global__ void k_spec_rates(DevMech M, long n, const double* fwd, const double*
     }
 }
 
+// ---- optional precondition check (SURVEY.md 8(b) "Preconditions": T > 0 -- log T is taken --, finite inputs,
+// p > 0): first offending state index, or LONG_MAX ----
+__global__ void k_check_inputs(long n, int nsp, const double* pres, const double* y, long y_si, long y_ss,
+                               unsigned long long* first_bad)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const double T = y[s * y_ss], p = pres[s];
+    bool bad = !(T > 0.0) || !(p > 0.0) || !(T < 1.0e300) || !(p < 1.0e300);
+    for (int i = 1; i < nsp; ++i) {
+        const double v = y[i * y_si + s * y_ss];
+        bad |= !(v == v) || !(v < 1.0e300) || !(v > -1.0e300);
+    }
+    if (bad) atomicMin(first_bad, (unsigned long long)s);
+}
+
 // ---- finite-difference Jacobian helpers (fd_jacob.c:56-111) ----
 __global__ void k_fd_setup(long n, int nsp, const double* y, const double* dy0, double* r)
 {
@@ -226,8 +242,8 @@ struct pj_mech {
     DevMech M;
     bool on_device = false;
     int device = -1;
-    DevBuf<double> sp, rd, rtd, eff_am1, kcg, plog, sri, cheb, net_nu, sp_nu;
-    DevBuf<int32_t> ri, rti, eff_sp, net_sp, sp_ptr, sp_rxn, fin_tgt, fin_part, fin_cnt;
+    DevBuf<double> sp, rd, rtd, eff_am1, kcg, plog, sri, cheb, net_nu, sp_nu, gen_nu;
+    DevBuf<int32_t> ri, rti, eff_sp, net_sp, sp_ptr, sp_rxn, fin_tgt, fin_part, fin_cnt, gen_sp;
     DevBuf<uint32_t> sched, ecol;
     DevBuf<uint16_t> smap;
     DevBuf<int32_t> ecol_ptr;
@@ -248,6 +264,8 @@ struct pj_mech {
     double* jv_tmp = nullptr;    // Jacobian chunk of the unfused J*v path
     size_t jv_tmp_doubles = 0;
     int use_spec = 1;          // 0: never, 1: SoA Jacobians (default), 2: every layout
+    int check_inputs = 0;      // 1: the *_dev entry points verify T > 0, p > 0, finite (one extra pass + a sync)
+    unsigned long long* d_bad = nullptr;
 };
 
 namespace {
@@ -287,7 +305,10 @@ int ensure_device(pj_mech* m)
     HIPCHK(m->sri.upload(P.sri)); HIPCHK(m->cheb.upload(P.cheb));
     HIPCHK(m->net_sp.upload(P.net_sp)); HIPCHK(m->net_nu.upload(P.net_nu));
     HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
+    HIPCHK(m->gen_sp.upload(P.gen_sp)); HIPCHK(m->gen_nu.upload(P.gen_nu));
     DevMech& M = m->M;
+    M.gen_sp = m->gen_sp.p; M.gen_nu = m->gen_nu.p;
+    for (int t = 0; t < NUTAB_N; ++t) M.nutab[t] = P.nutab[t];
     M.sp = m->sp.p; M.ri = m->ri.p; M.rd = m->rd.p; M.rti = m->rti.p; M.rtd = m->rtd.p; M.nrp = P.nrp;
     M.smap = m->smap.p; M.ecol_ptr = m->ecol_ptr.p; M.ecol = m->ecol.p; M.eff_sp = m->eff_sp.p; M.eff_am1 = m->eff_am1.p;
     M.kcg = m->kcg.p; M.plog = m->plog.p; M.sri = m->sri.p; M.cheb = m->cheb.p; M.net_sp = m->net_sp.p; M.net_nu = m->net_nu.p;
@@ -497,7 +518,7 @@ void pj_mech_destroy(pj_mech* m)
         m->smap.release(); m->ecol_ptr.release(); m->ecol.release(); m->eff_am1.release(); m->kcg.release(); m->plog.release(); m->sri.release(); m->cheb.release();
         m->net_nu.release(); m->sp_nu.release(); m->sched.release(); m->ri.release(); m->eff_sp.release();
         m->fin_tgt.release(); m->fin_part.release(); m->fin_cnt.release();
-        m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release();
+        m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release(); m->gen_sp.release(); m->gen_nu.release();
         m->ws.release(); m->ws1.release();
     }
     if (m->spec_lib) dlclose(m->spec_lib);
@@ -510,6 +531,29 @@ int pj_mech_rev_rates(const pj_mech* m) { return m->P.nrev; }
 int pj_mech_pres_mod_rates(const pj_mech* m) { return m->P.npres; }
 
 int pj_mech_set_sum_last_species(pj_mech* m, int on) { m->M.sum_last = on ? 1 : 0; return PJ_OK; }
+
+int pj_mech_set_check_inputs(pj_mech* m, int on) { if (!m) return fail(PJ_EINVAL, "bad argument"); m->check_inputs = on ? 1 : 0; return PJ_OK; }
+
+// the precondition pass of the *_dev entry points (only when switched on: it synchronises the stream)
+static int check_inputs(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout, void* stream)
+{
+    if (!m->check_inputs) return PJ_OK;
+    int rc = ensure_device(m);
+    if (rc) return rc;
+    long y_si, y_ss;
+    set_layout(n, m->P.nsp, y_layout, &y_si, &y_ss);
+    if (!m->d_bad) HIPCHK(hipMalloc((void**)&m->d_bad, sizeof(unsigned long long)));
+    unsigned long long bad = ~0ull;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(m->d_bad, &bad, sizeof(bad), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_check_inputs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, m->P.nsp, d_pres, d_y, y_si,
+                       y_ss, m->d_bad);
+    HIPCHK(hipMemcpyAsync(&bad, m->d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (bad != ~0ull)
+        return fail(PJ_EINVAL, "state " + std::to_string(bad) + ": T and p must be positive and every input finite");
+    return PJ_OK;
+}
 
 unsigned long long pj_mech_spec_hash(const pj_mech* m) { return programs_hash(m->P); }
 
@@ -619,6 +663,7 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
     if (!m || n < 0) return fail(PJ_EINVAL, "bad argument");
     if (n == 0) return PJ_OK;
     if (!d_pres || !d_y || !d_jac) return fail(PJ_EINVAL, "null device pointer");
+    if (const int rc = check_inputs(m, n, d_pres, d_y, y_layout, stream)) return rc;
     Batch B;
     memset(&B, 0, sizeof(B));
     B.n = n; B.pres = d_pres; B.y = d_y; B.jac = d_jac; B.o_ld = n;
@@ -645,6 +690,7 @@ int pj_eval_jacobian_vec_dev(pj_mech* m, long n, const double* d_pres, const dou
     if (!m || n < 0) return fail(PJ_EINVAL, "bad argument");
     if (n == 0) return PJ_OK;
     if (!d_pres || !d_y || !d_v || !d_w) return fail(PJ_EINVAL, "null device pointer");
+    if (const int rc0 = check_inputs(m, n, d_pres, d_y, y_layout, stream)) return rc0;
     const int nsp = m->P.nsp;
     long y_si, y_ss, v_si, v_ss;
     set_layout(n, nsp, y_layout, &y_si, &y_ss);
@@ -694,6 +740,7 @@ int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_
     if (!m || n < 0) return fail(PJ_EINVAL, "bad argument");
     if (n == 0) return PJ_OK;
     if (!d_pres || !d_y) return fail(PJ_EINVAL, "null device pointer");
+    if (const int rc = check_inputs(m, n, d_pres, d_y, y_layout, stream)) return rc;
     Batch B;
     memset(&B, 0, sizeof(B));
     B.n = n; B.pres = d_pres; B.y = d_y; B.o_ld = n;

@@ -33,6 +33,18 @@ constexpr double RU_ = 8314.4621;   // chem_utilities.py:16
 constexpr double LN10 = 2.302585092994045684;
 constexpr double INV_LN10 = 0.434294481903251828;
 
+// C^nu of a general-stoichiometry factor: whole-number coefficients by repeated multiplication (as the
+// reference emits them), fractional ones through pow() (rate_subs.py:634-658)
+PJ_DEV double pj_cpow(const double C, const double nu)
+{
+    if (nu == floor(nu)) {
+        double r = 1.0;
+        for (int q = 0; q < (int)nu; ++q) r *= C;
+        return r;
+    }
+    return pow(C, nu);
+}
+
 struct DevMech {
     int nsp, nrxn, ng, ne, nv;
     int lastq_rxn, sum_last;
@@ -54,6 +66,9 @@ struct DevMech {
     const double* cheb;        // Chebyshev records
     const int32_t* net_sp;
     const double* net_nu;
+    const int32_t* gen_sp;     // F_GEN reactions: (species, nu) factors (pj_tables.h)
+    const double* gen_nu;
+    double nutab[NUTAB_N];     // scatter nu codes 8..: fractional / large net coefficients
     const int32_t* sp_ptr;
     const int32_t* sp_rxn;
     const double* sp_nu;
@@ -333,8 +348,16 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         // ---- concentration products ----
         const double cr0 = V[RI_(RI_R0) * TS + s], cr1 = V[RI_(RI_R1) * TS + s], cr2 = V[RI_(RI_R2) * TS + s];
         const double cp0 = V[RI_(RI_P0) * TS + s], cp1 = V[RI_(RI_P1) * TS + s], cp2 = V[RI_(RI_P2) * TS + s];
-        const double Rf = kf * (cr0 * cr1 * cr2);
-        const double Rr = kr * (cp0 * cp1 * cp2);
+        double prodr = cr0 * cr1 * cr2, prodp = cp0 * cp1 * cp2;
+        const int gp0 = RI_(RI_GEN_PTR), gnr = RI_(RI_GEN_NR), gnp = RI_(RI_GEN_NP);
+        if (fl & F_GEN) {
+            // general stoichiometry: C^nu by repeated multiplication for whole numbers, pow() otherwise
+            // (rate_subs.py:634-658, 811-840)
+            for (int f = 0; f < gnr; ++f) prodr *= pj_cpow(V[M.gen_sp[gp0 + f] * TS + s], M.gen_nu[gp0 + f]);
+            for (int f = 0; f < gnp; ++f) prodp *= pj_cpow(V[M.gen_sp[gp0 + gnr + f] * TS + s], M.gen_nu[gp0 + gnr + f]);
+        }
+        const double Rf = kf * prodr;
+        const double Rr = kr * prodp;
         const double R = Rf - Rr;
 
         // ---- pressure modification ----
@@ -444,6 +467,23 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
             PJ_GSLOT(RI_(RI_P1), -ckr * (cp0 * cp2))
             PJ_GSLOT(RI_(RI_P2), -ckr * (cp0 * cp1))
         }
+        if (fl & F_GEN) {
+            // one value per factor: c k nu C^(nu-1) prod_others (create_jacobian.py:400-448; the power of C_j
+            // itself only "if (nu - 1) > 0": reference quirk kept for parity)
+            for (int side = 0; side < ((fl & F_REV) ? 2 : 1); ++side) {
+                const int f0 = gp0 + side * gnr, nf = side ? gnp : gnr;
+                const double ck = side ? -ckr : ckf;
+                for (int f = 0; f < nf; ++f) {
+                    const double nuf = M.gen_nu[f0 + f];
+                    double gv = ck * nuf;
+                    if (nuf - 1.0 > 0.0) gv *= pj_cpow(V[M.gen_sp[f0 + f] * TS + s], nuf - 1.0);
+                    for (int h = 0; h < nf; ++h)
+                        if (h != f) gv *= pj_cpow(V[M.gen_sp[f0 + h] * TS + s], M.gen_nu[f0 + h]);
+                    V[g * TS + s] = gv; ++g;
+                    if (M.gen_sp[f0 + f] == last) gN += gv;
+                }
+            }
+        }
         if (fl & F_COLLIDER) { PJ_GSLOT(RI_(RI_COLLIDER), bcol) }
         #undef PJ_GSLOT
         if (fl & F_EFFTYPE)      // (alpha_ij - 1) b_i for the enhanced-collider columns
@@ -498,23 +538,27 @@ PJ_DEV void phase_scatter(const DevMech& M, double* V, int tid, int NT, bool den
     uint32_t c[4], c1[4], c2[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-        c[x] = (nr > 0) ? sc[x * IL] : (4u << 29);
-        c1[x] = (nr > 4) ? sc[(4 + x) * IL] : (4u << 29);
+        c[x] = (nr > 0) ? sc[x * IL] : (4u << 28);
+        c1[x] = (nr > 4) ? sc[(4 + x) * IL] : (4u << 28);
     }
     for (int r = 0; r < nr; r += 4) {
         const bool more = r + 8 < nr;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) c2[x] = more ? sc[(r + 8 + x) * IL] : (4u << 29);
+        for (int x = 0; x < 4; ++x) c2[x] = more ? sc[(r + 8 + x) * IL] : (4u << 28);
         double v[4], t[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             v[x] = V[(c[x] & 8191u) * TS + s];
-            t[x] = T[((c[x] >> 13) & 65535u) * TS];
+            t[x] = T[((c[x] >> 13) & 32767u) * TS];
         }
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const int nu = (int)(c[x] >> 29) - 4;
-            if (nu) T[((c[x] >> 13) & 65535u) * TS] = t[x] + (double)nu * v[x];
+            // nu code (pj_tables.h): 0..7 are the whole numbers -4..3, 8.. index the mechanism's table of
+            // fractional / larger net coefficients
+            const unsigned nc = c[x] >> 28;
+            double nu = (double)((int)nc - 4);
+            if (nc >= 8u) nu = M.nutab[nc - 8u];
+            if (nc != 4u) T[((c[x] >> 13) & 32767u) * TS] = t[x] + nu * v[x];
         }
 #pragma unroll
         for (int x = 0; x < 4; ++x) { c[x] = c1[x]; c1[x] = c2[x]; }

@@ -34,10 +34,10 @@ using namespace pj;
 constexpr bool lane_supported()
 {
     for (int i = 0; i < pjs::NRXN; ++i)
-        if (pjs::RI[i][RI_FLAGS] & (F_SRI | F_CHEB)) return false;
+        if (pjs::RI[i][RI_FLAGS] & (F_SRI | F_CHEB | F_GEN)) return false;
     return true;
 }
-static_assert(lane_supported(), "pj_lane.hip: SRI / Chebyshev reactions are not implemented here; build kind 'rblk'");
+static_assert(lane_supported(), "pj_lane.hip: SRI / Chebyshev reactions and general stoichiometry are not implemented here; build kind 'rblk'");
 
 
 namespace {

@@ -193,6 +193,62 @@ __device__ __forceinline__ void static_range(F&& f)
 
 #include "pj_math.h"
 
+// General stoichiometry (F_GEN: a fractional coefficient or more than three molecules on a side; pj_tables.h):
+// C^nu of factor F of the header's GEN_SP / GEN_NU lists -- whole-number coefficients by repeated multiplication,
+// as the reference emits them, fractional ones through pow() (rate_subs.py:634-658) -- and nu C^(nu-1), where the
+// power of C is only there "if (nu - 1) > 0" (create_jacobian.py:417-427: reference quirk kept for parity)
+template <int F>
+__device__ __forceinline__ double gen_pow(const double C)
+{
+    constexpr double nu = pjs::GEN_NU[F][0];
+    if constexpr (nu == (double)(int)nu) {
+        double r = 1.0;
+        static_for<(int)nu>([&](auto) PJR_INL { r *= C; });
+        return r;
+    } else {
+        return pow(C, nu);
+    }
+}
+template <int F>
+__device__ __forceinline__ double gen_dpow(const double C)
+{
+    constexpr double nu = pjs::GEN_NU[F][0];
+    double r = nu;
+    if constexpr (nu - 1.0 > 0.0) {
+        if constexpr (nu == (double)(int)nu) static_for<(int)nu - 1>([&](auto) PJR_INL { r *= C; });
+        else r *= pow(C, nu - 1.0);
+    }
+    return r;
+}
+
+// Real-valued reaction constants in the visit bodies: as 64-bit literals (two s_mov_b32 each, an issue slot
+// apiece at one wavefront per SIMD) or, PJQ_RD_CONST = 1, read through the scalar cache from the __constant__
+// tables of the header (RDT, EFFT: s_load_dwordx2..x16 at immediate offsets from one opaque base; the
+// scheduler batches neighbouring fields).  Constants that encode for free (0, +-0.5, +-1, +-2, +-4, or 32 zero low
+// bits: a single literal dword) stay literals either way.
+#ifndef PJQ_RD_CONST
+#define PJQ_RD_CONST 0
+#endif
+constexpr bool cheap_literal(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    return (u & 0xffffffffull) == 0;
+}
+#if PJQ_RD_CONST && !defined(PJR_HOST_EMU)
+typedef const __attribute__((address_space(4))) double* pjq_cptr;
+#define PJQ_CONST_BASES() \
+    pjq_cptr rdt_ = (pjq_cptr)&pjs::RDT[0][0], efft_ = (pjq_cptr)&pjs::EFFT[0][0], invw_ = (pjq_cptr)&pjs::INVWT[0][0]; \
+    asm volatile("" : "+s"(rdt_), "+s"(efft_), "+s"(invw_));
+#define RDC(i_, f_) (cheap_literal(pjs::RD[i_][f_]) ? pjs::RD[i_][f_] : rdt_[(i_) * RDW + (f_)])
+#define EFC(e_) (cheap_literal(pjs::EFF_AM1[e_][0]) ? pjs::EFF_AM1[e_][0] : efft_[e_])
+#define INVW(j_) invw_[j_]
+#else
+#define PJQ_CONST_BASES()
+#define RDC(i_, f_) pjs::RD[i_][f_]
+#define EFC(e_) pjs::EFF_AM1[e_][0]
+#define INVW(j_) pjs::SP[j_][0]
+#endif
+
 #if PJQ_PAIR
 typedef double d2s __attribute__((ext_vector_type(2)));
 // Pair stores: a lane writes 16 bytes, two neighbouring states of one Jacobian entry.  The lanes of a
@@ -505,6 +561,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     double pjq_sink = 0.0;
 #endif
     double T, rho, invrho, Wbar, mconc;
+    PJQ_CONST_BASES()
     {
         // one round trip for everything the prologue reads: the state and this thread's share of the
         // K_c table are requested before anything waits (a load behind other workgroups' Jacobian
@@ -725,15 +782,26 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             PJQ_SCHED_BARRIER();
 #endif
             // ---- phase B ----
-            const double pr_ = cr0 * cr1 * cr2, pp_ = cp0 * cp1 * cp2;
+            double pr_ = cr0 * cr1 * cr2, pp_ = cp0 * cp1 * cp2;
+            // general stoichiometry: the molecule slots are empty, the factors multiply in here
+            constexpr int GP = pjs::RI[i][RI_GEN_PTR];
+            constexpr int GNR = (fl & F_GEN) ? pjs::RI[i][RI_GEN_NR] : 0;
+            constexpr int GNP = ((fl & F_GEN) && (fl & F_REV)) ? pjs::RI[i][RI_GEN_NP] : 0;
+            double gcf[GNR + GNP > 0 ? GNR + GNP : 1], gpw[GNR + GNP > 0 ? GNR + GNP : 1];
+            static_for<GNR + GNP>([&](auto fc) PJR_INL {
+                constexpr int f = decltype(fc)::value;
+                gcf[f] = conc(std::integral_constant<int, pjs::GEN_SP[GP + f][0]>{});
+                gpw[f] = gen_pow<GP + f>(gcf[f]);
+                if constexpr (f < GNR) pr_ *= gpw[f]; else pp_ *= gpw[f];
+            });
             // Arrhenius (rate_subs.py:113-147); exp(-ln K_c) and T dlnK_c/dT from the pre-summed NASA
             // polynomials of the reaction's groups (rate_subs.py:660-809); the two exponentials of a
             // reversible reaction are evaluated side by side
             double kf = 0.0, ekc = 0.0, td = 0.0, lnk = 0.0, lnKc = 0.0;
             if constexpr (!is_pre(i))
-                lnk = pjs::RD[i][RD_LNA] + pjs::RD[i][RD_B] * logT - pjs::RD[i][RD_TA] * invT;
+                lnk = RDC(i, RD_LNA) + RDC(i, RD_B) * logT - RDC(i, RD_TA) * invT;
             if constexpr ((fl & F_REV) != 0) {
-                lnKc = pjs::RD[i][RD_LNPREF];
+                lnKc = RDC(i, RD_LNPREF);
                 static_for<KCNT>([&](auto cc) PJR_INL {
                     constexpr int c = decltype(cc)::value;
                     const double* a = ka[c];
@@ -776,14 +844,14 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     double Mc = mconc;
                     static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
                         constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
-                        Mc += pjs::EFF_AM1[e][0] * conc(std::integral_constant<int, pjs::EFF_SP[e][0]>{});
+                        Mc += EFC(e) * conc(std::integral_constant<int, pjs::EFF_SP[e][0]>{});
                     });
                     c = Mc;
                     lead = -c * R * invT;
                     if constexpr ((fl & F_EFFTYPE) != 0) bM = R;
                 }
                 if constexpr ((fl & F_NO_DT) == 0) {
-                    const double dlnk = pjs::RD[i][RD_B] + pjs::RD[i][RD_TA] * invT;
+                    const double dlnk = RDC(i, RD_B) + RDC(i, RD_TA) * invT;
                     double el = R * dlnk + Rf * (1.0 - nr);
                     if constexpr ((fl & F_REV) != 0) el -= Rr * ((1.0 - np_) - td);
                     theta = (lead + c * invT * el) * invrho;
@@ -802,7 +870,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             const double q_ = ckf * pr_ - ckr * pp_;
 
             double gN = 0.0;
-            if constexpr (has_anm1<i>()) gN = bM * pjs::RD[i][RD_ANM1];
+            if constexpr (has_anm1<i>()) gN = bM * RDC(i, RD_ANM1);
             constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
             auto slot = [&](auto spc, const double gv) PJR_INL {
                 constexpr int sp = decltype(spc)::value;
@@ -829,6 +897,14 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 slot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -gkr * (cp0 * cp2));
                 slot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -gkr * (cp0 * cp1));
             }
+            static_for<GNR + GNP>([&](auto fc) PJR_INL {
+                // one value per factor: c k nu C^(nu-1) prod_others (create_jacobian.py:400-448)
+                constexpr int f = decltype(fc)::value;
+                constexpr int f0 = f < GNR ? 0 : GNR, f1 = f < GNR ? GNR : GNR + GNP;
+                double gv = (f < GNR ? gkf : -gkr) * gen_dpow<GP + f>(gcf[f]);
+                static_range<f0, f1>([&](auto hc) PJR_INL { if constexpr (decltype(hc)::value != f) gv *= gpw[decltype(hc)::value]; });
+                slot(std::integral_constant<int, pjs::GEN_SP[GP + f][0]>{}, gv);
+            });
             if constexpr ((fl & F_COLLIDER) != 0)
                 slot(std::integral_constant<int, (pjs::RI[i][RI_COLLIDER] >= 0 ? pjs::RI[i][RI_COLLIDER] : ONE)>{}, bcol);
             if constexpr ((fl & F_EFFTYPE) != 0) {
@@ -836,7 +912,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
                     constexpr int es = pjs::EFF_SP[e][0];
                     // the last species' enhanced efficiency is already in gN (RD_ANM1)
-                    if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, pjs::EFF_AM1[e][0] * bM);
+                    if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, EFC(e) * bM);
                 });
             }
             const double rq = rp + gN;
@@ -905,9 +981,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #ifndef PJQ_NO_E      // experiment: what the energy-row partial sums cost (results wrong)
                     E[j] += hW[r] * S[si];
 #endif
-                    return pjs::SP[j][0] * (WP[r] + pjs::SP[k][1] * S[si]) - WQN[r];
+                    return INVW(j) * (WP[r] + pjs::SP[k][1] * S[si]) - WQN[r];
                 } else {
-                    return pjs::SP[j][0] * WP[r] - WQN[r];
+                    return INVW(j) * WP[r] - WQN[r];
                 }
             }
         };
@@ -1121,6 +1197,7 @@ __global__ void __launch_bounds__(NTHR) k_rate(PjqArgs A)
     if (s >= A.n) s = A.n - 1;
     double om[NSP];
     double T, p, rho, invrho, Wbar, mconc;
+    PJQ_CONST_BASES()
 #if !PJQ_C_LDS
     State L;
 #endif
@@ -1208,11 +1285,11 @@ __global__ void __launch_bounds__(NTHR) k_rate(PjqArgs A)
             // Arrhenius (+ optional third body): rate_subs.py:113-147, 634-658, 660-840, 1076-1134
             constexpr int fl = pjs::RI[i][RI_FLAGS];
             const double cr0 = CC(pjs::RI[i][RI_R0]), cr1 = CC(pjs::RI[i][RI_R1]), cr2 = CC(pjs::RI[i][RI_R2]);
-            const double lnk = pjs::RD[i][RD_LNA] + pjs::RD[i][RD_B] * logT - pjs::RD[i][RD_TA] * invT;
+            const double lnk = RDC(i, RD_LNA) + RDC(i, RD_B) * logT - RDC(i, RD_TA) * invT;
             double kf, Rr = 0.0;
             if constexpr ((fl & F_REV) != 0) {
                 const double cp0 = CC(pjs::RI[i][RI_P0]), cp1 = CC(pjs::RI[i][RI_P1]), cp2 = CC(pjs::RI[i][RI_P2]);
-                double lnKc = pjs::RD[i][RD_LNPREF];
+                double lnKc = RDC(i, RD_LNPREF);
                 static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJR_INL {
                     constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
                     const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
@@ -1226,13 +1303,20 @@ __global__ void __launch_bounds__(NTHR) k_rate(PjqArgs A)
                 kf = exp_one(lnk);
                 if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
             }
-            const double Rf = kf * (cr0 * cr1 * cr2);
+            double Rf = kf * (cr0 * cr1 * cr2);
+            if constexpr ((fl & F_GEN) != 0) {
+                // general stoichiometry: the molecule slots are empty, the factors multiply in here
+                constexpr int GP = pjs::RI[i][RI_GEN_PTR], GNR = pjs::RI[i][RI_GEN_NR], GNP = pjs::RI[i][RI_GEN_NP];
+                static_for<GNR>([&](auto fc) PJR_INL { Rf *= gen_pow<GP + decltype(fc)::value>(CC(pjs::GEN_SP[GP + decltype(fc)::value][0])); });
+                if constexpr ((fl & F_REV) != 0)
+                    static_for<GNP>([&](auto fc) PJR_INL { Rr *= gen_pow<GP + GNR + decltype(fc)::value>(CC(pjs::GEN_SP[GP + GNR + decltype(fc)::value][0])); });
+            }
             double c = 1.0;
             if constexpr ((fl & F_THD) != 0) {
                 c = mconc;
                 static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
                     constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
-                    c += pjs::EFF_AM1[e][0] * CC(pjs::EFF_SP[e][0]);
+                    c += EFC(e) * CC(pjs::EFF_SP[e][0]);
                 });
             }
             rate_out(ic, Rf, Rr, c);

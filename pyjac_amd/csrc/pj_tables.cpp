@@ -186,9 +186,29 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         };
         int rs[3], ps[3];
         double nr, np_;
-        const int nrs = slots(reac_ptr, reac_sp, reac_nu, rs, nr);
-        const int nps = slots(prod_ptr, prod_sp, prod_nu, ps, np_);
-        if (nrs < 0 || nps < 0) { p.error = "more than 3 molecules on one side of a reaction (or fractional nu)"; return false; }
+        int nrs = slots(reac_ptr, reac_sp, reac_nu, rs, nr);
+        int nps = slots(prod_ptr, prod_sp, prod_nu, ps, np_);
+        // General stoichiometry (a fractional coefficient, or more than three molecules on a side): the molecule
+        // slots stay empty (factor 1) and the reaction carries (species, nu) factor lists -- one derivative value
+        // g per factor instead of one per molecule (mech_interpret.py:300-318, 398-416; rate_subs.py:634-658;
+        // create_jacobian.py:400-448)
+        ri[RI_GEN_PTR] = (int)p.gen_sp.size();
+        if (nrs < 0 || nps < 0) {
+            fl |= F_GEN;
+            nr = np_ = 0.0;
+            for (int q = reac_ptr[i]; q < reac_ptr[i + 1]; ++q) {
+                if (!(reac_nu[q] > 0.0)) { p.error = "non-positive stoichiometric coefficient"; return false; }
+                p.gen_sp.push_back(reac_sp[q]); p.gen_nu.push_back(reac_nu[q]); nr += reac_nu[q];
+            }
+            ri[RI_GEN_NR] = reac_ptr[i + 1] - reac_ptr[i];
+            for (int q = prod_ptr[i]; q < prod_ptr[i + 1]; ++q) {
+                if (!(prod_nu[q] > 0.0)) { p.error = "non-positive stoichiometric coefficient"; return false; }
+                p.gen_sp.push_back(prod_sp[q]); p.gen_nu.push_back(prod_nu[q]); np_ += prod_nu[q];
+            }
+            ri[RI_GEN_NP] = prod_ptr[i + 1] - prod_ptr[i];
+            for (int r = 0; r < 3; ++r) rs[r] = ps[r] = ONE;
+            nrs = nps = 0;
+        }
         for (int r = 0; r < 3; ++r) { ri[RI_R0 + r] = rs[r]; ri[RI_P0 + r] = ps[r]; }
 
         const int col = pdep_sp[i];
@@ -286,6 +306,11 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         ri[RI_GBASE] = ng;
         for (int r = 0; r < nrs; ++r) gslot_sp[d].push_back(rs[r]);
         if (fl & F_REV) for (int r = 0; r < nps; ++r) gslot_sp[d].push_back(ps[r]);
+        if (fl & F_GEN) {
+            for (int f = 0; f < ri[RI_GEN_NR]; ++f) gslot_sp[d].push_back(p.gen_sp[ri[RI_GEN_PTR] + f]);
+            if (fl & F_REV)
+                for (int f = 0; f < ri[RI_GEN_NP]; ++f) gslot_sp[d].push_back(p.gen_sp[ri[RI_GEN_PTR] + ri[RI_GEN_NR] + f]);
+        }
         if (fl & F_COLLIDER) gslot_sp[d].push_back(col);
         // enhanced colliders of an [M] with efficiencies: one slot each holding
         // (alpha_ij - 1) b_i, in eff-list order (the last species goes to gN instead)
@@ -341,24 +366,7 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
 
     if (v.NV >= 8192 || nrxn >= 8192) { p.error = "mechanism too large for the 13-bit program encoding"; return false; }
 
-    // ---- P4: per species-block entry gather, packed for LDS ----
-    const int ne = nsp * (nsp - 1);
-    p.ne = ne;
-    std::vector<std::vector<uint16_t>> codes(ne);
-    for (int d = 0; d < nrxn; ++d) {
-        const int32_t* ri = &p.ri[(size_t)d * RIW];
-        const int gb = ri[RI_GBASE];
-        for (size_t t = 0; t < gslot_sp[d].size(); ++t) {
-            const int j = gslot_sp[d][t];
-            if (j >= last) continue;
-            for (int q = 0; q < ri[RI_NET_CNT]; ++q) {
-                const int k = p.net_sp[ri[RI_NET_PTR] + q];
-                const int nu = (int)p.net_nu[ri[RI_NET_PTR] + q];
-                if (nu < -4 || nu > 3) { p.error = "net stoichiometric coefficient out of range"; return false; }
-                codes[k + nsp * j].push_back((uint16_t)(((v.G + gb + (int)t) << 3) | (nu + 4)));
-            }
-        }
-    }
+    p.ne = nsp * (nsp - 1);
     // ---- field-major reaction tables ----
     p.nrp = (nrxn + 63) / 64 * 64;
     p.rti.assign((size_t)(RIW + EFF_INL) * p.nrp, 0);
@@ -384,7 +392,7 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         const int gb = ri[RI_GBASE];
         for (int q = 0; q < ri[RI_NET_CNT]; ++q) {
             const int k = p.net_sp[ri[RI_NET_PTR] + q];
-            const int nu = (int)p.net_nu[ri[RI_NET_PTR] + q];
+            const double nu = p.net_nu[ri[RI_NET_PTR] + q];
             p.contribs.push_back({v.RQ + d, v.T_OM + k, nu, true});
             p.contribs.push_back({v.RTH + d, v.T_JT + k, nu, true});
             p.contribs.push_back({v.RP + d, v.T_P + k, nu, true});
@@ -396,7 +404,7 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
             if (j >= last) continue;
             for (int q = 0; q < ri[RI_NET_CNT]; ++q)
                 p.contribs.push_back({v.G + gb + (int)t, v.T_S + p.net_sp[ri[RI_NET_PTR] + q] + nsp * j,
-                                      (int)p.net_nu[ri[RI_NET_PTR] + q], false});
+                                      p.net_nu[ri[RI_NET_PTR] + q], false});
         }
     }
 
@@ -429,30 +437,15 @@ bool build_programs(const int32_t* I, long nI, const double* D, long nD, Program
         v.NSLOT = v.X + SC_COUNT * nsp;
     }
 
-    auto pack = [&](const std::vector<std::vector<uint16_t>>& lists, uint16_t pad, int* en_off, int* c_off) -> bool {
-        *en_off = (int)p.prog.size();
-        p.prog.resize(p.prog.size() + lists.size());
-        if (p.prog.size() & 1) p.prog.push_back(0);          // keep the code area 8-byte aligned
-        *c_off = (int)p.prog.size();
-        int batch = 0;
-        for (size_t e = 0; e < lists.size(); ++e) {
-            std::vector<uint16_t> l = lists[e];
-            while (l.size() % 4) l.push_back(pad);
-            const int nb = (int)l.size() / 4;
-            if (nb > 255 || batch >= (1 << 24)) return false;
-            p.prog[*en_off + e] = ((uint32_t)batch << 8) | (uint32_t)nb;
-            for (size_t x = 0; x < l.size(); x += 2) p.prog.push_back((uint32_t)l[x] | ((uint32_t)l[x + 1] << 16));
-            batch += nb;
-        }
-        return true;
-    };
-    if (!pack(codes, (uint16_t)((v.ONE << 3) | 4), &p.p4en, &p.p4c)) { p.error = "P4 program overflow"; return false; }
-    {
-        std::vector<std::vector<uint16_t>> l3(nsp);
-        for (int k = 0; k < nsp; ++k)
-            for (int q = p.sp_ptr[k]; q < p.sp_ptr[k + 1]; ++q)
-                l3[k].push_back((uint16_t)((p.sp_rxn[q] << 3) | ((int)p.sp_nu[q] + 4)));
-        if (!pack(l3, (uint16_t)4, &p.p3en, &p.p3c)) { p.error = "P3 program overflow"; return false; }
+    // net coefficients the 4-bit scatter code cannot express as a whole number in -4..3
+    p.n_nutab = 0;
+    for (auto& c : p.contribs) {
+        if (c.nu == std::floor(c.nu) && c.nu >= -4.0 && c.nu <= 3.0) continue;
+        bool have = false;
+        for (int t = 0; t < p.n_nutab; ++t) have |= (p.nutab[t] == c.nu);
+        if (have) continue;
+        if (p.n_nutab >= NUTAB_N) { p.error = "more than 8 distinct fractional / large net stoichiometric coefficients"; return false; }
+        p.nutab[p.n_nutab++] = c.nu;
     }
     return true;
 }
@@ -496,7 +489,7 @@ bool build_schedule(Programs& p, int NW, int IL, Schedule& out)
     v.SC = v.TB + v.NTILE;
     v.X = v.SC + SC_COUNT;
     v.NSLOT = v.X + SC_COUNT * p.nsp;
-    if (v.NTILE >= 65536 || v.NV >= 8192) { p.error = "mechanism too large for the scatter encoding"; return false; }
+    if (v.NTILE >= 32768 || v.NV >= 8192) { p.error = "mechanism too large for the scatter encoding"; return false; }
     // ownership: heaviest target to the least loaded wavefront; dense and sparse balanced separately
     std::vector<std::vector<int>> own_d(NW), own_s(NW);
     for (int pass = 0; pass < 2; ++pass) {
@@ -527,11 +520,14 @@ bool build_schedule(Programs& p, int NW, int IL, Schedule& out)
             std::partial_sort(rem.begin(), rem.begin() + take, rem.end(),
                               [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
             for (int l = 0; l < GW * IL; ++l) {
-                uint32_t code = 4u << 29;        // no-op
+                uint32_t code = 4u << 28;        // no-op (nu = 0)
                 if (l < (int)take) {
                     const int i = rem[l].second;
                     const Contrib& c = p.contribs[tg[owned[i]].terms[pos[i]++]];
-                    code = (uint32_t)c.src | ((uint32_t)tg[owned[i]].slot << 13) | ((uint32_t)(c.nu + 4) << 29);
+                    uint32_t nuc = 0;
+                    if (c.nu == std::floor(c.nu) && c.nu >= -4.0 && c.nu <= 3.0) nuc = (uint32_t)((int)c.nu + 4);
+                    else for (int t = 0; t < p.n_nutab; ++t) if (p.nutab[t] == c.nu) nuc = 8u + (uint32_t)t;
+                    code = (uint32_t)c.src | ((uint32_t)tg[owned[i]].slot << 13) | (nuc << 28);
                 }
                 codes.push_back(code);
             }
@@ -562,7 +558,8 @@ uint64_t programs_hash(const Programs& p)
     if (!p.sri.empty()) mix(p.sri.data(), p.sri.size() * 8);        // (hashes of mechanisms without them unchanged)
     if (!p.cheb.empty()) mix(p.cheb.data(), p.cheb.size() * 8);
     mix(p.net_sp.data(), p.net_sp.size() * 4); mix(p.net_nu.data(), p.net_nu.size() * 8);
-    mix(p.prog.data(), p.prog.size() * 4);
+    mix(p.smap.data(), p.smap.size() * 2);
+    if (!p.gen_sp.empty()) { mix(p.gen_sp.data(), p.gen_sp.size() * 4); mix(p.gen_nu.data(), p.gen_nu.size() * 8); }
     return h;
 }
 
@@ -602,7 +599,7 @@ std::string emit_spec_header(const Programs& p)
     int nnz = 0;
     for (int j = 0; j < nsp - 1; ++j)
         for (int k = 0; k < nsp; ++k)
-            if (p.prog[p.p4en + k + nsp * j] & 255u) sidx[(size_t)k * nsp + j] = nnz++;
+            if (p.smap[k + nsp * j] != 0xFFFF) sidx[(size_t)k * nsp + j] = nnz++;
     o += "constexpr int NSP = " + std::to_string(nsp) + ", NRXN = " + std::to_string(p.nrxn) +
          ", NNZ = " + std::to_string(nnz ? nnz : 1) + ", LASTQ = " + std::to_string(p.lastq_rxn) + ";\n";
     arr_d("SP", p.sp, SPW);
@@ -616,6 +613,8 @@ std::string emit_spec_header(const Programs& p)
     arr_d("CHEB", p.cheb, 1);
     arr_i("NET_SP", p.net_sp, 1);
     arr_d("NET_NU", p.net_nu, 1);
+    arr_i("GEN_SP", p.gen_sp, 1);      // F_GEN reactions: (species, nu) factors, RI_GEN_PTR / RI_GEN_NR / RI_GEN_NP
+    arr_d("GEN_NU", p.gen_nu, 1);
     arr_i("SIDX", sidx, nsp);
     {
         // reactions with identical equilibrium constants (same net stoichiometry: third-body
@@ -666,6 +665,9 @@ std::string emit_spec_header(const Programs& p)
         for (int k = 0; k < nsp; ++k) for (int c = 0; c < 4; ++c) spc.push_back(p.sp[(size_t)k * SPW + c]);
         dev_arr("SPT", spc, 4);
         dev_arr("SPF", p.sp, SPW);      // full species records (kept for tools)
+        std::vector<double> invw;       // 1 / W_j, contiguous: the per-column constant of the row kernels' output phase
+        for (int k = 0; k < nsp; ++k) invw.push_back(p.sp[(size_t)k * SPW]);
+        dev_arr("INVWT", invw, 1);
     }
     o += "#endif\n";
     o += "#ifdef __HIPCC__\n__device__ __attribute__((aligned(16))) const double LTAB[LT_SIZE] = {\n";
@@ -707,7 +709,7 @@ std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* 
     std::vector<int> nnz_row(nsp, 0);
     for (int j = 0; j < nsp - 1; ++j)
         for (int k = 0; k < nsp; ++k)
-            if (p.prog[p.p4en + k + nsp * j] & 255u) ++nnz_row[k];
+            if (p.smap[k + nsp * j] != 0xFFFF) ++nnz_row[k];
     std::vector<std::vector<int>> rx_of(nsp);
     for (int i = 0; i < nrxn; ++i) {
         const int32_t* ri = &p.ri[(size_t)i * RIW];
@@ -755,7 +757,7 @@ std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* 
             row_blk[k] = b; rowloc[k] = loc++;
             brows.push_back(k);
             for (int j = 0; j < nsp - 1; ++j)
-                if (p.prog[p.p4en + k + nsp * j] & 255u) sloc[(size_t)k * nsp + j] = bnnz[b]++;
+                if (p.smap[k + nsp * j] != 0xFFFF) sloc[(size_t)k * nsp + j] = bnnz[b]++;
         }
         brow_ptr.push_back((int32_t)brows.size());
         // falloff / PLOG reactions last: pj_rblk.hip reads their hand-over values from memory, and a

@@ -55,12 +55,18 @@ class Evaluator:
 
     def spec_kind(self) -> str:
         """Which specialised kernel family specialize(build=True) compiles for this mechanism."""
-        from .tables import F_CHEB, F_SRI, IA_FLAGS
-        I = self.tables.I
+        from .tables import DA_PROD_NU, DA_REAC_NU, F_CHEB, F_SRI, IA_FLAGS, IA_PROD_PTR, IA_REAC_PTR
+        I, D = self.tables.I, self.tables.D
         flags = I[I[16 + IA_FLAGS]:I[16 + IA_FLAGS] + self.n_fwd]
-        # (pj_lane.hip carries no SRI / Chebyshev code: those mechanisms take the row-block family at any size)
+        # (pj_lane.hip carries no SRI / Chebyshev code and no general stoichiometry -- fractional coefficients,
+        # more than three molecules on a side: those mechanisms take the row-block family at any size)
         small = self.nsp <= self.SPEC_MAX_NSP and self.n_fwd <= self.SPEC_MAX_RXN
-        return 'lane' if small and not any(int(f) & (F_SRI | F_CHEB) for f in flags) else 'rblk'
+        general = False
+        for ptr, nu in ((IA_REAC_PTR, DA_REAC_NU), (IA_PROD_PTR, DA_PROD_NU)):
+            pp = I[I[16 + ptr]:I[16 + ptr] + self.n_fwd + 1]
+            nn = D[I[48 + nu]:I[48 + nu] + int(pp[-1])]
+            general |= any(float(x) != int(x) for x in nn) or any(nn[pp[i]:pp[i + 1]].sum() > 3 for i in range(self.n_fwd))
+        return 'lane' if small and not general and not any(int(f) & (F_SRI | F_CHEB) for f in flags) else 'rblk'
 
     def spec_path(self, kind: str = None, **opts) -> str:
         """File name of a specialised library: mechanism hash + a digest of everything else that shapes the
@@ -124,6 +130,10 @@ class Evaluator:
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(_lib.lib().pj_mech_get_launch(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return dict(tile_states=a.value, threads=b.value, lds_bytes=c.value)
+
+    def set_check_inputs(self, on: bool):
+        """Verify T > 0, p > 0 and finite inputs before every device evaluation (one extra pass + a sync)."""
+        check(_lib.lib().pj_mech_set_check_inputs(self._h, int(on)))
 
     def set_sum_last_species(self, on: bool):
         check(_lib.lib().pj_mech_set_sum_last_species(self._h, int(on)))

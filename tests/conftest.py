@@ -17,6 +17,8 @@ MECHS = {
     'usc2_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'),
     'synth_mid24': os.path.join(GOLDEN, 'synth_mid24.inp'),     # 24 sp / 96 rxn incl. Troe, PLOG
     'synth_srichb': os.path.join(GOLDEN, 'synth_srichb.inp'),   # SRI falloff (3 / 5 parameters) + Chebyshev
+    # fractional stoichiometric coefficients, more than three molecules / species on a reaction side
+    'synth_fracnu': os.path.join(GOLDEN, 'synth_fracnu.inp'),
 }
 
 

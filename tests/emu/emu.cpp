@@ -8,7 +8,7 @@
 #include <cstring>
 #include <vector>
 struct uint2 { unsigned x, y; };
-using std::exp; using std::log; using std::fmax;
+using std::exp; using std::log; using std::fmax; using std::pow; using std::floor;
 #define PJ_DEV static inline
 #define PJ_LDS_ADD(ptr, v) (*(ptr) += (v))
 #include "../../pyjac_amd/csrc/pj_kernel.h"
@@ -56,6 +56,8 @@ extern "C" int emu_run(const int32_t* I, long nI, const double* D, long nD, long
     M.eff_sp = P.eff_sp.data(); M.eff_am1 = P.eff_am1.data(); M.kcg = P.kcg.data();
     M.plog = P.plog.data(); M.sri = P.sri.data(); M.cheb = P.cheb.data(); M.net_sp = P.net_sp.data(); M.net_nu = P.net_nu.data();
     M.sp_ptr = P.sp_ptr.data(); M.sp_rxn = P.sp_rxn.data(); M.sp_nu = P.sp_nu.data();
+    M.gen_sp = P.gen_sp.data(); M.gen_nu = P.gen_nu.data();
+    for (int t = 0; t < NUTAB_N; ++t) M.nutab[t] = P.nutab[t];
     Schedule S;
     if (!build_schedule(P, NT / 64, 64 / TS, S)) return -3;
     M.v = P.vm; M.nv = P.vm.NV;

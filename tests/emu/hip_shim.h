@@ -36,7 +36,7 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { static int dum
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return hipSuccess; }
-using std::exp; using std::log; using std::fmax;
+using std::exp; using std::log; using std::fmax; using std::pow; using std::floor;
 
 // clang / AMDGPU builtins used by the kernels
 #define __builtin_nontemporal_store(val, ptr) (*(ptr) = (val))

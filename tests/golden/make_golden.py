@@ -29,6 +29,7 @@ CASES = {
     'usc2_shaped': os.path.join(ROOT, 'pyjac_amd', 'data', 'usc2_shaped.inp'),
     'synth_mid24': os.path.join(HERE, 'synth_mid24.inp'),
     'synth_srichb': os.path.join(HERE, 'synth_srichb.inp'),     # SRI falloff + Chebyshev rate forms
+    'synth_fracnu': os.path.join(HERE, 'synth_fracnu.inp'),     # fractional nu, > 3 molecules per side
 }
 
 

@@ -1,7 +1,8 @@
-"""CPU, world_size 2, gloo: bench.py's own multi-rank branch (launch through torch.distributed.run,
-partition, barriers, MAX-reduce of the elapsed time, validation all-gather + checksums) with a CPU
-stand-in for the evaluator (PJ_BENCH_STUB=1), so that the first 8-GPU run of the driver is not also the
-first execution of that code."""
+"""CPU, world_size 2, gloo: bench.py's main() itself -- launch through torch.distributed.run, per-rank states,
+barriers, MAX-reduce of the elapsed time, the chunked validation all-gather, the recomputation of a remote rank's
+states and the checksums -- with a CPU stand-in for the evaluator that this directory supplies
+(PJ_BENCH_EVALUATOR=stub_evaluator:make, Jacobians from the oracle), so that the first 8-GPU run of the driver is
+not also the first execution of that code."""
 import json
 import os
 import socket
@@ -16,15 +17,21 @@ def test_bench_multi_rank_branch_over_gloo():
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, PJ_BENCH_STUB='1', MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, PJ_BENCH_EVALUATOR='stub_evaluator:make', MASTER_ADDR='127.0.0.1', PJ_VALIDATE_CHUNK='100',
+               PYTHONPATH=os.path.join(ROOT, 'tests') + os.pathsep + os.environ.get('PYTHONPATH', ''))
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
                           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
-                          '--gpus', '2', '--steps', '3', '--warmup', '1'], env=env, capture_output=True, text=True,
+                          '--gpus', '2', '--steps', '3', '--warmup', '1', '--workload', 'h2', '--states', '700',
+                          '--validate-states', '512', '--no-cpu-baseline'], env=env, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1                   # rank 0 prints ONE JSON line
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['steps'] == 3 and j['warmup'] == 1 and j['scaling'] == 'weak'
-    assert j['validation_allgather']['ok'] is True
+    v = j['validation_allgather']
+    assert v['ok'] is True and v['states_per_rank'] == 512 and v['remote_rank_checked'] == 1
+    assert v['remote_states_recomputed'] >= 64 and v['remote_max_rel_diff'] == 0.0
+    assert v['gathered_bytes'] == 2 * 100 * 512 * 8          # 2 ranks x NSP^2 rows x 512 states, in 100-state chunks
+    assert j['metric'] == 'fp64 analytical Jacobians/s' and j['config']['states_per_gpu'] == 700
     assert j['value'] > 0 and j['ms_per_step'] > 0

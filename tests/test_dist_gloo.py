@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pyjac_amd.dist import gather_shards, global_entry, shard_checksums, shard_range
+from pyjac_amd.dist import gather_shards, global_entry, iter_gathered, shard_checksums, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -40,6 +40,12 @@ def _worker(rank, world, port, n, rows, q):
         ok = g.shape == (world, rows, n // world)
         for st in (0, n // world - 1, n // world, n - 1):
             ok &= torch.equal(global_entry(g, st, n, world), _fake_jac(st, st + 1, rows)[:, 0])
+        # the same gathered batch, 77 states at a time through one receive buffer (ragged last chunk)
+        seen = 0
+        for c0, part in iter_gathered(local, 77):
+            ok &= torch.equal(part, g[:, :, c0:c0 + part.shape[2]])
+            seen += part.shape[2]
+        ok &= seen == n // world
         cs = shard_checksums(local)
         ok &= torch.allclose(cs[rank], torch.stack([local.sum(), (local * local).sum()]))
         ok &= cs.shape == (world, 2)

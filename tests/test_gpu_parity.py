@@ -76,7 +76,7 @@ def _batch_api(ev, pres, y_soa):
     return {k: v.reshape(-1, n).T for k, v in out.items()}
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'synth_srichb'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'synth_srichb', 'synth_fracnu'])
 def test_batch_api_matches_reference_golden(name, golden, tables, torch_cuda):
     g = golden(name)
     ev = _ev(name)
@@ -663,10 +663,15 @@ def test_table_file_through_c_abi_only(tmp_path, tables, torch_cuda):
     L.pj_mech_destroy(h)
 
 
+@pytest.mark.parametrize('name', ['synth_srichb', 'synth_fracnu'])
 @pytest.mark.parametrize('path', ['k_eval', 'rblk'])
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
-def test_sri_and_chebyshev_rate_forms(path, layout, tables, golden, torch_cuda):
-    """N4: SRI falloff (3 and 5 parameters, LOW and HIGH, with efficiencies and with a collider species) and
+def test_sri_chebyshev_and_general_stoichiometry(name, path, layout, tables, golden, torch_cuda):
+    """N1 (synth_fracnu): fractional stoichiometric coefficients (pow(C, nu) in the rates, nu C^(nu-1) in the
+    Jacobian with the reference's "(nu - 1) > 0" quirk), more than three molecules / species on a side, on
+    elementary, third-body and Troe falloff reactions and with the last species as a reactant
+    (mech_interpret.py:300-318, 398-416; rate_subs.py:634-658; create_jacobian.py:400-448).
+    N4 (synth_srichb): SRI falloff (3 and 5 parameters, LOW and HIGH, with efficiencies and with a collider species) and
     Chebyshev rate expressions (reversible and not), through the table-driven kernel and through the
     row-block family (where the pre-pass evaluates them), against the oracle on random states and against
     vectors from pyJac's generated C: Jacobian and every rate output."""
@@ -674,7 +679,6 @@ def test_sri_and_chebyshev_rate_forms(path, layout, tables, golden, torch_cuda):
     from oracle.oracle import Oracle
     from pyjac_amd import synth
     torch = torch_cuda
-    name = 'synth_srichb'
     ev = _ev(name)
     assert ev.spec_kernel == 'pj_rblk'
     ev.use_spec(2 if path == 'rblk' else 0)
@@ -709,3 +713,30 @@ def test_sri_and_chebyshev_rate_forms(path, layout, tables, golden, torch_cuda):
     gross, sdy = rate_scales(tables(name), pres, y_aos, ref['conc'], ref['fwd'], ref['rev'], ref['pres_mod'])
     assert mixed_err(r['spec_rates'], ref['spec_rates'], gross[:, None]) <= 1.0
     assert mixed_err(r['dydt'], ref['dydt'], sdy) <= 1.0
+
+
+def test_optional_precondition_check(torch_cuda):
+    """pj_mech_set_check_inputs: T <= 0, p <= 0 or a non-finite input is refused with the index of the first
+    offending state instead of producing undefined results (off by default, as in the reference)."""
+    import pyjac_amd
+    from pyjac_amd import _lib, synth
+    torch = torch_cuda
+    ev = _ev('h2o2_n2')
+    n = 1000
+    pres, y = synth.dist_a(n, ev.nsp)
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    ev.set_check_inputs(True)
+    ev.jacobian(d_p, d_y)                      # clean batch passes
+    for row, col, val in ((0, 417, -5.0), (3, 12, float('nan')), (0, 999, 0.0)):
+        bad = d_y.clone()
+        bad[row, col] = val
+        with pytest.raises(_lib.PyjacError, match='state %d' % col):
+            ev.jacobian(d_p, bad)
+        with pytest.raises(_lib.PyjacError, match='state %d' % col):
+            ev.rates(d_p, bad, want=('dydt',))
+    badp = d_p.clone()
+    badp[5] = float('inf')
+    with pytest.raises(_lib.PyjacError, match='state 5'):
+        ev.jacobian(badp, d_y)
+    ev.set_check_inputs(False)
+    ev.jacobian(badp, d_y)                     # unchecked: no error (results for that state undefined)

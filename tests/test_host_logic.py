@@ -123,7 +123,8 @@ def _run_emu(tab, pres, y_soa, TS, NT, aos):
                                             ('synth_alltypes', 4, 128, True),
                                             ('synth_alltypes', 64, 64, False),
                                             ('synth_alltypes', 1, 64, True),
-                                            ('synth_srichb', 16, 256, False), ('synth_srichb', 1, 64, True)])
+                                            ('synth_srichb', 16, 256, False), ('synth_srichb', 1, 64, True),
+                                            ('synth_fracnu', 16, 256, False), ('synth_fracnu', 1, 64, True)])
 def test_kernel_phases_match_oracle(name, TS, NT, aos, tables):
     tab = tables(name)
     o = Oracle(tab)

@@ -11,7 +11,7 @@ KEYS = ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')
 
 
 @pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24',
-                                  'synth_srichb'])
+                                  'synth_srichb', 'synth_fracnu'])
 def test_oracle_matches_reference_golden(name, golden, tables):
     g = golden(name)
     tab = tables(name)
@@ -40,7 +40,8 @@ def test_oracle_writes_full_jacobian_block(tables):
     assert np.isfinite(jac).all()
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24', 'synth_srichb'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24', 'synth_srichb',
+                                  'synth_fracnu'])
 def test_oracle_matches_reference_live(name, tables):
     if not Reference.available(name):
         pytest.skip('oracle/_ref not built (no /root/reference here)')

@@ -28,6 +28,8 @@ def _rblk_emu_lib(name, budget, tmp, **kw):
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=1000)),
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
+    # N1: fractional stoichiometric coefficients, more than three molecules / species per side
+    ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6)),
 ])
 def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     """k_rate (pj_spec_rates of the row-block library): conc, fwd, rev, pres_mod, spec_rates handed from
@@ -74,6 +76,10 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_DEPTH=1',))),
     # SRI falloff (3 / 5 parameters, LOW / HIGH, collider) and Chebyshev reactions: evaluated by the pre-pass
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
+    # N1: fractional stoichiometric coefficients (pow), more than three molecules / species per side, also on
+    # third-body and falloff reactions and with the last species as a reactant
+    ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6)),
+    ('synth_fracnu', 200, dict(blocks_per_part=1, rates_per_part=1000, c_lds=1)),
 ])
 def test_rblk_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     """Row blocks that rebuild their rates (Arrhenius, K_c, third body, theta per visit), the falloff /
