@@ -67,6 +67,13 @@ int pj_mech_set_sum_last_species(pj_mech* m, int on);
  * return PJ_EINVAL naming the first offending state; costs one pass over the inputs and a stream
  * synchronisation.  0 (default): no check, as in the reference (undefined results for such states). */
 int pj_mech_set_check_inputs(pj_mech* m, int on);
+/* Which kernel evaluates Jacobians when no mechanism-specific library is attached (or pj_mech_use_spec(m, 0)):
+ * 2 k_tab -- table-driven, one state per lane, row blocks with accumulators in LDS, wavefront-uniform control
+ * flow over a program built at load time (csrc/pj_tab.h; the formulation of the compiled row-block kernels: every
+ * entry within rtol 1e-6 of the exact value); 0 k_eval -- the cooperative kernel (a workgroup per tile of states),
+ * which also serves every rate output; 1 (default) k_tab for SoA Jacobians, k_eval for AoS ones (each one's
+ * faster layout).  No compiler is needed for either.  PJ_EUNSUPPORTED if k_tab cannot hold the mechanism. */
+int pj_mech_set_generic_kernel(pj_mech* m, int which);
 /* launch tuning: states per workgroup tile (power of two <= 64, 0 = auto),
  * threads per workgroup (multiple of 64, 0 = auto) */
 int pj_mech_set_launch(pj_mech* m, int tile_states, int threads);

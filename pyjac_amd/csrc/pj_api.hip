@@ -11,6 +11,7 @@
 
 #define PJ_DEV __device__ __forceinline__
 #include "pj_kernel.h"
+#include "pj_tab.h"
 #include "../../include/pyjac_amd.h"
 
 using namespace pj;
@@ -134,6 +135,25 @@ k_eval(DevMech M, Batch B, int mode, const double* cin, const double* Tin, doubl
 }
 
 // eval_spec_rates from caller-supplied rates (pyjacob_wrapper.pyx:11); one thread per state
+// ---- k_tab / k_tab_fin: the table-driven state-per-lane Jacobian kernels (pj_tab.h, pj_tabprog.h) ----
+// 256 threads: G lane groups on the same L = 256 / G states; LDS: concentration columns + the groups' accumulators
+__global__ void __launch_bounds__(256) k_tab(DevMech M, TabDev P, Batch B)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    TabLane Ln;
+    tab_stage(M, P, B, lds, (int)threadIdx.x, (long)blockIdx.x, Ln);
+    __syncthreads();
+    tab_blocks(M, P, B, lds, (int)threadIdx.x, Ln);
+}
+
+__global__ void __launch_bounds__(256) k_tab_fin(DevMech M, TabDev P, Batch B)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    tab_fin_stage(M, P, B, lds, (int)threadIdx.x, (long)blockIdx.x);
+    __syncthreads();
+    tab_fin_cols(M, P, B, lds, (int)threadIdx.x, (long)blockIdx.x);
+}
+
 __global__ void k_spec_rates(DevMech M, long n, const double* fwd, const double* rev,
                              const double* pm, double* sr)
 {
@@ -264,6 +284,13 @@ struct pj_mech {
     double* jv_tmp = nullptr;    // Jacobian chunk of the unfused J*v path
     size_t jv_tmp_doubles = 0;
     int use_spec = 1;          // 0: never, 1: SoA Jacobians (default), 2: every layout
+    // table-driven state-per-lane Jacobian kernel (pj_tab.h): program built at load time, scratch per handle
+    TabProg tab;
+    DevBuf<int32_t> tab_I;
+    DevBuf<double> tab_D, tab_E;
+    double* tab_scr = nullptr;
+    long tab_scr_ld = 0;
+    int generic = 1;           // Jacobians without an attached library: 1 k_tab for SoA / k_eval for AoS, 0 k_eval, 2 k_tab
     int check_inputs = 0;      // 1: the *_dev entry points verify T > 0, p > 0, finite (one extra pass + a sync)
     unsigned long long* d_bad = nullptr;
 };
@@ -306,6 +333,12 @@ int ensure_device(pj_mech* m)
     HIPCHK(m->net_sp.upload(P.net_sp)); HIPCHK(m->net_nu.upload(P.net_nu));
     HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
     HIPCHK(m->gen_sp.upload(P.gen_sp)); HIPCHK(m->gen_nu.upload(P.gen_nu));
+    if (m->tab.ok) {
+        // (the visit stream is read a little past its end by the look-ahead of the last visit: padded)
+        m->tab.I.resize(m->tab.I.size() + 64, 0);
+        m->tab.D.resize(m->tab.D.size() + 64, 0.0);
+        HIPCHK(m->tab_I.upload(m->tab.I)); HIPCHK(m->tab_D.upload(m->tab.D)); HIPCHK(m->tab_E.upload(m->tab.E));
+    }
     DevMech& M = m->M;
     M.gen_sp = m->gen_sp.p; M.gen_nu = m->gen_nu.p;
     for (int t = 0; t < NUTAB_N; ++t) M.nutab[t] = P.nutab[t];
@@ -386,12 +419,51 @@ int launch_ts(pj_mech* m, const Batch& B, int mode, const double* cin, const dou
     return PJ_OK;
 }
 
+// Jacobians only, no attached library: k_tab + k_tab_fin
+int launch_tab(pj_mech* m, const Batch& B, hipStream_t st)
+{
+    const TabProg& T = m->tab;
+    const long nsp = m->P.nsp;
+    if (m->tab_scr_ld < B.n) {
+        if (m->tab_scr) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(m->tab_scr); m->tab_scr = nullptr; m->tab_scr_ld = 0; }
+        hipError_t e = hipMalloc((void**)&m->tab_scr, sizeof(double) * (size_t)(nsp + 1) * (size_t)B.n);
+        if (e != hipSuccess) return fail(PJ_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        m->tab_scr_ld = B.n;
+    }
+    TabDev X;
+    X.L = T.L; X.G = T.G; X.B = T.B; X.ZERO = T.ZERO; X.TRASH = T.TRASH;
+    X.I = m->tab_I.p; X.D = m->tab_D.p; X.E = m->tab_E.p;
+    X.o_grp_ptr = T.o_grp_ptr; X.o_grp_blk = T.o_grp_blk; X.o_blk = T.o_blk; X.o_row = T.o_row; X.o_ent = T.o_ent; X.o_vi = T.o_vi;
+    X.scr = m->tab_scr; X.scr_ld = m->tab_scr_ld;
+    static const int tab_dbg = getenv("PJ_TAB_DBG") ? atoi(getenv("PJ_TAB_DBG")) : 0;
+    X.dbg = tab_dbg;
+    static thread_local size_t configured = 0, configured_fin = 0;
+    if (T.lds_bytes > 64 * 1024 && T.lds_bytes > configured) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T.lds_bytes));
+        configured = T.lds_bytes;
+    }
+    const size_t lds_fin = sizeof(double) * (size_t)(nsp + 28) * 64;
+    if (lds_fin > 64 * 1024 && lds_fin > configured_fin) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_tab_fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin));
+        configured_fin = lds_fin;
+    }
+    hipLaunchKernelGGL(k_tab, dim3((unsigned)((B.n + T.L - 1) / T.L)), dim3(256), T.lds_bytes, st, m->M, X, B);
+    hipLaunchKernelGGL(k_tab_fin, dim3((unsigned)((B.n + 63) / 64)), dim3(256), lds_fin, st, m->M, X, B);
+    HIPCHK(hipGetLastError());
+    return PJ_OK;
+}
+
 int launch(pj_mech* m, const Batch& B, int mode, const double* cin, const double* Tin, double* aux,
            hipStream_t st)
 {
     if (B.n <= 0) return PJ_OK;
     int rc = ensure_device(m);
     if (rc) return rc;
+    // Jacobians only: k_tab for lane-contiguous (SoA) blocks -- its stores are 512-byte runs there --, the
+    // cooperative k_eval for AoS blocks (its native output order: 47 against 66 ms per 1e6 GRI-shaped Jacobians)
+    if (mode == MODE_JAC && !cin && !Tin && !aux && m->tab.ok && !B.conc && !B.fwd && !B.rev && !B.pres_mod &&
+        !B.spec_rates && !B.dy && (m->generic == 2 || (m->generic == 1 && B.j_ss == 1)))
+        return launch_tab(m, B, st);
     int ts, nt;
     size_t lds;
     rc = pick_launch(m, &ts, &nt, &lds);
@@ -476,6 +548,13 @@ int pj_mech_create(const int32_t* I, long nI, const double* D, long nD, pj_mech*
         delete m;
         return fail(PJ_ENOMEM, std::string("mechanism tables: ") + ex.what());
     }
+    try {
+        // the run-time program of k_tab (a mechanism it cannot hold falls back to k_eval: tab.ok stays false)
+        (void)build_tab_program(m->P, 156 * 1024, m->tab);
+    } catch (const std::exception&) {
+        m->tab.ok = false;
+    }
+    if (const char* e = getenv("PJ_GENERIC")) m->generic = atoi(e);
     DevMech& M = m->M;
     memset(&M, 0, sizeof(M));
     M.nsp = m->P.nsp; M.nrxn = m->P.nrxn; M.ng = m->P.ng; M.ne = m->P.ne; M.nv = m->P.vm.NV;
@@ -519,6 +598,9 @@ void pj_mech_destroy(pj_mech* m)
         m->net_nu.release(); m->sp_nu.release(); m->sched.release(); m->ri.release(); m->eff_sp.release();
         m->fin_tgt.release(); m->fin_part.release(); m->fin_cnt.release();
         m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release(); m->gen_sp.release(); m->gen_nu.release();
+        m->tab_I.release(); m->tab_D.release(); m->tab_E.release();
+        if (m->tab_scr) (void)hipFree(m->tab_scr);
+        if (m->d_bad) (void)hipFree(m->d_bad);
         m->ws.release(); m->ws1.release();
     }
     if (m->spec_lib) dlclose(m->spec_lib);
@@ -531,6 +613,14 @@ int pj_mech_rev_rates(const pj_mech* m) { return m->P.nrev; }
 int pj_mech_pres_mod_rates(const pj_mech* m) { return m->P.npres; }
 
 int pj_mech_set_sum_last_species(pj_mech* m, int on) { m->M.sum_last = on ? 1 : 0; return PJ_OK; }
+
+int pj_mech_set_generic_kernel(pj_mech* m, int which)
+{
+    if (!m || which < 0 || which > 2) return fail(PJ_EINVAL, "bad argument");
+    if (which == 2 && !m->tab.ok) return fail(PJ_EUNSUPPORTED, "k_tab cannot hold this mechanism: " + m->tab.error);
+    m->generic = which;
+    return PJ_OK;
+}
 
 int pj_mech_set_check_inputs(pj_mech* m, int on) { if (!m) return fail(PJ_EINVAL, "bad argument"); m->check_inputs = on ? 1 : 0; return PJ_OK; }
 

@@ -447,7 +447,7 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         const double theta = (fl & F_NO_DT) ? 0.0 : (lead + c * invT * el) * L.invrho;
 
         // ---- dense-in-j scalars (create_jacobian.py:127-269) ----
-        const double a = c * (nr * Rf - ((fl & F_REV) ? np_ * Rr : 0.0)) + a_extra;
+        // (q - a with a = c (nr R_f - np R_r) + a_extra is formed below so that nothing cancels when nr or np is 1)
 
         // ---- sparse column values g (one per molecule slot) ----
         const double ckf = c * kf * kf_jac_ratio, ckr = c * kr * kf_jac_ratio;
@@ -494,7 +494,7 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
             }
 
         const double q = c * R;
-        const double rp = (L.Wbar * L.invrho) * (q - a) + bM;
+        const double rp = (L.Wbar * L.invrho) * (c * ((1.0 - nr) * Rf - ((fl & F_REV) ? (1.0 - np_) * Rr : 0.0)) - a_extra) + bM;
         V[(M.v.RQ + i) * TS + s] = q;
         V[(M.v.RTH + i) * TS + s] = theta;
         V[(M.v.RP + i) * TS + s] = rp;

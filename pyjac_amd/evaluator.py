@@ -131,6 +131,11 @@ class Evaluator:
         check(_lib.lib().pj_mech_get_launch(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return dict(tile_states=a.value, threads=b.value, lds_bytes=c.value)
 
+    def set_generic_kernel(self, name: str):
+        """'auto' (default: k_tab for SoA Jacobians, k_eval for AoS ones), 'k_tab' (table-driven state-per-lane
+        row blocks) or 'k_eval' (cooperative kernel) for Jacobians evaluated without an attached library."""
+        check(_lib.lib().pj_mech_set_generic_kernel(self._h, {'k_eval': 0, 'auto': 1, 'k_tab': 2}[name]))
+
     def set_check_inputs(self, on: bool):
         """Verify T > 0, p > 0 and finite inputs before every device evaluation (one extra pass + a sync)."""
         check(_lib.lib().pj_mech_set_check_inputs(self._h, int(on)))

@@ -11,8 +11,12 @@ struct uint2 { unsigned x, y; };
 using std::exp; using std::log; using std::fmax; using std::pow; using std::floor;
 #define PJ_DEV static inline
 #define PJ_LDS_ADD(ptr, v) (*(ptr) += (v))
+#define PJT_CONST
+#define PJ_UNIFORM(x) (x)
 #include "../../pyjac_amd/csrc/pj_kernel.h"
+#include "../../pyjac_amd/csrc/pj_tab.h"
 #include "../../pyjac_amd/csrc/pj_tables.cpp"
+#include "../../pyjac_amd/csrc/pj_tabprog.cpp"
 
 using namespace pj;
 
@@ -76,6 +80,50 @@ extern "C" int emu_run(const int32_t* I, long nI, const double* D, long nD, long
         case 4: run_tiles<4>(M, B, NT, jac != nullptr); break;
         case 1: run_tiles<1>(M, B, NT, jac != nullptr); break;
         default: return -2;
+    }
+    return 0;
+}
+
+
+// k_tab / k_tab_fin (pj_tab.h) thread by thread: the stage of every thread of a workgroup, then its row blocks
+// (what __syncthreads() separates on the GPU), then the energy-row kernel the same way.  info[0..5]: L, G, B,
+// blocks, visits, LDS bytes of the program that build_tab_program chose for `lds_avail`.
+extern "C" int emu_tab_run(const int32_t* I, long nI, const double* D, long nD, long n, const double* pres,
+                           const double* y_soa, double* jac, int jac_aos, int sum_last, long lds_avail, int* info)
+{
+    Programs P;
+    if (!build_programs(I, nI, D, nD, P)) return -1;
+    TabProg T;
+    if (!build_tab_program(P, (size_t)lds_avail, T)) return -2;
+    if (info) { info[0] = T.L; info[1] = T.G; info[2] = T.B; info[3] = T.nblk; info[4] = T.nvisit; info[5] = (int)T.lds_bytes; }
+    DevMech M;
+    memset(&M, 0, sizeof(M));
+    M.nsp = P.nsp; M.nrxn = P.nrxn; M.lastq_rxn = P.lastq_rxn; M.sum_last = sum_last;
+    M.sp = P.sp.data(); M.ri = P.ri.data(); M.rd = P.rd.data();
+    M.eff_sp = P.eff_sp.data(); M.eff_am1 = P.eff_am1.data(); M.kcg = P.kcg.data();
+    M.plog = P.plog.data(); M.sri = P.sri.data(); M.cheb = P.cheb.data();
+    M.gen_sp = P.gen_sp.data(); M.gen_nu = P.gen_nu.data();
+    std::vector<double> scr((size_t)(P.nsp + 1) * n);
+    TabDev X;
+    X.L = T.L; X.G = T.G; X.B = T.B; X.ZERO = T.ZERO; X.TRASH = T.TRASH;
+    T.I.resize(T.I.size() + 64, 0); T.D.resize(T.D.size() + 64, 0.0);      // look-ahead of the last visit
+    X.I = T.I.data(); X.D = T.D.data(); X.E = T.E.data();
+    X.o_grp_ptr = T.o_grp_ptr; X.o_grp_blk = T.o_grp_blk; X.o_blk = T.o_blk; X.o_row = T.o_row; X.o_ent = T.o_ent; X.o_vi = T.o_vi;
+    X.scr = scr.data(); X.scr_ld = n; X.dbg = 0;
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    B.n = n; B.pres = pres; B.y = y_soa; B.y_si = n; B.y_ss = 1; B.jac = jac;
+    if (jac_aos) { B.j_si = 1; B.j_ss = (long)P.nsp * P.nsp; } else { B.j_si = n; B.j_ss = 1; }
+    std::vector<double> lds(T.lds_bytes / 8 + 16, std::nan(""));
+    std::vector<TabLane> Ln(256);
+    for (long wg = 0; wg * T.L < n; ++wg) {
+        for (int tid = 0; tid < 256; ++tid) tab_stage(M, X, B, lds.data(), tid, wg, Ln[tid]);
+        for (int tid = 0; tid < 256; ++tid) tab_blocks(M, X, B, lds.data(), tid, Ln[tid]);
+    }
+    std::vector<double> lds2((size_t)(P.nsp + 28) * 64 + 16, std::nan(""));
+    for (long wg = 0; wg * 64 < n; ++wg) {
+        for (int tid = 0; tid < 256; ++tid) tab_fin_stage(M, X, B, lds2.data(), tid, wg);
+        for (int tid = 0; tid < 256; ++tid) tab_fin_cols(M, X, B, lds2.data(), tid, wg);
     }
     return 0;
 }

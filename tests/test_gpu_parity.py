@@ -102,7 +102,8 @@ def test_every_tile_mapping_and_layout(ts, layout, tables, torch_cuda):
     torch = torch_cuda
     name = 'synth_alltypes'
     ev = _ev(name)
-    ev.use_spec(False)          # this test is about the table-driven kernel's mappings
+    ev.use_spec(False)          # this test is about the cooperative table-driven kernel's mappings
+    ev.set_generic_kernel('k_eval')
     ev.set_launch(ts, 256)
     if ev.get_launch()['lds_bytes'] > 160 * 1024:
         pytest.skip('tile of %d states needs %d B of LDS' % (ts, ev.get_launch()['lds_bytes']))
@@ -212,7 +213,7 @@ def test_empty_and_single_state(torch_cuda):
 
 @pytest.mark.parametrize('name,n', [('gri30_shaped', 300), ('usc2_shaped', 160), ('usc2_shaped', 60)])
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
-@pytest.mark.parametrize('kernel', ['row_blocks', 'k_eval'])
+@pytest.mark.parametrize('kernel', ['row_blocks', 'k_tab', 'k_eval'])
 def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda):
     """Configs 3-5 (GRI-3.0-shaped 53 sp / 325 rxn; USC-II-shaped 111 sp / 784 rxn
     with PLOG; the species order is permuted so N2 ends up last), through the state-per-lane
@@ -228,8 +229,11 @@ def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda)
         assert ev.has_spec and ev.spec_kernel == 'pj_rblk', 'row-block library missing: run __graft_entry__.build()'
         ev.use_spec(2)
     else:
+        # the two paths that need no compiler: k_tab (state per lane, row blocks with LDS accumulators, program
+        # built at load time) and k_eval (a workgroup per state tile)
         ev.use_spec(False)
-        if ev.get_launch()['lds_bytes'] > 160 * 1024:
+        ev.set_generic_kernel(kernel)
+        if kernel == 'k_eval' and ev.get_launch()['lds_bytes'] > 160 * 1024:
             pytest.skip('working set of one state exceeds LDS: %d B' % ev.get_launch()['lds_bytes'])
     pres, y = synth.dist_b(n, ev.nsp, seed=21, Tlo=500, Thi=2600)
     d_p = torch.from_numpy(pres).cuda()
@@ -247,6 +251,12 @@ def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda)
     assert sc <= 1.0 and fro < 1e-9 and mx < MX_BIG[name], (name, layout, sc, mx, fro)
     _check_vs_truth('%s %s %s n=%d' % (name, layout, kernel, n), name, jac, ref,
                     _truth(name, tables, pres, y.T, ('dist_b21', n)), ev.nsp, table_driven=(kernel == 'k_eval'))
+    if kernel == 'k_tab':
+        # the same states through the cooperative kernel: the two no-compile paths agree
+        ev.set_generic_kernel('k_eval')
+        if ev.get_launch()['lds_bytes'] <= 160 * 1024:
+            other = ev.jacobian(d_p, torch.from_numpy(y).cuda()).cpu().numpy().T
+            assert jac_scaled_err(other, jac, ev.nsp) <= 1.0
 
 
 @pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])

@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import MECHS, ROOT, thresholded_rel_err
+from conftest import jac_scaled_err, MECHS, ROOT, thresholded_rel_err
 from oracle.oracle import Oracle
 from pyjac_amd import synth
 from pyjac_amd.mechanism import read_mech
@@ -139,6 +139,49 @@ def test_kernel_phases_match_oracle(name, TS, NT, aos, tables):
     ref_d = o.batch_dydt(pres, np.ascontiguousarray(y.T))
     mx, _ = thresholded_rel_err(out['dydt'].reshape(-1, n).T, ref_d)
     assert mx < 1e-10
+
+
+@pytest.mark.parametrize('name,lds_kb,aos,sum_last', [
+    ('h2o2_n2', 156, False, 0), ('synth_alltypes', 156, True, 1),
+    ('synth_alltypes', 30, False, 0),        # 64 states x 4 lane groups, 12 slots: rows split into column parts
+    ('synth_srichb', 156, False, 0), ('synth_fracnu', 40, True, 0), ('synth_mid24', 156, False, 1),
+    ('gri30_shaped', 156, False, 0),         # 128 states x 2 lane groups
+    ('usc2_shaped', 156, False, 0),          # 64 states x 4 lane groups, hub rows split
+])
+def test_table_driven_lane_kernel_matches_oracle(name, lds_kb, aos, sum_last, tables):
+    """k_tab / k_tab_fin (csrc/pj_tab.h: the state-per-lane kernel that needs no compilation; program built by
+    pj_tabprog.cpp) thread by thread on the host: stage, row blocks with accumulators in "LDS", output phase,
+    energy row from the finished species rows -- against the oracle, and entry-wise against the binary128 truth
+    for the two large mechanisms (the regrouped formulation is held to rtol 1e-6 on every entry)."""
+    tab = tables(name)
+    n = 70 if tab.nsp <= 30 else 24
+    pres, y = synth.dist_b(n, tab.nsp, seed=5, Tlo=500, Thi=2700)
+    I = np.ascontiguousarray(tab.I, dtype=np.int32)
+    D = np.ascontiguousarray(tab.D)
+    jac = np.full(tab.nsp * tab.nsp * n, np.nan)
+    info = (ctypes.c_int * 6)()
+    P = lambda a: a.ctypes.data_as(_dp)
+    rc = _emu().emu_tab_run(I.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.c_long(I.size), P(D),
+                            ctypes.c_long(D.size), ctypes.c_long(n), P(pres), P(np.ascontiguousarray(y)), P(jac),
+                            int(aos), sum_last, ctypes.c_long(lds_kb * 1024), info)
+    assert rc == 0
+    L, G, B = info[0], info[1], info[2]
+    assert L * G == 256 and info[5] <= lds_kb * 1024 and tab.nsp * L * 8 + 256 * B * 8 == info[5]
+    got = jac.reshape(n, -1) if aos else jac.reshape(-1, n).T
+    assert not np.isnan(got).any()           # every entry written
+    o = Oracle(tab)
+    o.lib.pjo_set_sum_last_species(sum_last)
+    try:
+        ref = o.batch_jacob(pres, np.ascontiguousarray(y.T))
+    finally:
+        o.lib.pjo_set_sum_last_species(0)
+    assert jac_scaled_err(got, ref, tab.nsp) <= 1.0
+    _, fro = thresholded_rel_err(got, ref)
+    assert fro < 1e-12
+    if tab.nsp > 30 and not sum_last:
+        from oracle.oracle import OracleQuad
+        mx, _ = thresholded_rel_err(got, OracleQuad(tab).batch_jacob(pres, np.ascontiguousarray(y.T)))
+        assert mx < 1e-7, mx
 
 
 def test_generated_build_dir_matches_reference_callers(tmp_path):

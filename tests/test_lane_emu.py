@@ -104,8 +104,7 @@ def test_random_mechanisms_lane_and_rows(seed, tmp_path):
     # the row-block kernels on the same mechanism, fine partition
     hdr = os.path.join(str(tmp_path), 'rows%d.h' % seed)
     _lib.check(_lib.lib().pj_mech_emit_rows_spec(ev._h, hdr.encode(), 14))
-    so = build_emu.build(hdr, os.path.join(str(tmp_path), 'librows%d.so' % seed), blocks_per_part=3,
-                              rates_per_part=9, defines=('-DPJR_RECOMPUTE_KR=1',))
+    so = build_emu.build_rblk(hdr, os.path.join(str(tmp_path), 'librblk%d.so' % seed), blocks_per_part=3, rates_per_part=9)
     R = ctypes.CDLL(so)
     R.pj_spec_jacobian.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp, ctypes.c_long,
                                    ctypes.c_long, ctypes.c_int, ctypes.c_void_p]

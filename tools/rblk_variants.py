@@ -42,12 +42,16 @@ def main():
     ref = None
     for tag in tags:
         ev = pyjac_amd.Evaluator(mech, specialize='off')
-        if tag == 'rblk':      # whatever prebuilt library of that family exists (any build digest)
+        if tag in ('tab', 'keval'):     # the no-compile paths: table-driven state-per-lane kernel / cooperative kernel
+            ev.set_generic_kernel('k_tab' if tag == 'tab' else 'k_eval')
+            so = None
+        elif tag == 'rblk':      # whatever prebuilt library of that family exists (any build digest)
             pat = os.path.basename(ev.spec_path(tag)).rsplit('_', 1)[0] + '_*.so'
             so = sorted(glob.glob(os.path.join(ROOT, 'pyjac_amd', 'spec', pat)))[-1]
         else:
             so = os.path.join(VDIR, '%s_%s.so' % (stem, tag))
-        _lib.check(_lib.lib().pj_mech_attach_spec(ev._h, so.encode()))
+        if so:
+            _lib.check(_lib.lib().pj_mech_attach_spec(ev._h, so.encode()))
         jac.fill_(float('nan'))
         ev.time_jacobian(d_p, d_y, jac, 2, L, L)
         ms = min(ev.time_jacobian(d_p, d_y, jac, 4, L, L) for _ in range(2))
@@ -57,7 +61,7 @@ def main():
             ref = sample
         line = '%-14s %8.3f ms  %.3g Jac/s  frac %.3f   vs first: %.2g  nan=%d' % (
             tag, ms, n / ms * 1e3, n * bj / ms / 1e6 / 8000, jac_scaled_err(sample, ref, ev0.nsp), int(np.isnan(sample).sum()))
-        if os.environ.get('PJ_VAR_RATES', '1') != '0':
+        if os.environ.get('PJ_VAR_RATES', '1') != '0' and so:
             line += ' | rates' + rates_ms(ev, d_p, d_y, n, torch)
         print(line, flush=True)
         ev.close()
