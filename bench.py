@@ -378,6 +378,20 @@ def main():
                              '%d bytes per state' % (bjv, bj))
                 except Exception as ex:
                     line['also']['fused_jacobian_vector_product'] = {'error': repr(ex)}
+                # the path a user without a compiler gets: the same batch through the table-driven kernels (no
+                # mechanism-specific library: k_tab for this SoA batch) -- reported, never part of `value`
+                try:
+                    ev0 = pyjac_amd.Evaluator(w['mech'], specialize='off')
+                    ev0.time_jacobian(d_p, d_y, jac, 1, L, L)
+                    ms0 = ev0.time_jacobian(d_p, d_y, jac, 3, L, L)
+                    line['also']['no_compile_path'] = dict(
+                        kernel='k_tab + k_tab_fin (table-driven, state per lane)', states=n, kernel_ms=ms0,
+                        jacobians_per_s=n / ms0 * 1e3, frac=n * bj / ms0 / 1e6 / HBM_PEAK_GBPS,
+                        finite=bool(torch.isfinite(jac[:, ::997]).all()))
+                    ev0.close()
+                    step()          # leave the headline kernel's output in `jac`
+                except Exception as ex:
+                    line['also']['no_compile_path'] = {'error': repr(ex)}
                 # configs[1] "spec_rates + Jacobian": the rate pass (pyjacob.cu k_dydt) on the same batch,
                 # with every intermediate array written (conc, fwd, rev, pres_mod, spec_rates, dy) and
                 # with dy only

@@ -31,13 +31,8 @@ def _truth(name, tables, pres, y_aos, key):
 def _check_vs_truth(label, name, jac, ref, truth, nsp, table_driven=False):
     rep = truth_report(jac, ref, truth, nsp, label=label)
     assert rep['test_vs_ref'] < MX_BIG[name], rep
-    if table_driven:
-        # k_eval sums a Jacobian entry in the order of its scatter schedule -- an order of its own, with the same
-        # conditioning on the entries that are 1e-13 of their row scale as pyJac's order has (measured 1.3e-6
-        # GRI-shaped): it is held to the bound the reference itself meets against the truth and to the scaled
-        # entry-wise metric (jac_scaled_err); only the state-per-lane kernels are held to RTOL on every entry
-        assert rep['test_vs_truth'] < MX_BIG[name], (rep['test_vs_truth'], rep['ref_vs_truth'])
-        return rep
+    # (table_driven: k_eval / k_tab; since the dense-in-j scalar rp is formed without the cancellation of q - a,
+    # they meet the same entry-wise bound as the compiled kernels: measured <= 1.6e-9)
     assert rep['test_vs_truth'] < RTOL and rep['test_over_1e6'] == 0, rep      # north star: entry-wise rtol 1e-6
     if rep['n_bad']:
         assert rep['bad_explained'], rep      # |kernel - truth| <= 1e-3 |kernel - reference| on each such entry

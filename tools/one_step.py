@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Exactly <steps> Jacobian evaluations of <n> synthetic states (for rocprofv3 PMC passes)."""
+"""Exactly <steps> evaluations of <n> synthetic states (for rocprofv3 passes):
+one_step.py <mech> <n> <steps> [lane|rblk|table] [jac|rates|dydt]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -7,13 +8,26 @@ import pyjac_amd
 from pyjac_amd import synth
 mech, n, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 kind = sys.argv[4] if len(sys.argv) > 4 else None
+what = sys.argv[5] if len(sys.argv) > 5 else 'jac'
 ev = pyjac_amd.Evaluator(mech, specialize='off')
 if kind != 'table':
     assert ev.specialize(build=False, kind=kind), 'no prebuilt specialisation'
 pres, y = (synth.dist_a if 'h2o2_n2' in mech else synth.dist_b)(n, ev.nsp)
 d_p = torch.from_numpy(pres).cuda(); d_y = torch.from_numpy(y).cuda()
-out = torch.empty((ev.nsp**2, n), dtype=torch.float64, device='cuda')
-for _ in range(steps):
-    ev.jacobian(d_p, d_y, out=out)
+if what == 'jac':
+    out = torch.empty((ev.nsp**2, n), dtype=torch.float64, device='cuda')
+    for _ in range(steps):
+        ev.jacobian(d_p, d_y, out=out)
+else:
+    import ctypes
+    from pyjac_amd import _lib
+    rows = dict(conc=ev.nsp, fwd=ev.n_fwd, rev=max(ev.n_rev, 1), pres_mod=max(ev.n_pres_mod, 1), spec_rates=ev.nsp, dy=ev.nsp)
+    bufs = {k: torch.empty((r, n), dtype=torch.float64, device='cuda') for k, r in rows.items()}
+    p = (lambda k: bufs[k].data_ptr()) if what == 'rates' else (lambda k: bufs[k].data_ptr() if k == 'dy' else None)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(steps):
+        _lib.check(_lib.lib().pj_eval_rates_dev(ev._h, n, d_p.data_ptr(), d_y.data_ptr(), 0, p('conc'), p('fwd'), p('rev'),
+                                                p('pres_mod'), p('spec_rates'), p('dy'), st))
+    out = bufs['dy']
 torch.cuda.synchronize()
 print(ev.spec_kernel or 'k_eval', n, steps, bool(torch.isfinite(out[:, ::997]).all()))
