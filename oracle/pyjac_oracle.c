@@ -59,7 +59,7 @@ typedef struct pjo_mech {
 
 pjo_mech *pjo_create(const int32_t *I, long nI, const double *D, long nD)
 {
-    if (nI < HDR || I[0] != MAGIC || I[1] != 1 || I[12] != nI || I[13] != nD)
+    if (nI < HDR || I[0] != MAGIC || I[1] != 2 || I[12] != nI || I[13] != nD)
         return NULL;
     pjo_mech *m = (pjo_mech *)calloc(1, sizeof(pjo_mech));
     m->I = (int32_t *)malloc(sizeof(int32_t) * nI);

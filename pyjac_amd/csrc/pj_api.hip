@@ -287,7 +287,7 @@ struct pj_mech {
     // table-driven state-per-lane Jacobian kernel (pj_tab.h): program built at load time, scratch per handle
     TabProg tab;
     DevBuf<int32_t> tab_I;
-    DevBuf<double> tab_D, tab_E;
+    DevBuf<double> tab_D;
     double* tab_scr = nullptr;
     long tab_scr_ld = 0;
     int generic = 1;           // Jacobians without an attached library: 1 k_tab for SoA / k_eval for AoS, 0 k_eval, 2 k_tab
@@ -334,10 +334,7 @@ int ensure_device(pj_mech* m)
     HIPCHK(m->sp_ptr.upload(P.sp_ptr)); HIPCHK(m->sp_rxn.upload(P.sp_rxn)); HIPCHK(m->sp_nu.upload(P.sp_nu));
     HIPCHK(m->gen_sp.upload(P.gen_sp)); HIPCHK(m->gen_nu.upload(P.gen_nu));
     if (m->tab.ok) {
-        // (the visit stream is read a little past its end by the look-ahead of the last visit: padded)
-        m->tab.I.resize(m->tab.I.size() + 64, 0);
-        m->tab.D.resize(m->tab.D.size() + 64, 0.0);
-        HIPCHK(m->tab_I.upload(m->tab.I)); HIPCHK(m->tab_D.upload(m->tab.D)); HIPCHK(m->tab_E.upload(m->tab.E));
+        HIPCHK(m->tab_I.upload(m->tab.I)); HIPCHK(m->tab_D.upload(m->tab.D));
     }
     DevMech& M = m->M;
     M.gen_sp = m->gen_sp.p; M.gen_nu = m->gen_nu.p;
@@ -432,8 +429,7 @@ int launch_tab(pj_mech* m, const Batch& B, hipStream_t st)
     }
     TabDev X;
     X.L = T.L; X.G = T.G; X.B = T.B; X.ZERO = T.ZERO; X.TRASH = T.TRASH;
-    X.I = m->tab_I.p; X.D = m->tab_D.p; X.E = m->tab_E.p;
-    X.o_grp_ptr = T.o_grp_ptr; X.o_grp_blk = T.o_grp_blk; X.o_blk = T.o_blk; X.o_row = T.o_row; X.o_ent = T.o_ent; X.o_vi = T.o_vi;
+    X.I = m->tab_I.p; X.D = m->tab_D.p;
     X.scr = m->tab_scr; X.scr_ld = m->tab_scr_ld;
     static const int tab_dbg = getenv("PJ_TAB_DBG") ? atoi(getenv("PJ_TAB_DBG")) : 0;
     X.dbg = tab_dbg;
@@ -550,7 +546,7 @@ int pj_mech_create(const int32_t* I, long nI, const double* D, long nD, pj_mech*
     }
     try {
         // the run-time program of k_tab (a mechanism it cannot hold falls back to k_eval: tab.ok stays false)
-        (void)build_tab_program(m->P, 156 * 1024, m->tab);
+        (void)build_tab_program(m->P, 156 * 1024, m->tab, getenv("PJ_TAB_L") ? atoi(getenv("PJ_TAB_L")) : 0);
     } catch (const std::exception&) {
         m->tab.ok = false;
     }
@@ -598,7 +594,7 @@ void pj_mech_destroy(pj_mech* m)
         m->net_nu.release(); m->sp_nu.release(); m->sched.release(); m->ri.release(); m->eff_sp.release();
         m->fin_tgt.release(); m->fin_part.release(); m->fin_cnt.release();
         m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release(); m->gen_sp.release(); m->gen_nu.release();
-        m->tab_I.release(); m->tab_D.release(); m->tab_E.release();
+        m->tab_I.release(); m->tab_D.release();
         if (m->tab_scr) (void)hipFree(m->tab_scr);
         if (m->d_bad) (void)hipFree(m->d_bad);
         m->ws.release(); m->ws1.release();

@@ -45,6 +45,7 @@
 #endif
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -1406,6 +1407,10 @@ double* g_rate_scr = nullptr;           // omega_k between the rate kernels of a
 long g_rate_scr_ld = 0;
 double* g_rate_dummy = nullptr;         // one row that takes the per-reaction outputs the caller does not want
 long g_rate_dummy_ld = 0;
+// The hand-over arrays, internal streams and events are per library, i.e. per process: host threads enqueue one
+// batch at a time (two Evaluators of one mechanism, or two threads, serialise here instead of racing; on the
+// device a batch on another stream is ordered behind the previous one by enter_batch's event)
+std::mutex g_batch_mutex;
 constexpr int MAXSTREAMS = 8;
 double* g_scr[MAXSTREAMS] = {};
 long g_scr_ld[MAXSTREAMS] = {};
@@ -1481,6 +1486,7 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
     if (n <= 0) return 0;
     const bool jv = w != nullptr;
     if (jv && !g_rows_jv[0]) return -5;
+    std::lock_guard<std::mutex> lock(g_batch_mutex);
     if (const int rc = enter_batch(stream)) return rc;
     int nstreams = PJQ_STREAMS;
     long chunk_env = 0;
@@ -1587,6 +1593,7 @@ __global__ void __launch_bounds__(256) k_soa2aos(const double* __restrict__ src,
 
 double* g_aos_tmp = nullptr;
 long g_aos_tmp_states = 0;
+std::mutex g_aos_mutex;                 // the staging block of the AoS path (taken before g_batch_mutex)
 
 int pj_spec_fast_aos(void) { return 1; }   // AoS Jacobians: SoA chunks + transpose, not strided lane stores
 
@@ -1596,6 +1603,7 @@ int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, lon
 #ifndef PJR_HOST_EMU
     constexpr long NE = (long)NSP * NSP;
     if (n >= PJQ_BLOCK && j_si == 1 && j_ss == NE && g_rows[0] && !getenv("PJ_RBLK_AOS_DIRECT")) {
+        std::lock_guard<std::mutex> lock(g_aos_mutex);
         // chunks that fill the device once (one workgroup per CU): 256 workgroups
         long chunk = 256L * PJQ_BLOCK;
         if (chunk > n) chunk = n;
@@ -1641,6 +1649,7 @@ int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y
     const bool full = fwd || rev || pres_mod;
     pjq_launch_fn* parts = full ? g_rate_full : g_rate_lean;
     if (!parts[0]) return -5;
+    std::lock_guard<std::mutex> lock(g_batch_mutex);
     if (const int rc = enter_batch(stream)) return rc;
     if (full && !(fwd && rev && pres_mod) && g_rate_dummy_ld < n) {
         if (g_rate_dummy) { (void)hipDeviceSynchronize(); (void)hipFree(g_rate_dummy); g_rate_dummy = nullptr; g_rate_dummy_ld = 0; }

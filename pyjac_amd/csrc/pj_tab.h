@@ -27,15 +27,13 @@ typedef const PJT_CONST double* tab_cd;
 typedef const PJT_CONST int32_t* tab_ci;
 struct TabTabs {
     tab_ci ri, eff_sp, gen_sp, I;
-    tab_cd rd, sp, kcg, plog, sri, cheb, eff_am1, gen_nu, D, E;
+    tab_cd rd, sp, kcg, plog, sri, cheb, eff_am1, gen_nu;
 };
 
 struct TabDev {
     int L, G, B, ZERO, TRASH;
-    const int32_t* I;               // program words (TabProg::I)
-    const double* D;                // program doubles (TabProg::D)
-    const double* E;                // per output entry: column constant (TabProg::E)
-    int o_grp_ptr, o_grp_blk, o_blk, o_row, o_ent, o_vi;
+    const int32_t* I;               // per lane group: first word, records, words of the first two records (TabProg::I)
+    const double* D;                // record streams (TabProg::D)
     double* scr;                    // [nsp + 1][n]: omega_k of every species, then the last species' d/dT sum
     long scr_ld;
     int dbg;                        // timing experiments (PJ_TAB_DBG): 1 no reaction arithmetic, 2 no accumulation, 4 no output
@@ -45,8 +43,9 @@ PJ_DEV TabTabs tab_tabs(const DevMech& M, const TabDev& P)
 {
     TabTabs X;
     X.ri = (tab_ci)M.ri; X.eff_sp = (tab_ci)M.eff_sp; X.gen_sp = (tab_ci)M.gen_sp; X.I = (tab_ci)P.I;
+    (void)P;
     X.rd = (tab_cd)M.rd; X.sp = (tab_cd)M.sp; X.kcg = (tab_cd)M.kcg; X.plog = (tab_cd)M.plog; X.sri = (tab_cd)M.sri;
-    X.cheb = (tab_cd)M.cheb; X.eff_am1 = (tab_cd)M.eff_am1; X.gen_nu = (tab_cd)M.gen_nu; X.D = (tab_cd)P.D; X.E = (tab_cd)P.E;
+    X.cheb = (tab_cd)M.cheb; X.eff_am1 = (tab_cd)M.eff_am1; X.gen_nu = (tab_cd)M.gen_nu;
     return X;
 }
 
@@ -121,19 +120,22 @@ PJ_DEV void tab_stage(const DevMech& M, const TabDev& P, const Batch& B, double*
 // ---- one reaction, every rate form, for one state (reaction index d is wavefront-uniform) ----
 #define TAB_C(idx) (((idx) == nsp) ? 1.0 : CL[(idx) * L + lane])
 // ri / rd: the reaction's records, effs / effa: its enhanced colliders and efficiencies - 1, kc: its K_c rows --
-// all inline in the visit stream (pj_tabprog.h)
+// all inline in the visit record, which sits in the wavefront's LDS ring (pj_tabprog.h): every lane reads the same
+// address (a broadcast), the values arrive in vector registers and only what steers control flow is moved to
+// scalar registers
 PJ_DEV void tab_reaction(const DevMech& M, const TabTabs& X, const TabLane& Ln, const double* CL, const int L, const int lane,
-                         tab_ci ri, tab_cd rd, tab_cd kc, tab_ci effs, tab_cd effa, TabRx& R)
+                         const int32_t* ri, const double* rd, const double* kc, const int32_t* effs, const double* effa,
+                         TabRx& R)
 {
     const int nsp = M.nsp, last = nsp - 1;
-    const int fl = ri[RI_FLAGS];
+    const int fl = PJ_UNIFORM(ri[RI_FLAGS]);
     const double T = Ln.T, logT = Ln.logT, invT = Ln.invT;
     // ---- forward rate constant and T dln k_f/dT ----
     double lnk, dlnk, kf_jac_ratio = 1.0;
     if (fl & F_PLOG) {
         // rate_subs.py:598-632 (breakpoints compared at their printed value); create_jacobian.py:1687-1850
-        tab_cd Pl = X.plog + (long)ri[RI_PLOG_PTR] * PLW;
-        const int np = ri[RI_PLOG_CNT];
+        tab_cd Pl = X.plog + (long)PJ_UNIFORM(ri[RI_PLOG_PTR]) * PLW;
+        const int np = PJ_UNIFORM(ri[RI_PLOG_CNT]);
         lnk = Pl[2] + Pl[3] * logT - Pl[4] * invT;
         dlnk = Pl[3] + Pl[4] * invT;
         for (int q = 1; q < np; ++q) {
@@ -154,8 +156,8 @@ PJ_DEV void tab_reaction(const DevMech& M, const TabTabs& X, const TabLane& Ln, 
         }
     } else if (fl & F_CHEB) {
         // rate_subs.py:149-251 ('{:.8e}' constants); create_jacobian.py:1532-1684 ('{:.16e}')
-        tab_cd C = X.cheb + ri[RI_PLOG_PTR];
-        const int cn = ri[RI_PLOG_CNT] >> 8, cm = ri[RI_PLOG_CNT] & 255;
+        tab_cd C = X.cheb + PJ_UNIFORM(ri[RI_PLOG_PTR]);
+        const int cn = PJ_UNIFORM(ri[RI_PLOG_CNT]) >> 8, cm = PJ_UNIFORM(ri[RI_PLOG_CNT]) & 255;
         const double lg10p = Ln.logp * INV_LN10;
         auto cheb_sum = [&](tab_cd c, const double Tred, const double Pred) {
             double kl = 0.0, u0 = 1.0, u1 = Tred;
@@ -203,18 +205,15 @@ PJ_DEV void tab_reaction(const DevMech& M, const TabTabs& X, const TabLane& Ln, 
     double kr = 0.0, TdlnKc = 0.0;
     if (fl & F_REV) {
         double lnKc = rd[RD_LNPREF];
-        tab_cd g = kc;
+        const double* g = kc;
         const double T2 = T * T, T3 = T2 * T, T4 = T2 * T2;
-        for (int c = 0; c < ri[RI_KC_CNT]; ++c, g += KCW) {
-            tab_cd a = g + 1;
-            tab_cd b = g + 8;
-            const double la = a[0] + a[1] * logT + a[2] * T + a[3] * T2 + a[4] * T3 + a[5] * T4 - a[6] * invT;
-            const double lb = b[0] + b[1] * logT + b[2] * T + b[3] * T2 + b[4] * T3 + b[5] * T4 - b[6] * invT;
-            const double da = a[1] + a[2] * T + 2.0 * a[3] * T2 + 3.0 * a[4] * T3 + 4.0 * a[5] * T4 + a[6] * invT;
-            const double db = b[1] + b[2] * T + 2.0 * b[3] * T2 + 3.0 * b[4] * T3 + 4.0 * b[5] * T4 + b[6] * invT;
-            const bool lo = T <= g[0];
-            lnKc += lo ? la : lb;
-            TdlnKc += lo ? da : db;
+        const int nkc = PJ_UNIFORM(ri[RI_KC_CNT]);
+        for (int c = 0; c < nkc; ++c, g += KCW) {
+            // the range is a per-state property: each lane reads its own row of the pair (two addresses per
+            // wavefront at most: no bank conflicts)
+            const double* a = (T <= g[0]) ? g + 1 : g + 8;
+            lnKc += a[0] + a[1] * logT + a[2] * T + a[3] * T2 + a[4] * T3 + a[5] * T4 - a[6] * invT;
+            TdlnKc += a[1] + a[2] * T + 2.0 * a[3] * T2 + 3.0 * a[4] * T3 + 4.0 * a[5] * T4 + a[6] * invT;
         }
         kr = kf * tab_exp(-lnKc);
     }
@@ -223,7 +222,7 @@ PJ_DEV void tab_reaction(const DevMech& M, const TabTabs& X, const TabLane& Ln, 
     const double cr0 = TAB_C(r0), cr1 = TAB_C(r1), cr2 = TAB_C(r2);
     const double cp0 = TAB_C(p0), cp1 = TAB_C(p1), cp2 = TAB_C(p2);
     double prodr = cr0 * cr1 * cr2, prodp = cp0 * cp1 * cp2;
-    const int gp0 = ri[RI_GEN_PTR], gnr = ri[RI_GEN_NR], gnp = ri[RI_GEN_NP];
+    const int gp0 = PJ_UNIFORM(ri[RI_GEN_PTR]), gnr = PJ_UNIFORM(ri[RI_GEN_NR]), gnp = PJ_UNIFORM(ri[RI_GEN_NP]);
     if (fl & F_GEN) {
         for (int f = 0; f < gnr; ++f) prodr *= pj_cpow(TAB_C(X.gen_sp[gp0 + f]), X.gen_nu[gp0 + f]);
         for (int f = 0; f < gnp; ++f) prodp *= pj_cpow(TAB_C(X.gen_sp[gp0 + gnr + f]), X.gen_nu[gp0 + gnr + f]);
@@ -233,7 +232,7 @@ PJ_DEV void tab_reaction(const DevMech& M, const TabTabs& X, const TabLane& Ln, 
     double c = 1.0, lead = 0.0, a_extra = 0.0, bM = 0.0, bcol = 0.0;
     if (fl & (F_THD | F_PDEP)) {
         double Mc = Ln.mconc;
-        const int ne = ri[RI_EFF_CNT];
+        const int ne = PJ_UNIFORM(ri[RI_EFF_CNT]);
         for (int e = 0; e < ne; ++e) Mc += effa[e] * CL[effs[e] * L + lane];
         if (fl & F_THD) {
             c = Mc;
@@ -272,7 +271,7 @@ PJ_DEV void tab_reaction(const DevMech& M, const TabTabs& X, const TabLane& Ln, 
                         Xtroe * (rd[RD_B0] + e0T - 1.0) * invT;
             }
             if (fl & F_SRI) {
-                tab_cd Q = X.sri + (long)ri[RI_PLOG_PTR] * SRW;
+                tab_cd Q = X.sri + (long)PJ_UNIFORM(ri[RI_PLOG_PTR]) * SRW;
                 const double lgPr = log(fmax(Pr, 1.0e-300)) * INV_LN10;
                 const double Xs = 1.0 / (1.0 + lgPr * lgPr);
                 const double S6 = Q[SR_A6] * tab_exp(-Q[SR_B6] * invT) + tab_exp(-T / Q[SR_C6]);
@@ -334,14 +333,13 @@ PJ_DEV void tab_reaction(const DevMech& M, const TabTabs& X, const TabLane& Ln, 
     R.rq = R.rp + gN;
 }
 
-// value of general-stoichiometry factor f (0-based: reactant factors, then product factors) of reaction d:
+// value of general-stoichiometry factor f (0-based: reactant factors, then product factors) of the reaction:
 // c k nu C^(nu-1) prod_others, the power of C itself only "if (nu - 1) > 0" (create_jacobian.py:400-448)
-PJ_DEV double tab_gen_value(const DevMech& M, const TabTabs& X, const double* CL, const int L, const int lane, const int d, const int f,
-                            const TabRx& R)
+PJ_DEV double tab_gen_value(const DevMech& M, const TabTabs& X, const double* CL, const int L, const int lane, const int32_t* ri,
+                            const int f, const TabRx& R)
 {
     const int nsp = M.nsp;
-    tab_ci ri = X.ri + (long)d * RIW;
-    const int gp0 = ri[RI_GEN_PTR], gnr = ri[RI_GEN_NR], gnp = ri[RI_GEN_NP];
+    const int gp0 = PJ_UNIFORM(ri[RI_GEN_PTR]), gnr = PJ_UNIFORM(ri[RI_GEN_NR]), gnp = PJ_UNIFORM(ri[RI_GEN_NP]);
     const bool prod = f >= gnr;
     const int f0 = prod ? gp0 + gnr : gp0, nf = prod ? gnp : gnr, fl_ = prod ? f - gnr : f;
     const double nuf = X.gen_nu[f0 + fl_];
@@ -352,56 +350,92 @@ PJ_DEV double tab_gen_value(const DevMech& M, const TabTabs& X, const double* CL
 }
 #undef TAB_C
 
-// ---- the row blocks of this thread's lane group ----
+// ---- the record stream of this thread's lane group (pj_tabprog.h), through the wavefront's LDS ring ----
+// A dependent scalar load costs ~0.9 us here (the stream is read once per workgroup and misses the scalar cache; its
+// counter, lgkmcnt, is the one the LDS reads wait on), so the program does not come through the scalar unit at all:
+// the 64 lanes of a wavefront copy record r + 2 into the ring slot that record r leaves (512-byte vector loads
+// issued when r starts, written to LDS when r is done), and every field is an LDS read at a uniform address.
+#ifndef PJT_FETCH_ALL
+#define PJT_FETCH_ALL 0         // 1 (host emulation, one thread at a time): a thread copies whole records itself
+#endif
 PJ_DEV void tab_blocks(const DevMech& M, const TabDev& P, const Batch& B, double* lds, int tid, const TabLane& Ln)
 {
     const TabTabs X = tab_tabs(M, P);
     const int L = P.L, nsp = M.nsp, last = nsp - 1;
-    const int g = PJ_UNIFORM(tid / L), lane = tid % L;
+    const int g = PJ_UNIFORM(tid / L), lane = tid % L, wave = PJ_UNIFORM(tid / 64), wl = tid % 64;
     const double* CL = lds;
     double* ACC = lds + (long)nsp * L + (long)g * P.B * L + lane;       // this lane's column of the group's slots
+    double* RING = lds + (long)nsp * L + 256L * P.B + (long)(PJT_FETCH_ALL ? tid : wave) * TAB_RING_WORDS;
 #define A_(slot) ACC[(long)(slot) * L]
-    const tab_ci I = X.I;
     const long gs = Ln.gs;
     A_(P.ZERO) = 0.0;
     A_(P.TRASH) = 0.0;
-    const int b_lo = I[P.o_grp_ptr + g], b_hi = I[P.o_grp_ptr + g + 1];
-    for (int bi = b_lo; bi < b_hi; ++bi) {
-        const int b = I[P.o_grp_blk + bi];
-        tab_ci bk = I + P.o_blk + b * TAB_BLK;
-        const int nvis = bk[1], row0 = bk[2], nrow = bk[3], nslot = bk[5];
-        for (int s = 0; s < nslot; ++s) A_(s) = 0.0;
-        tab_ci vi = I + P.o_vi + bk[0];
-        tab_cd vd = X.D + bk[4];
-        for (int v = 0; v < nvis; ++v) {
-            const int d = vi[0], nhit = vi[1];
-            // the next visit's records: one word per 64-byte line is requested now, so that its scalar loads hit the
-            // scalar cache when it starts (the visit stream is read once per workgroup: every line is a miss otherwise)
-            tab_ci nvi = vi + vi[2];
-            tab_cd nvd = vd + vi[3];
-            const int pf0 = nvi[0], pf1 = nvi[16], pf2 = nvi[32];
-            const double pd0 = nvd[0], pd1 = nvd[8], pd2 = nvd[16], pd3 = nvd[24], pd4 = nvd[32];
-            tab_ci ri = vi + 4;
-            (void)d;
-            const int fl = ri[RI_FLAGS], necnt = ri[RI_EFF_CNT], kcw = (fl & F_REV) ? ri[RI_KC_CNT] * KCW : 0;
-            tab_ci effs = ri + RIW;
-            tab_cd rd = vd, kc = vd + RDW, effa = vd + RDW + kcw;
+    const int nrec = X.I[4 * g + 1];
+    const double* S = P.D + X.I[4 * g];
+    // Ring of three slots: record r is in slot r % 3, record r + 1 in the next one; record r + 2 is in flight in
+    // registers (requested when record r - 1 started, written to its slot when record r - 1 ... r ends), record
+    // r + 3 is requested when record r starts: two requests are outstanding, i.e. a load has two records' time.
+    long pos2 = 0;                  // word of record r + 2
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;        // record r + 2 (requested one record ago)
+    int pn = 0;                     // its words
+    {
+        const int nw0 = X.I[4 * g + 2], nw1 = X.I[4 * g + 3];
+#if PJT_FETCH_ALL
+        for (int w = 0; w < nw0; ++w) RING[w] = S[w];
+        for (int w = 0; w < nw1; ++w) RING[TAB_RSZ + w] = S[nw0 + w];
+#else
+        for (int w = wl; w < nw0; w += 64) RING[w] = S[w];
+        for (int w = wl; w < nw1; w += 64) RING[TAB_RSZ + w] = S[nw0 + w];
+#endif
+        pos2 = nw0 + nw1;
+        // record 2: its size is in record 0's header (global copy)
+        const int32_t* h0 = (const int32_t*)S;
+        pn = nrec > 2 ? PJ_UNIFORM(h0[3]) : 0;
+#if !PJT_FETCH_ALL
+        if (pn > 0) p0 = S[pos2 + wl];
+        if (pn > 64) p1 = S[pos2 + 64 + wl];
+        if (pn > 128) p2 = S[pos2 + 128 + wl];
+#endif
+    }
+    for (int r = 0; r < nrec; ++r) {
+        double* rec = RING + (r % 3) * TAB_RSZ;
+        const int32_t* hi = (const int32_t*)rec;
+        const int type = PJ_UNIFORM(hi[0]) & 255, flags = PJ_UNIFORM(hi[0]) >> 8, a1 = PJ_UNIFORM(hi[1]);
+        const int nw2 = PJ_UNIFORM(hi[3]), niw = PJ_UNIFORM(hi[4]), nw3 = PJ_UNIFORM(hi[5]);
+        (void)nw2;
+        // request record r + 3 (it follows record r + 2, whose position and size are known)
+        const long pos3 = pos2 + pn;
+        const double* nx = S + pos3;
+        double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+#if !PJT_FETCH_ALL
+        if (nw3 > 0) f0 = nx[wl];
+        if (nw3 > 64) f1 = nx[64 + wl];
+        if (nw3 > 128) f2 = nx[128 + wl];
+#endif
+        const int32_t* vi = hi + 6;
+        const double* vd = rec + 3 + niw;
+        if (type == TAB_T_VISIT) {
+            const int nhit = a1;
+            const int32_t* ri = vi;
+            const int fl = PJ_UNIFORM(ri[RI_FLAGS]), necnt = PJ_UNIFORM(ri[RI_EFF_CNT]);
+            const int kcw = (fl & F_REV) ? PJ_UNIFORM(ri[RI_KC_CNT]) * KCW : 0;
             TabRx R;
             if (P.dbg & 1) { R.q = R.theta = R.rp = R.rq = R.bM = R.bcol = R.ckf = R.ckr = Ln.T; for (int t = 0; t < TAB_NSLOT; ++t) R.g[t] = Ln.p; }
-            else tab_reaction(M, X, Ln, CL, L, lane, ri, rd, kc, effs, effa, R);
-            vi += 4 + RIW + necnt;
+            else tab_reaction(M, X, Ln, CL, L, lane, ri, vd, vd + RDW, ri + RIW, vd + RDW + kcw, R);
+            vi += RIW + necnt;
             vd += RDW + kcw + necnt;
             for (int h = 0; h < nhit; ++h) {
-                if (P.dbg & 2) { A_(P.TRASH) += R.q + R.rp + R.rq + R.theta + R.g[0] + R.g[1] + R.g[2] + R.g[3] + R.g[4] + R.g[5] + R.g[6]; const int ne_ = vi[1 + TAB_NSLOT], ng_ = vi[2 + TAB_NSLOT]; vi += TAB_HIT_I + ne_ + 2 * ng_; vd += TAB_HIT_D + ne_ + ng_; continue; }
-                const int base = vi[0], neff = vi[1 + TAB_NSLOT], ngen = vi[2 + TAB_NSLOT], hfl = vi[3 + TAB_NSLOT];
+                const int neff = PJ_UNIFORM(vi[1 + TAB_NSLOT]), ngen = PJ_UNIFORM(vi[2 + TAB_NSLOT]), hfl = PJ_UNIFORM(vi[3 + TAB_NSLOT]);
+                if (P.dbg & 2) { A_(P.TRASH) += R.q + R.rp + R.rq + R.theta + R.g[0] + R.g[1] + R.g[2] + R.g[3] + R.g[4] + R.g[5] + R.g[6]; vi += TAB_HIT_I + neff + 2 * ngen; vd += TAB_HIT_D + neff + ngen; continue; }
+                const int base = vi[0];
                 const double nu = vd[0];
                 {   // dense sums and the reactant slots: read, update, write back (the slots of one batch are
                     // distinct, or TRASH)
-                    double a0 = A_(base), a1 = A_(base + 1), a2 = A_(base + 2), a3 = A_(base + 3);
+                    double a0 = A_(base), a1_ = A_(base + 1), a2 = A_(base + 2), a3 = A_(base + 3);
                     double s0 = A_(vi[1]), s1 = A_(vi[2]), s2 = A_(vi[3]);
-                    a0 += nu * R.q; a1 += nu * R.rp; a2 += nu * R.rq; a3 += nu * R.theta;
+                    a0 += nu * R.q; a1_ += nu * R.rp; a2 += nu * R.rq; a3 += nu * R.theta;
                     s0 += vd[1] * R.g[0]; s1 += vd[2] * R.g[1]; s2 += vd[3] * R.g[2];
-                    A_(base) = a0; A_(base + 1) = a1; A_(base + 2) = a2; A_(base + 3) = a3;
+                    A_(base) = a0; A_(base + 1) = a1_; A_(base + 2) = a2; A_(base + 3) = a3;
                     A_(vi[1]) = s0; A_(vi[2]) = s1; A_(vi[3]) = s2;
                     // reference quirk (create_jacobian.py:2786-2818): J_nplusone is assigned, not accumulated
                     if (hfl & 1) A_(base + 4) = nu * R.theta;
@@ -416,44 +450,33 @@ PJ_DEV void tab_blocks(const DevMech& M, const TabDev& P, const Batch& B, double
                 for (int e = 0; e < neff; ++e) A_(vi[e]) += vd[e] * R.bM;
                 vi += neff; vd += neff;
                 for (int e = 0; e < ngen; ++e)
-                    A_(vi[2 * e]) += vd[e] * tab_gen_value(M, X, CL, L, lane, d, vi[2 * e + 1], R);
+                    A_(vi[2 * e]) += vd[e] * tab_gen_value(M, X, CL, L, lane, ri, PJ_UNIFORM(vi[2 * e + 1]), R);
                 vi += 2 * ngen; vd += ngen;
             }
-#ifdef __HIP_DEVICE_COMPILE__
-            asm volatile("" :: "s"(pf0), "s"(pf1), "s"(pf2), "s"(pd0), "s"(pd1), "s"(pd2), "s"(pd3), "s"(pd4));
-#else
-            (void)pf0; (void)pf1; (void)pf2; (void)pd0; (void)pd1; (void)pd2; (void)pd3; (void)pd4;
-#endif
-        }
-        // ---- output phase: rows of the block ----
-        for (int r = 0; r < ((P.dbg & 4) ? 0 : nrow); ++r) {
-            tab_ci rw = I + P.o_row + (row0 + r) * TAB_ROW;
-            const int k = rw[0], base = rw[1], first = rw[2] & 1, e0 = rw[3], ne = rw[4];
+        } else if (type == TAB_T_BEGIN) {
+            for (int s_ = 0; s_ < a1; ++s_) A_(s_) = 0.0;
+        } else if (!(P.dbg & 4)) {
+            // ---- output record: a row of the block (or a column part of it) ----
+            const int k = a1, first = flags & 1, base = PJ_UNIFORM(vi[0]), ne = PJ_UNIFORM(vi[1]);
+            const int32_t* en = vi + 2;
+            const double* ed = vd;
             const double om = A_(base), Pk = A_(base + 1), Qk = A_(base + 2), JT = A_(base + 3), JTQ = A_(base + 4);
             const double Wk = X.sp[k * SPW + 1];
-            tab_ci en = I + P.o_ent + e0;
-            tab_cd ed = X.E + e0;
+            const long cs = (long)nsp * B.j_si;
             if (k < last) {
                 const double WP = Wk * Pk, WQN = (Wk * X.sp[last * SPW]) * Qk;
                 double* Jr = B.jac + gs * B.j_ss + (long)(k + 1) * B.j_si;
-                const long cs = (long)nsp * B.j_si;
                 if (first) {
                     Jr[0] = Wk * JT;                                   // d/dT column (create_jacobian.py:2786-2818)
                     P.scr[(long)k * P.scr_ld + gs] = om;
                 }
-                // J(k, j) = (1 / W_j) (W_k (P_k + S_kj)) - W_k Q_k / W_N, TAB_EB entries at a time: the program words
-                // and column constants of the next batch are requested while this one is computed and stored
-                int w[TAB_EB];
-                double ic[TAB_EB];
-                for (int u = 0; u < TAB_EB; ++u) { w[u] = en[u]; ic[u] = ed[u]; }
+                // J(k, j) = (1 / W_j) (W_k (P_k + S_kj)) - W_k Q_k / W_N, TAB_EB entries at a time
                 for (int e = 0; e < ne; e += TAB_EB) {
-                    int wn[TAB_EB];
-                    double icn[TAB_EB];
-                    for (int u = 0; u < TAB_EB; ++u) { wn[u] = en[e + TAB_EB + u]; icn[u] = ed[e + TAB_EB + u]; }
+                    int w[TAB_EB];
                     double sv[TAB_EB];
+                    for (int u = 0; u < TAB_EB; ++u) w[u] = en[e + u];
                     for (int u = 0; u < TAB_EB; ++u) sv[u] = A_(w[u] >> 16);
-                    for (int u = 0; u < TAB_EB; ++u) Jr[cs * ((w[u] & 0xFFFF) + 1)] = ic[u] * (WP + Wk * sv[u]) - WQN;
-                    for (int u = 0; u < TAB_EB; ++u) { w[u] = wn[u]; ic[u] = icn[u]; }
+                    for (int u = 0; u < TAB_EB; ++u) Jr[cs * ((w[u] & 0xFFFF) + 1)] = ed[e + u] * (WP + Wk * sv[u]) - WQN;
                 }
             } else {
                 // the last species has no row of its own: its terms open the energy row's column sums
@@ -465,7 +488,6 @@ PJ_DEV void tab_blocks(const DevMech& M, const TabDev& P, const Batch& B, double
                 const double hW = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
                                          T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
                 double* J0 = B.jac + gs * B.j_ss;
-                const long cs = (long)nsp * B.j_si;
                 if (first) {
                     P.scr[(long)k * P.scr_ld + gs] = om;
                     P.scr[(long)nsp * P.scr_ld + gs] = M.sum_last ? JT : JTQ;
@@ -473,6 +495,19 @@ PJ_DEV void tab_blocks(const DevMech& M, const TabDev& P, const Batch& B, double
                 for (int e = 0; e < ne; ++e) J0[cs * ((en[e] & 0xFFFF) + 1)] = hW * (Pk - ed[e] * Qk + A_(en[e] >> 16));
             }
         }
+        // record r + 2 (requested a record ago) lands in the slot after record r + 1's; the request made above
+        // stays in flight for another record
+        {
+            double* dst = RING + ((r + 2) % 3) * TAB_RSZ;
+#if PJT_FETCH_ALL
+            for (int w = 0; w < pn; ++w) dst[w] = S[pos2 + w];
+#else
+            if (pn > 0) dst[wl] = p0;
+            if (pn > 64) dst[64 + wl] = p1;
+            if (pn > 128) dst[128 + wl] = p2;
+#endif
+        }
+        p0 = f0; p1 = f1; p2 = f2; pn = nw3; pos2 = pos3;
     }
 #undef A_
 }

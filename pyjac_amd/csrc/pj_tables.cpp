@@ -34,7 +34,9 @@ int kind_rank(int fl)
 static bool validate_blob(const int32_t* I, long nI, const double* D, long nD, std::string& err)
 {
     auto bad = [&](const char* what) { err = std::string("malformed mechanism table blob: ") + what; return false; };
-    if (nI < HDR || I[0] != MAGIC || I[1] != 1 || I[12] != nI || I[13] != nD) return bad("header");
+    if (nI < HDR || I[0] != MAGIC) return bad("header");
+    if (I[1] != BLOB_VERSION) { err = "mechanism table blob: version " + std::to_string(I[1]) + ", this library reads version " + std::to_string(BLOB_VERSION) + " (write the table file again with this release)"; return false; }
+    if (I[12] != nI || I[13] != nD) return bad("header");
     const int nsp = I[2], nrxn = I[3];
     if (nsp < 1 || nsp > 4096 || nrxn < 0 || nrxn > 8191 || I[4] < 0 || I[4] > nrxn || I[5] < 0 || I[5] > nrxn)
         return bad("sizes");
@@ -98,6 +100,15 @@ static bool validate_blob(const int32_t* I, long nI, const double* D, long nD, s
         for (int i = 0; i < nrxn; ++i) if (pp[i + 1] < pp[i] || kp[i + 1] < kp[i]) return bad("PLOG / K_c pointer not monotone");
         if ((long)pp[nrxn] * 4 > dlen[DA_PLOG] || (long)pp[nrxn] > dlen[DA_PLOG4]) return bad("PLOG table too short");
         if ((long)kp[nrxn] * KCW > dlen[DA_KCG]) return bad("K_c group table too short");
+    }
+    {
+        // flag combinations the kernels do not expect (a record field is shared between PLOG rows, SRI rows and
+        // Chebyshev records: RI_PLOG_PTR / RI_PLOG_CNT)
+        const int32_t* fl = ia(IA_FLAGS);
+        for (int i = 0; i < nrxn; ++i) {
+            if ((fl[i] & F_CHEB) && (fl[i] & (F_PLOG | F_PDEP | F_THD))) return bad("Chebyshev reaction combined with another pressure dependence");
+            if ((fl[i] & F_SRI) && ((fl[i] & F_PLOG) || !(fl[i] & F_PDEP) || (fl[i] & F_TROE))) return bad("SRI parameters on a reaction that is not a plain falloff");
+        }
     }
     const int32_t *pd = ia(IA_PDEP_SP), *ri = ia(IA_REV_IDX), *pi = ia(IA_PRES_IDX);
     for (int i = 0; i < nrxn; ++i)

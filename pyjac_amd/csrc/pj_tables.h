@@ -15,6 +15,7 @@ namespace pj {
 // canonical blob constants (pyjac_amd/tables.py)
 constexpr int HDR = 96;
 constexpr int32_t MAGIC = 0x314D4A50;
+constexpr int32_t BLOB_VERSION = 2;   // 2: 16 integer / 22 real arrays (Chebyshev, per-emitter SRI rows)
 enum { F_REV = 1, F_THD = 2, F_PDEP = 4, F_LOW = 8, F_HIGH = 16, F_TROE = 32,
        F_SRI = 64, F_PLOG = 128, F_TROE4 = 256, F_SRI5 = 512, F_HAS_EFF = 1024,
        // derived on the host:

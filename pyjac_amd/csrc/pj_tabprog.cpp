@@ -2,6 +2,7 @@
 #include "pj_tabprog.h"
 
 #include <algorithm>
+#include <cstring>
 #include <numeric>
 
 namespace pj {
@@ -12,7 +13,7 @@ struct Part { int k; std::vector<int> cols; bool first; };           // a row or
 struct Block { std::vector<Part> parts; std::vector<int> rx; long cost = 0; };
 }  // namespace
 
-bool build_tab_program(const Programs& p, size_t lds_avail, TabProg& out)
+bool build_tab_program(const Programs& p, size_t lds_avail, TabProg& out, int force_L)
 {
     out = TabProg();
     const int nsp = p.nsp, nrxn = p.nrxn, last = nsp - 1, ONE = nsp;
@@ -20,16 +21,19 @@ bool build_tab_program(const Programs& p, size_t lds_avail, TabProg& out)
     if (nsp < 2) return fail("k_tab: at least two species");
     // ---- geometry: L states per workgroup, B accumulator slots per lane group ----
     int L = 0, B = 0;
+    const long ring = 4L * TAB_RING_WORDS * 8;       // one ring per wavefront
     for (int cand : {256, 128, 64}) {
-        const long room = (long)lds_avail - (long)nsp * cand * 8;
+        const long room = (long)lds_avail - (long)nsp * cand * 8 - ring;
         const int b = room > 0 ? (int)(room / (256L * 8)) : 0;
-        if (b >= 46 || cand == 64) { L = cand; B = b; break; }
+        // (measured, GRI-shaped: 64 states x 4 one-wavefront groups with 55 slots 52 ms, 128 x 2 with 41 slots 72 ms)
+        if (force_L ? cand == force_L : (b >= 56 || cand == 64)) { L = cand; B = b; break; }
     }
+    if (!L) return fail("k_tab: states per workgroup must be 256, 128 or 64");
     if (B > 96) B = 96;
     if (B < DENSE + 3 + 2) return fail("k_tab: the concentration columns of this mechanism leave no room for accumulators in LDS");
     const int cap = B - 2;                       // slots a block may use (ZERO and TRASH are the last two)
     out.L = L; out.G = 256 / L; out.B = B; out.ZERO = B - 2; out.TRASH = B - 1;
-    out.lds_bytes = (size_t)nsp * L * 8 + (size_t)256 * B * 8;
+    out.lds_bytes = (size_t)nsp * L * 8 + (size_t)256 * B * 8 + (size_t)ring;
 
     // ---- structural pattern, reactions per row ----
     auto nz = [&](int k, int j) { return p.smap[(size_t)k + (size_t)nsp * j] != 0xFFFF; };
@@ -107,128 +111,169 @@ bool build_tab_program(const Programs& p, size_t lds_avail, TabProg& out)
         for (auto& l : gb) std::sort(l.begin(), l.end());
     }
 
-    // ---- emit ----
-    std::vector<int32_t> grp_ptr{0}, grp_blk, blk, row, ent, vi;
-    std::vector<double>& vd = out.D;
+    // ---- emit: one record stream per lane group, in execution order ----
+    // (8-byte words; a record is header[3] + integer words + doubles, at most TAB_RSZ words: a wavefront moves it
+    // into its LDS ring with one to three 512-byte loads, two records ahead of use)
+    struct Rec { int type = 0, flags = 0, a1 = 0; std::vector<int32_t> iw; std::vector<double> dw; };
+    std::vector<double>& S = out.D;
+    auto words_of = [](const Rec& r) { return 3 + (int)((r.iw.size() + 1) / 2) + (int)r.dw.size(); };
+    auto put_rec = [&](std::vector<Rec>& list, Rec&& r) -> bool {
+        if (words_of(r) > TAB_RSZ) return false;
+        list.push_back(std::move(r));
+        return true;
+    };
+    std::vector<int32_t> grp;        // per group: first word, records, words of the first and of the second record
     for (int g = 0; g < out.G; ++g) {
-        for (int b : gb[g]) grp_blk.push_back(b);
-        grp_ptr.push_back((int32_t)grp_blk.size());
-    }
-    for (int b = 0; b < nblk; ++b) {
-        const Block& bl = blocks[b];
-        // slots: DENSE per part, then the parts' S columns
-        std::vector<int> base(bl.parts.size());
-        std::vector<std::vector<int>> slot_of(bl.parts.size(), std::vector<int>(nsp, -1));
-        int next = DENSE * (int)bl.parts.size();
-        for (size_t r = 0; r < bl.parts.size(); ++r) {
-            base[r] = DENSE * (int)r;
-            for (int j : bl.parts[r].cols) slot_of[r][j] = next++;
-        }
-        if (next > cap) return fail("k_tab: internal error, block exceeds the accumulator budget");
-        blk.push_back((int32_t)vi.size());
-        blk.push_back((int32_t)bl.rx.size());
-        blk.push_back((int32_t)(row.size() / TAB_ROW));
-        blk.push_back((int32_t)bl.parts.size());
-        blk.push_back((int32_t)vd.size());
-        blk.push_back((int32_t)next);
-        for (size_t r = 0; r < bl.parts.size(); ++r) {
-            const Part& pt = bl.parts[r];
-            row.push_back(pt.k);
-            row.push_back(base[r]);
-            row.push_back(pt.first ? 1 : 0);
-            row.push_back((int32_t)ent.size());
-            int cnt = 0;
-            for (int j = 0; j < last; ++j) {
-                const bool mine = slot_of[r][j] >= 0;
-                if (!mine && !(pt.first && !nz(pt.k, j))) continue;     // other part's column
-                ent.push_back((int32_t)j | ((int32_t)(mine ? slot_of[r][j] : out.ZERO) << 16));
-                // the entry's column constant next to it: 1 / W_j (W_j / W_N for the last species' pseudo-row)
-                out.E.push_back(pt.k == last ? p.sp[(size_t)j * SPW + 3] : p.sp[(size_t)j * SPW]);
-                ++cnt;
+        std::vector<Rec> recs;
+        for (int b : gb[g]) {
+            const Block& bl = blocks[b];
+            // slots: DENSE per part, then the parts' S columns
+            std::vector<int> base(bl.parts.size());
+            std::vector<std::vector<int>> slot_of(bl.parts.size(), std::vector<int>(nsp, -1));
+            int next = DENSE * (int)bl.parts.size();
+            for (size_t r = 0; r < bl.parts.size(); ++r) {
+                base[r] = DENSE * (int)r;
+                for (int j : bl.parts[r].cols) slot_of[r][j] = next++;
             }
-            // padded to whole batches of TAB_EB entries by repeating the last one (the same value to the same
-            // address once more): the output loop has no tail and reads one batch ahead
-            while (cnt % TAB_EB) { ent.push_back(ent.back()); out.E.push_back(out.E.back()); ++cnt; }
-            row.push_back(cnt);
-            row.push_back(0);
-        }
-        // visits
-        for (int d : bl.rx) {
-            const int32_t* ri = &p.ri[(size_t)d * RIW];
-            const int fl = ri[RI_FLAGS];
-            std::vector<std::pair<int, double>> hits;      // (part index, nu_k)
-            for (size_t r = 0; r < bl.parts.size(); ++r)
-                for (int q = 0; q < ri[RI_NET_CNT]; ++q)
-                    if (p.net_sp[ri[RI_NET_PTR] + q] == bl.parts[r].k) hits.push_back({(int)r, p.net_nu[ri[RI_NET_PTR] + q]});
-            // a visit carries its reaction's records inline (integer record + enhanced colliders; real record + K_c
-            // polynomial rows + efficiencies): everything a visit reads sits at fixed offsets from the two stream
-            // pointers, i.e. one round of scalar loads instead of a chain of dependent ones
-            const size_t vi0 = vi.size(), vd0 = vd.size();
-            vi.push_back(d);
-            vi.push_back((int32_t)hits.size());
-            vi.push_back(0);        // ints of this visit (filled in below): the next visit's records are
-            vi.push_back(0);        // doubles of this visit            requested while this one is computed
-            for (int f = 0; f < RIW; ++f) vi.push_back(ri[f]);
-            for (int e = 0; e < ri[RI_EFF_CNT]; ++e) vi.push_back(p.eff_sp[ri[RI_EFF_PTR] + e]);
-            for (int f = 0; f < RDW; ++f) vd.push_back(p.rd[(size_t)d * RDW + f]);
-            if (fl & F_REV)
-                for (int c = 0; c < ri[RI_KC_CNT] * KCW; ++c) vd.push_back(p.kcg[(size_t)ri[RI_KC_PTR] * KCW + c]);
-            for (int e = 0; e < ri[RI_EFF_CNT]; ++e) vd.push_back(p.eff_am1[ri[RI_EFF_PTR] + e]);
-            int sp[TAB_NSLOT];
-            for (int t = 0; t < 3; ++t) { sp[t] = ri[RI_R0 + t]; sp[3 + t] = (fl & F_REV) ? ri[RI_P0 + t] : ONE; }
-            sp[6] = (fl & F_COLLIDER) ? ri[RI_COLLIDER] : ONE;
-            for (auto& h : hits) {
-                const int r = h.first;
-                const double nu = h.second;
-                int sl[TAB_NSLOT];
-                double mult[TAB_NSLOT];
-                for (int t = 0; t < TAB_NSLOT; ++t) {
-                    sl[t] = out.TRASH; mult[t] = 0.0;
-                    const int j = sp[t];
-                    if (j == ONE || j >= last || j < 0) continue;
-                    // the first position of a species within its side takes the multiplicity
-                    const int t0 = t < 3 ? 0 : t < 6 ? 3 : 6, t1 = t < 3 ? 3 : t < 6 ? 6 : 7;
-                    bool first = true; int cnt = 0;
-                    for (int u = t0; u < t1; ++u) if (sp[u] == j) { if (u < t) first = false; ++cnt; }
-                    if (!first || slot_of[r][j] < 0) continue;
-                    sl[t] = slot_of[r][j]; mult[t] = cnt;
-                }
-                // enhanced colliders: (alpha - 1) b_M into the collider's column (the last species goes to gN)
-                std::vector<std::pair<int, double>> effl;
-                if (fl & F_EFFTYPE)
-                    for (int e = 0; e < ri[RI_EFF_CNT]; ++e) {
-                        const int es = p.eff_sp[ri[RI_EFF_PTR] + e];
-                        if (es != last && slot_of[r][es] >= 0) effl.push_back({slot_of[r][es], nu * p.eff_am1[ri[RI_EFF_PTR] + e]});
+            if (next > cap) return fail("k_tab: internal error, block exceeds the accumulator budget");
+            { Rec r; r.type = TAB_T_BEGIN; r.a1 = next; put_rec(recs, std::move(r)); }
+            for (int d : bl.rx) {
+                const int32_t* ri = &p.ri[(size_t)d * RIW];
+                const int fl = ri[RI_FLAGS];
+                std::vector<std::pair<int, double>> hits;      // (part index, nu_k)
+                for (size_t r = 0; r < bl.parts.size(); ++r)
+                    for (int q = 0; q < ri[RI_NET_CNT]; ++q)
+                        if (p.net_sp[ri[RI_NET_PTR] + q] == bl.parts[r].k) hits.push_back({(int)r, p.net_nu[ri[RI_NET_PTR] + q]});
+                int sp[TAB_NSLOT];
+                for (int t = 0; t < 3; ++t) { sp[t] = ri[RI_R0 + t]; sp[3 + t] = (fl & F_REV) ? ri[RI_P0 + t] : ONE; }
+                sp[6] = (fl & F_COLLIDER) ? ri[RI_COLLIDER] : ONE;
+                // a visit carries its reaction's records inline: integer record + enhanced colliders, real record +
+                // K_c polynomial rows + efficiencies, then the accumulate program of every row of the block it changes
+                // (a visit that would not fit a ring slot is cut into several visits of the same reaction)
+                size_t h0 = 0;
+                while (h0 < hits.size() || h0 == 0) {
+                    Rec v;
+                    v.type = TAB_T_VISIT;
+                    for (int f = 0; f < RIW; ++f) v.iw.push_back(ri[f]);
+                    for (int e = 0; e < ri[RI_EFF_CNT]; ++e) v.iw.push_back(p.eff_sp[ri[RI_EFF_PTR] + e]);
+                    for (int f = 0; f < RDW; ++f) v.dw.push_back(p.rd[(size_t)d * RDW + f]);
+                    if (fl & F_REV)
+                        for (int c = 0; c < ri[RI_KC_CNT] * KCW; ++c) v.dw.push_back(p.kcg[(size_t)ri[RI_KC_PTR] * KCW + c]);
+                    for (int e = 0; e < ri[RI_EFF_CNT]; ++e) v.dw.push_back(p.eff_am1[ri[RI_EFF_PTR] + e]);
+                    if (words_of(v) > TAB_RSZ) return fail("k_tab: a reaction record exceeds the ring slot (too many K_c groups / colliders)");
+                    int nh = 0;
+                    for (; h0 < hits.size(); ++h0) {
+                        const int r = hits[h0].first;
+                        const double nu = hits[h0].second;
+                        int sl[TAB_NSLOT];
+                        double mult[TAB_NSLOT];
+                        for (int t = 0; t < TAB_NSLOT; ++t) {
+                            sl[t] = out.TRASH; mult[t] = 0.0;
+                            const int j = sp[t];
+                            if (j == ONE || j >= last || j < 0) continue;
+                            // the first position of a species within its side takes the multiplicity
+                            const int t0 = t < 3 ? 0 : t < 6 ? 3 : 6, t1 = t < 3 ? 3 : t < 6 ? 6 : 7;
+                            bool first = true; int cnt = 0;
+                            for (int u = t0; u < t1; ++u) if (sp[u] == j) { if (u < t) first = false; ++cnt; }
+                            if (!first || slot_of[r][j] < 0) continue;
+                            sl[t] = slot_of[r][j]; mult[t] = cnt;
+                        }
+                        // enhanced colliders: (alpha - 1) b_M into the collider's column (the last species goes to gN)
+                        std::vector<std::pair<int, double>> effl;
+                        if (fl & F_EFFTYPE)
+                            for (int e = 0; e < ri[RI_EFF_CNT]; ++e) {
+                                const int es = p.eff_sp[ri[RI_EFF_PTR] + e];
+                                if (es != last && slot_of[r][es] >= 0) effl.push_back({slot_of[r][es], nu * p.eff_am1[ri[RI_EFF_PTR] + e]});
+                            }
+                        // general stoichiometry: one value per factor
+                        std::vector<std::pair<int, int>> genl;
+                        if (fl & F_GEN) {
+                            const int nf = ri[RI_GEN_NR] + ((fl & F_REV) ? ri[RI_GEN_NP] : 0);
+                            for (int f = 0; f < nf; ++f) {
+                                const int j = p.gen_sp[ri[RI_GEN_PTR] + f];
+                                if (j < last && slot_of[r][j] >= 0) genl.push_back({slot_of[r][j], f});
+                            }
+                        }
+                        Rec t = v;          // tentatively with this hit
+                        t.iw.push_back(base[r]);
+                        for (int q = 0; q < TAB_NSLOT; ++q) t.iw.push_back(sl[q]);
+                        t.iw.push_back((int32_t)effl.size());
+                        t.iw.push_back((int32_t)genl.size());
+                        t.iw.push_back((bl.parts[r].k == last && d == p.lastq_rxn) ? 1 : 0);
+                        for (auto& e : effl) t.iw.push_back(e.first);
+                        for (auto& q : genl) { t.iw.push_back(q.first); t.iw.push_back(q.second); }
+                        t.dw.push_back(nu);
+                        for (int q = 0; q < TAB_NSLOT; ++q) t.dw.push_back(nu * mult[q]);
+                        for (auto& e : effl) t.dw.push_back(e.second);
+                        for (size_t q = 0; q < genl.size(); ++q) t.dw.push_back(nu);
+                        if (words_of(t) > TAB_RSZ) {
+                            if (nh == 0) return fail("k_tab: one row's share of a visit exceeds the ring slot");
+                            break;
+                        }
+                        v = std::move(t);
+                        ++nh;
                     }
-                // general stoichiometry: one value per factor
-                std::vector<std::pair<int, int>> genl;
-                if (fl & F_GEN) {
-                    const int nf = ri[RI_GEN_NR] + ((fl & F_REV) ? ri[RI_GEN_NP] : 0);
-                    for (int f = 0; f < nf; ++f) {
-                        const int j = p.gen_sp[ri[RI_GEN_PTR] + f];
-                        if (j < last && slot_of[r][j] >= 0) genl.push_back({slot_of[r][j], f});
-                    }
+                    v.a1 = nh;
+                    put_rec(recs, std::move(v));
+                    ++out.nvisit;
+                    if (hits.empty()) break;
                 }
-                vi.push_back(base[r]);
-                for (int t = 0; t < TAB_NSLOT; ++t) vi.push_back(sl[t]);
-                vi.push_back((int32_t)effl.size());
-                vi.push_back((int32_t)genl.size());
-                vi.push_back((bl.parts[r].k == last && d == p.lastq_rxn) ? 1 : 0);
-                vd.push_back(nu);
-                for (int t = 0; t < TAB_NSLOT; ++t) vd.push_back(nu * mult[t]);
-                for (auto& e : effl) { vi.push_back(e.first); vd.push_back(e.second); }
-                for (auto& g : genl) { vi.push_back(g.first); vi.push_back(g.second); vd.push_back(nu); }
             }
-            vi[vi0 + 2] = (int32_t)(vi.size() - vi0);
-            vi[vi0 + 3] = (int32_t)(vd.size() - vd0);
-            ++out.nvisit;
+            // output records: a row (or column part of a row), at most TAB_EMAX entries each
+            for (size_t r = 0; r < bl.parts.size(); ++r) {
+                const Part& pt = bl.parts[r];
+                std::vector<std::pair<int32_t, double>> en;
+                for (int j = 0; j < last; ++j) {
+                    const bool mine = slot_of[r][j] >= 0;
+                    if (!mine && !(pt.first && !nz(pt.k, j))) continue;     // other part's column
+                    // the entry's column constant next to it: 1 / W_j (W_j / W_N for the last species' pseudo-row)
+                    en.push_back({(int32_t)j | ((int32_t)(mine ? slot_of[r][j] : out.ZERO) << 16),
+                                  pt.k == last ? p.sp[(size_t)j * SPW + 3] : p.sp[(size_t)j * SPW]});
+                }
+                bool first = pt.first;
+                for (size_t e0 = 0; e0 < en.size() || e0 == 0; e0 += TAB_EMAX) {
+                    Rec o;
+                    o.type = TAB_T_ROW;
+                    o.flags = first ? 1 : 0;
+                    o.a1 = pt.k;
+                    const size_t e1 = std::min(en.size(), e0 + TAB_EMAX);
+                    size_t cnt = e1 > e0 ? e1 - e0 : 0;
+                    // padded to whole batches of TAB_EB entries by repeating the last one (the same value to the same
+                    // address once more), plus one batch of look-ahead
+                    const size_t padded = (cnt + TAB_EB - 1) / TAB_EB * TAB_EB;
+                    o.iw.push_back(base[r]);
+                    o.iw.push_back((int32_t)padded);
+                    for (size_t e = 0; e < padded + TAB_EB; ++e) {
+                        const auto& x = cnt ? en[e0 + std::min(e, cnt - 1)] : std::pair<int32_t, double>{out.ZERO << 16, 0.0};
+                        o.iw.push_back(x.first);
+                        o.dw.push_back(x.second);
+                    }
+                    if (!cnt) { o.iw[1] = 0; }
+                    if (!put_rec(recs, std::move(o))) return fail("k_tab: internal error, output record exceeds the ring slot");
+                    first = false;
+                    if (en.empty()) break;
+                }
+            }
         }
+        // serialise the group's records; every header names the sizes of the next two records
+        grp.push_back((int32_t)S.size());
+        grp.push_back((int32_t)recs.size());
+        grp.push_back(recs.size() > 0 ? words_of(recs[0]) : 0);
+        grp.push_back(recs.size() > 1 ? words_of(recs[1]) : 0);
+        for (size_t q = 0; q < recs.size(); ++q) {
+            const Rec& r = recs[q];
+            const int niw = (int)((r.iw.size() + 1) / 2);
+            auto pair = [&](int32_t lo, int32_t hi) { double w; int32_t v[2] = {lo, hi}; memcpy(&w, v, 8); S.push_back(w); };
+            pair(r.type | (r.flags << 8), r.a1);
+            pair(q + 1 < recs.size() ? words_of(recs[q + 1]) : 0, q + 2 < recs.size() ? words_of(recs[q + 2]) : 0);
+            pair(niw, q + 3 < recs.size() ? words_of(recs[q + 3]) : 0);
+            for (int w = 0; w < niw; ++w) pair(r.iw[2 * w], 2 * w + 1 < (int)r.iw.size() ? r.iw[2 * w + 1] : 0);
+            for (double x : r.dw) S.push_back(x);
+        }
+        if (S.size() >= (1u << 30)) return fail("k_tab: program too large");
     }
-    for (int q = 0; q < TAB_EB; ++q) { ent.push_back(out.ZERO << 16); out.E.push_back(0.0); }      // look-ahead of the last batch
-    if (ent.size() >= (1u << 30) || vi.size() >= (1u << 30)) return fail("k_tab: program too large");
-    auto put = [&](const std::vector<int32_t>& v) { const int o = (int)out.I.size(); out.I.insert(out.I.end(), v.begin(), v.end()); return o; };
-    out.o_grp_ptr = put(grp_ptr); out.o_grp_blk = put(grp_blk); out.o_blk = put(blk); out.o_row = put(row);
-    out.o_ent = put(ent); out.o_vi = put(vi);
+    for (int q = 0; q < TAB_RSZ; ++q) S.push_back(0.0);          // the last fetches read a whole slot
+    out.I = grp;
     out.ok = true;
     return true;
 }

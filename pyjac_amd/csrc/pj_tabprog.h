@@ -30,8 +30,12 @@ namespace pj {
 constexpr int TAB_NSLOT = 7;          // molecule-slot positions of a reaction: R0 R1 R2 P0 P1 P2 collider
 constexpr int TAB_HIT_I = 1 + TAB_NSLOT + 3;   // ints per hit: dense base, 7 slots, n_eff, n_gen, flags (1: J_nplusone quirk value)
 constexpr int TAB_HIT_D = 1 + TAB_NSLOT;       // doubles per hit: nu_k, nu_k * multiplicity per slot
-constexpr int TAB_BLK = 6, TAB_ROW = 6, TAB_DENSE = 5;
-constexpr int TAB_EB = 8;             // output entries per batch (a row's entry list is padded to whole batches)
+constexpr int TAB_DENSE = 5;          // omega_k, P_k, Q_k, sum nu theta, J_nplusone quirk value
+constexpr int TAB_EB = 8;             // output entries per batch (a record's entry list is padded to whole batches)
+constexpr int TAB_RSZ = 192;          // 8-byte words of a ring slot = largest record
+constexpr int TAB_EMAX = 112;         // output entries per record at most
+constexpr int TAB_RING_WORDS = 3 * TAB_RSZ;   // per wavefront: the record in use and the next two
+enum { TAB_T_VISIT = 0, TAB_T_ROW = 1, TAB_T_BEGIN = 2 };
 
 struct TabProg {
     bool ok = false;
@@ -40,27 +44,29 @@ struct TabProg {
     int ZERO = 0, TRASH = 0;          // slot that always reads 0 / slot that takes updates nobody wants
     int nblk = 0, nvisit = 0;
     size_t lds_bytes = 0;
-    // integer program, one array with offsets (scalar loads):
-    //   grp_ptr[G + 1]                 blocks of group g: grp_blk[grp_ptr[g] .. grp_ptr[g + 1])
-    //   blk[b * TAB_BLK ..]            visit offset (into vi), visit count, first row, row count, offset into D, slots used
-    //   row[r * 6 ..]                  species k, dense base slot, flags (1: writes omega_k / d/dT column),
-    //                                  entry offset (into ent), entry count, reserved
-    //   ent[e]                         column j | slot << 16   (slot == ZERO: structurally zero)
-    //   vi[...]                        visits: rxn, nhit, ints and doubles of this visit, the reaction's integer record (RIW) and enhanced-collider
-    //                                  species inline, then per hit TAB_HIT_I ints + n_eff slots + n_gen (slot, factor)
-    // doubles vd[...]: per visit the reaction's real record (RDW), its K_c rows (KCW each) and efficiencies - 1
-    //                  inline, then per hit TAB_HIT_D doubles + n_eff coefficients + n_gen nu_k
+    // D: the record streams of the lane groups, 8-byte words.  A record:
+    //   word 0   int32 pair { type | flags << 8, a1 }     VISIT: a1 = rows of the block this visit changes ("hits");
+    //                                                     BEGIN: a1 = accumulator slots to clear; ROW: a1 = species k,
+    //                                                     flags & 1: this part also writes omega_k / the d/dT column
+    //   word 1   int32 pair { words of the next record, words of the one after }
+    //   word 2   int32 pair { integer words that follow, words of the third record from here }
+    //   then the integer words (int32 pairs), then doubles:
+    //   VISIT    ints: the reaction's integer record (RIW), its enhanced-collider species, then per hit TAB_HIT_I
+    //            ints + n_eff slots + n_gen (slot, factor);  doubles: the real record (RDW), its K_c rows (KCW each),
+    //            efficiencies - 1, then per hit TAB_HIT_D doubles + n_eff coefficients + n_gen nu_k
+    //   ROW      ints: dense base slot, entries (padded to batches of TAB_EB, plus one batch), then
+    //            column j | slot << 16 each (slot == ZERO: structurally zero);  doubles: 1 / W_j per entry
+    //            (W_j / W_N in the last species' pseudo-row)
+    // I: per group { first word, records, words of the first record, words of the second }
     std::vector<int32_t> I;
     std::vector<double> D;
-    std::vector<double> E;             // per output entry: 1 / W_j (W_j / W_N in the last species' pseudo-row)
-    int o_grp_ptr = 0, o_grp_blk = 0, o_blk = 0, o_row = 0, o_ent = 0, o_vi = 0;
     std::string error;
 };
 
-// Chooses L (the largest of 256 / 128 / 64 that leaves at least 44 accumulator slots next to the concentration
-// columns in `lds_avail` bytes), partitions the rows, assigns blocks to groups (longest processing time first)
-// and writes the program.  false + error: the mechanism does not fit (a row needs more than the budget even
-// when split, which cannot happen, or more than 32767 slots / entries).
-bool build_tab_program(const Programs& p, size_t lds_avail, TabProg& out);
+// Chooses L (the largest of 256 / 128 / 64 that leaves at least 56 accumulator slots next to the concentration
+// columns and the wavefronts' rings in `lds_avail` bytes; force_L: that value), partitions the rows, assigns blocks
+// to groups (longest processing time first) and writes the record streams.  false + error: the mechanism does not
+// fit (a reaction record larger than a ring slot, no room for accumulators).
+bool build_tab_program(const Programs& p, size_t lds_avail, TabProg& out, int force_L = 0);
 
 }  // namespace pj

@@ -34,7 +34,7 @@ import numpy as np
 from .mechanism import Mechanism, PA, RU, get_nu
 
 MAGIC = 0x314D4A50
-VERSION = 1
+VERSION = 2
 HDR = 96
 
 # reaction flag bits

@@ -13,6 +13,7 @@ using std::exp; using std::log; using std::fmax; using std::pow; using std::floo
 #define PJ_LDS_ADD(ptr, v) (*(ptr) += (v))
 #define PJT_CONST
 #define PJ_UNIFORM(x) (x)
+#define PJT_FETCH_ALL 1
 #include "../../pyjac_amd/csrc/pj_kernel.h"
 #include "../../pyjac_amd/csrc/pj_tab.h"
 #include "../../pyjac_amd/csrc/pj_tables.cpp"
@@ -106,15 +107,13 @@ extern "C" int emu_tab_run(const int32_t* I, long nI, const double* D, long nD, 
     std::vector<double> scr((size_t)(P.nsp + 1) * n);
     TabDev X;
     X.L = T.L; X.G = T.G; X.B = T.B; X.ZERO = T.ZERO; X.TRASH = T.TRASH;
-    T.I.resize(T.I.size() + 64, 0); T.D.resize(T.D.size() + 64, 0.0);      // look-ahead of the last visit
-    X.I = T.I.data(); X.D = T.D.data(); X.E = T.E.data();
-    X.o_grp_ptr = T.o_grp_ptr; X.o_grp_blk = T.o_grp_blk; X.o_blk = T.o_blk; X.o_row = T.o_row; X.o_ent = T.o_ent; X.o_vi = T.o_vi;
+    X.I = T.I.data(); X.D = T.D.data();
     X.scr = scr.data(); X.scr_ld = n; X.dbg = 0;
     Batch B;
     memset(&B, 0, sizeof(B));
     B.n = n; B.pres = pres; B.y = y_soa; B.y_si = n; B.y_ss = 1; B.jac = jac;
     if (jac_aos) { B.j_si = 1; B.j_ss = (long)P.nsp * P.nsp; } else { B.j_si = n; B.j_ss = 1; }
-    std::vector<double> lds(T.lds_bytes / 8 + 16, std::nan(""));
+    std::vector<double> lds(T.lds_bytes / 8 + 256 * TAB_RING_WORDS, std::nan(""));      // (a ring per emulated thread)
     std::vector<TabLane> Ln(256);
     for (long wg = 0; wg * T.L < n; ++wg) {
         for (int tid = 0; tid < 256; ++tid) tab_stage(M, X, B, lds.data(), tid, wg, Ln[tid]);

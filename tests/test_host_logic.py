@@ -143,8 +143,8 @@ def test_kernel_phases_match_oracle(name, TS, NT, aos, tables):
 
 @pytest.mark.parametrize('name,lds_kb,aos,sum_last', [
     ('h2o2_n2', 156, False, 0), ('synth_alltypes', 156, True, 1),
-    ('synth_alltypes', 30, False, 0),        # 64 states x 4 lane groups, 12 slots: rows split into column parts
-    ('synth_srichb', 156, False, 0), ('synth_fracnu', 40, True, 0), ('synth_mid24', 156, False, 1),
+    ('synth_alltypes', 50, False, 0),        # 64 states x 4 lane groups, 13 slots: rows split into column parts
+    ('synth_srichb', 156, False, 0), ('synth_fracnu', 52, True, 0), ('synth_mid24', 156, False, 1),
     ('gri30_shaped', 156, False, 0),         # 128 states x 2 lane groups
     ('usc2_shaped', 156, False, 0),          # 64 states x 4 lane groups, hub rows split
 ])
@@ -166,7 +166,7 @@ def test_table_driven_lane_kernel_matches_oracle(name, lds_kb, aos, sum_last, ta
                             int(aos), sum_last, ctypes.c_long(lds_kb * 1024), info)
     assert rc == 0
     L, G, B = info[0], info[1], info[2]
-    assert L * G == 256 and info[5] <= lds_kb * 1024 and tab.nsp * L * 8 + 256 * B * 8 == info[5]
+    assert L * G == 256 and info[5] <= lds_kb * 1024 and tab.nsp * L * 8 + 256 * B * 8 + 4 * 576 * 8 == info[5]
     got = jac.reshape(n, -1) if aos else jac.reshape(-1, n).T
     assert not np.isnan(got).any()           # every entry written
     o = Oracle(tab)
@@ -214,3 +214,27 @@ def test_generated_build_dir_matches_reference_callers(tmp_path):
             "assert all(hasattr(c, f) for f in ('py_cuinit', 'py_cujac', 'py_cuclean')); print('ok')" % (d, ROOT))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == 'ok', out.stderr[-1500:]
+
+
+def test_blob_validation_refuses_bad_flag_combinations_and_versions(tables):
+    """validate_blob (csrc/pj_tables.cpp): a Chebyshev reaction that is also PLOG / falloff / third body, or SRI
+    parameters on something that is not a plain falloff, would make the kernels index the wrong table (the record
+    field is shared): refused at load time, with the version mismatch of an old table file reported as such."""
+    import pyjac_amd
+    from pyjac_amd import _lib
+    from pyjac_amd.tables import F_CHEB, F_PLOG, F_SRI, IA_FLAGS, MechTables
+    tab = tables('synth_srichb')
+    I = np.array(tab.I, dtype=np.int32)
+    fo = I[16 + IA_FLAGS]
+    cheb = [i for i in range(tab.nrxn) if I[fo + i] & F_CHEB]
+    sri = [i for i in range(tab.nrxn) if I[fo + i] & F_SRI]
+    assert cheb and sri
+    for idx, extra, msg in ((cheb[0], F_PLOG, 'Chebyshev'), (sri[0], F_PLOG, 'SRI')):
+        J = I.copy()
+        J[fo + idx] |= extra
+        with pytest.raises(_lib.PyjacError, match=msg):
+            pyjac_amd.Evaluator(MechTables(J, tab.D.copy(), tab.nsp, tab.nrxn, tab.nrev, tab.npres, []), specialize='off')
+    J = I.copy()
+    J[1] = 1
+    with pytest.raises(_lib.PyjacError, match='version 1'):
+        pyjac_amd.Evaluator(MechTables(J, tab.D.copy(), tab.nsp, tab.nrxn, tab.nrev, tab.npres, []), specialize='off')
