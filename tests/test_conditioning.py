@@ -24,12 +24,32 @@ from emu_libs import rblk_emu_lib, run_jacobian  # noqa: E402
 from pyjac_amd import synth  # noqa: E402
 
 
+def _ktab_emulated(tab, pres, y_soa):
+    """The same formulation through the table-driven kernel k_tab, emulated thread by thread (tests/emu/emu.cpp):
+    no per-mechanism compilation, so the 111-species case costs seconds instead of a two-minute emulation build."""
+    import ctypes
+    from test_host_logic import _emu
+    dp = ctypes.POINTER(ctypes.c_double)
+    n = pres.size
+    I = np.ascontiguousarray(tab.I, dtype=np.int32)
+    D = np.ascontiguousarray(tab.D)
+    jac = np.full(tab.nsp * tab.nsp * n, np.nan)
+    P = lambda a: a.ctypes.data_as(dp)
+    rc = _emu().emu_tab_run(I.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.c_long(I.size), P(D),
+                            ctypes.c_long(D.size), ctypes.c_long(n), P(np.ascontiguousarray(pres)),
+                            P(np.ascontiguousarray(y_soa)), P(jac), 0, 0, ctypes.c_long(156 * 1024), None)
+    assert rc == 0
+    return jac.reshape(-1, n).T
+
+
 @pytest.mark.parametrize('name,n_random', [('gri30_shaped', 300), ('usc2_shaped', 48)])
 def test_regrouped_formulation_is_closer_to_the_truth_than_the_reference(name, n_random, tables, golden, tmp_path_factory):
     from oracle.oracle import Oracle, OracleQuad
     tab = tables(name)
-    ev, L = rblk_emu_lib(name, 56, tmp_path_factory, blocks_per_part=13, c_lds=int(tab.nsp > 64))
-    nsp = ev.nsp
+    nsp = tab.nsp
+    # 53 species: the compiled row-block kernels through their CPU emulation build (shared with
+    # tests/test_rblk_emu.py); 111 species: the table-driven kernel of the same formulation
+    L = rblk_emu_lib(name, 56, tmp_path_factory, blocks_per_part=13, c_lds=0)[1] if nsp <= 64 else None
     g = golden(name)
     pres, y = synth.dist_b(n_random, nsp, seed=11, Tlo=800, Thi=2500)
     pres = np.concatenate([g['pres'], pres])
@@ -38,8 +58,9 @@ def test_regrouped_formulation_is_closer_to_the_truth_than_the_reference(name, n
     ng = g['pres'].size
     truth = OracleQuad(tab).batch_jacob(pres, y_aos)
     orc = Oracle(tab).batch_jacob(pres, y_aos)
-    emu = run_jacobian(L, nsp, pres, y)
-    rep = truth_report(emu, orc, truth, nsp, label='%s (emulated pj_rblk vs oracle, %d states)' % (name, pres.size))
+    emu = run_jacobian(L, nsp, pres, y) if L is not None else _ktab_emulated(tab, pres, y)
+    rep = truth_report(emu, orc, truth, nsp, label='%s (emulated %s vs oracle, %d states)' % (
+        name, 'pj_rblk' if L is not None else 'k_tab', pres.size))
     # the kernels' formulation meets the entry-wise tolerance against the exact value, with room to spare
     assert rep['test_vs_truth'] < 1e-7
     assert rep['test_over_1e6'] == 0
