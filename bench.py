@@ -287,13 +287,17 @@ def main():
         ok, nbytes = True, 0
         peer = (rank + 1) % world
         p_pres, p_y = make_states(w, ev.nsp, n, seed=20240901 + peer)
-        sample = torch.arange(0, nv, max(1, nv // 64))
-        pj = ev.jacobian(torch.from_numpy(np.ascontiguousarray(p_pres[sample.numpy()])).to(dev),
-                         torch.from_numpy(np.ascontiguousarray(p_y[:, sample.numpy()] if soa else p_y[:, sample.numpy()].T)).to(dev),
+        # the first min(nv, 512) states of the peer's shard, as one contiguous batch: whole workgroups, i.e. the same
+        # kernel variant that produced the peer's shard (a strided handful would take the small-batch kernels)
+        ns = min(nv, 512)
+        sample = torch.arange(0, ns)
+        pj = ev.jacobian(torch.from_numpy(np.ascontiguousarray(p_pres[:ns])).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(p_y[:, :ns] if soa else p_y[:, :ns].T)).to(dev),
                          y_layout=L, jac_layout=L)
         pj = pj if soa else pj.T
         sync()
         remote_err = 0.0
+        nsp_ = ev.nsp
         for c0, g in iter_gathered(shard, int(os.environ.get('PJ_VALIDATE_CHUNK', 1024))):
             cols = g.shape[2]
             ok &= bool(torch.equal(g[rank], shard[:, c0:c0 + cols])) and bool(torch.isfinite(g).all())
@@ -303,13 +307,18 @@ def main():
             if bool(inside.any()):
                 got = g[peer][:, (sample[inside] - c0).to(g.device)]
                 ref = pj[:, inside.to(pj.device)]
-                remote_err = max(remote_err, float(((got - ref).abs() / (ref.abs() + 1e-300)).max()))
+                # entry-wise |d| <= 1e-6 |J| + 1e-12 max(row scale, column scale): the metric of tests/conftest.py
+                # (identical kernels give 0; another kernel variant differs at rounding level on entries that are
+                # 1e-13 of their row scale, where a plain relative error means nothing)
+                ab = ref.abs().reshape(nsp_, nsp_, -1)                     # [col][row][state]
+                scale = torch.maximum(ab.amax(dim=0, keepdim=True), ab.amax(dim=1, keepdim=True)).expand_as(ab).reshape(ref.shape)
+                tol = 1e-6 * ref.abs() + 1e-12 * scale + 1e-300
+                remote_err = max(remote_err, float(((got - ref).abs() / tol).max()))
         for r in range(world):
             ok &= bool(torch.allclose(cs[r, 0], sums[r], rtol=1e-9))
-        # same kernels on the same inputs: bit-identical unless the two ranks run different kernel variants
-        ok &= remote_err <= 1e-9
+        ok &= remote_err <= 1.0
         validation = dict(states_per_rank=nv, gathered_bytes=nbytes, ok=bool(ok), remote_rank_checked=peer,
-                          remote_states_recomputed=int(sample.numel()), remote_max_rel_diff=remote_err,
+                          remote_states_recomputed=int(sample.numel()), remote_max_err_over_tolerance=remote_err,
                           seconds=round(time.perf_counter() - t0, 4))
 
     if rank == 0:
