@@ -67,6 +67,12 @@ int pj_mech_set_sum_last_species(pj_mech* m, int on);
  * return PJ_EINVAL naming the first offending state; costs one pass over the inputs and a stream
  * synchronisation.  0 (default): no check, as in the reference (undefined results for such states). */
 int pj_mech_set_check_inputs(pj_mech* m, int on);
+/* Everything the six per-state functions below return, for ONE state y = [T, Y_0 .. Y_{NSP-2}], in one upload, one
+ * set of launches and one download (any output may be null).  The reference's functional tester calls the six
+ * functions on the same state one after the other (functional_tester/test.py:1299-1327); pyjac_amd/pyjacob.py fills
+ * a one-state cache through this entry point so that the sequence costs one evaluation. */
+int pj_eval_state(pj_mech* m, double pres, const double* y, double* conc, double* fwd, double* rev, double* pres_mod,
+                  double* spec_rates, double* dy, double* jac);
 /* Which kernel evaluates Jacobians when no mechanism-specific library is attached (or pj_mech_use_spec(m, 0)):
  * 2 k_tab -- table-driven, one state per lane, row blocks with accumulators in LDS, wavefront-uniform control
  * flow over a program built at load time (csrc/pj_tab.h; the formulation of the compiled row-block kernels: every

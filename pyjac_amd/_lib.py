@@ -33,6 +33,7 @@ SIGNATURES = {
     'pj_mech_set_sum_last_species': (ctypes.c_int, [_vp, ctypes.c_int]),
     'pj_mech_set_check_inputs': (ctypes.c_int, [_vp, ctypes.c_int]),
     'pj_mech_set_generic_kernel': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'pj_eval_state': (ctypes.c_int, [_vp, ctypes.c_double] + [_dp] * 8),
     'pj_mech_set_launch': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     'pj_mech_get_launch': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int),
                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -1009,6 +1009,14 @@ int pj_eval_jacob(pj_mech* m, double t, double pres, const double* y, double* ja
     return run_ws(m, m->ws1, 1, &pres, y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, jac, nullptr);
 }
 
+int pj_eval_state(pj_mech* m, double pres, const double* y, double* conc, double* fwd, double* rev, double* pres_mod,
+                  double* spec_rates, double* dy, double* jac)
+{
+    int rc = one(m);
+    if (rc) return rc;
+    return run_ws(m, m->ws1, 1, &pres, y, conc, fwd, rev, pres_mod, spec_rates, dy, jac, nullptr);
+}
+
 int pj_eval_conc(pj_mech* m, double T, double pres, const double* mass_frac, double* y_N,
                  double* mw_avg, double* rho, double* conc)
 {

@@ -745,3 +745,52 @@ def test_optional_precondition_check(torch_cuda):
         ev.jacobian(badp, d_y)
     ev.set_check_inputs(False)
     ev.jacobian(badp, d_y)                     # unchecked: no error (results for that state undefined)
+
+
+def test_per_state_cache_serves_the_testers_call_sequence(golden, torch_cuda):
+    """pyjacob's one-state cache: the six per-state calls of the reference's functional tester on one state
+    (test.py:1299-1327) cost one evaluation, give exactly what the uncached calls give, and a changed input is never
+    served from the cache."""
+    from pyjac_amd import pyjacob
+    g = golden('synth_alltypes')
+    ev = pyjacob.use_mechanism(MECHS['synth_alltypes'])
+    nsp = ev.nsp
+
+    def sequence(P, y):
+        mass_frac = np.concatenate([y[1:], [0.0]])
+        out = dict(conc=np.zeros(nsp), fwd=np.zeros(ev.n_fwd), rev=np.zeros(ev.n_rev), pm=np.zeros(ev.n_pres_mod),
+                   sr=np.zeros(nsp), dy=np.zeros(nsp + 1), jac=np.zeros(nsp * nsp))
+        pyjacob.py_eval_conc(y[0], P, mass_frac, 0.0, 0.0, out['conc'])
+        pyjacob.py_eval_rxn_rates(y[0], P, out['conc'], out['fwd'], out['rev'])
+        pyjacob.py_get_rxn_pres_mod(y[0], P, out['conc'], out['pm'])
+        pyjacob.py_eval_spec_rates(out['fwd'], out['rev'], out['pm'], out['sr'])
+        pyjacob.py_dydt(0.0, P, np.concatenate([y, [0.0]]), out['dy'])
+        pyjacob.py_eval_jacobian(0.0, P, y, out['jac'])
+        out['yN'] = mass_frac[-1]
+        return out
+
+    for s in (3, 40):
+        P, y = float(g['pres'][s]), g['y'][s].copy()
+        pyjacob.cache_states(False)
+        plain = sequence(P, y)
+        pyjacob.cache_states(True)
+        h0 = pyjacob.cache_hits
+        cached = sequence(P, y)
+        assert pyjacob.cache_hits - h0 == 5          # one evaluation, five calls served from it
+        for k in ('conc', 'fwd', 'rev', 'pm', 'jac'):
+            mx, _ = thresholded_rel_err(cached[k], plain[k])
+            assert mx < 1e-12, (k, mx)
+        assert abs(cached['yN'] - plain['yN']) < 1e-15
+        sc = np.abs(plain['fwd']).max() + 1e-300
+        assert np.abs(cached['sr'] - plain['sr']).max() <= 1e-10 * sc
+        assert np.allclose(cached['dy'][:nsp], plain['dy'][:nsp], rtol=1e-9, atol=1e-10 * np.abs(plain['dy'][:nsp]).max())
+        # another pressure: not served from the cache
+        h1 = pyjacob.cache_hits
+        jac2 = np.zeros(nsp * nsp)
+        pyjacob.py_eval_jacobian(0.0, 2.0 * P, y, jac2)
+        assert pyjacob.cache_hits == h1 and not np.array_equal(jac2, cached['jac'])
+        # intermediate arrays that are not the cached state's: evaluated, not served
+        conc2 = cached['conc'] * 1.01
+        fwd2, rev2 = np.zeros(ev.n_fwd), np.zeros(ev.n_rev)
+        pyjacob.py_eval_rxn_rates(y[0], 2.0 * P, conc2, fwd2, rev2)
+        assert pyjacob.cache_hits == h1 and not np.allclose(fwd2, cached['fwd'])
