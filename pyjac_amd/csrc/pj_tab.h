@@ -26,8 +26,8 @@ namespace pj {
 typedef const PJT_CONST double* tab_cd;
 typedef const PJT_CONST int32_t* tab_ci;
 struct TabTabs {
-    tab_ci ri, eff_sp, gen_sp, I;
-    tab_cd rd, sp, kcg, plog, sri, cheb, eff_am1, gen_nu;
+    tab_ci gen_sp, I;
+    tab_cd sp, plog, sri, cheb, gen_nu;
 };
 
 struct TabDev {
@@ -42,10 +42,8 @@ struct TabDev {
 PJ_DEV TabTabs tab_tabs(const DevMech& M, const TabDev& P)
 {
     TabTabs X;
-    X.ri = (tab_ci)M.ri; X.eff_sp = (tab_ci)M.eff_sp; X.gen_sp = (tab_ci)M.gen_sp; X.I = (tab_ci)P.I;
-    (void)P;
-    X.rd = (tab_cd)M.rd; X.sp = (tab_cd)M.sp; X.kcg = (tab_cd)M.kcg; X.plog = (tab_cd)M.plog; X.sri = (tab_cd)M.sri;
-    X.cheb = (tab_cd)M.cheb; X.eff_am1 = (tab_cd)M.eff_am1; X.gen_nu = (tab_cd)M.gen_nu;
+    X.gen_sp = (tab_ci)M.gen_sp; X.I = (tab_ci)P.I;
+    X.sp = (tab_cd)M.sp; X.plog = (tab_cd)M.plog; X.sri = (tab_cd)M.sri; X.cheb = (tab_cd)M.cheb; X.gen_nu = (tab_cd)M.gen_nu;
     return X;
 }
 
