@@ -117,6 +117,16 @@ int pj_mech_has_spec(const pj_mech* m);
  * and, if it transposes through LDS (pj_lane.hip), for AoS ones (otherwise AoS output is the
  * cooperative kernel's native layout and goes there); 2: use it for every layout */
 int pj_mech_use_spec(pj_mech* m, int on);
+/* Launch settings of an attached pj_rblk.hip library, per handle (every handle owns its hand-over arrays, internal
+ * streams and staging blocks: two handles of one mechanism run independently).  A negative value leaves a setting
+ * unchanged.  streams: internal streams the chunks of a batch are dealt to (0: the build's default, 1: everything
+ * on the caller's stream, at most 8); chunk_states: states per chunk (< 256: the build's default); split_tail:
+ * batches whose last round of workgroups is partially filled run as two unequal parts on two streams (default 1);
+ * aos_direct: AoS Jacobians by strided lane stores instead of SoA chunks + LDS-tiled transpose (default 0).  The
+ * defaults come from the environment, read once when the library is attached (PJ_RBLK_STREAMS, PJ_RBLK_CHUNK,
+ * PJ_RBLK_SPLIT, PJ_RBLK_AOS_DIRECT).  PJ_EINVAL without such a library.  (pyJac's counterpart: none -- its batch
+ * path owns one set of module-level device buffers, pyjacob.cu:65-80) */
+int pj_mech_set_spec_launch(pj_mech* m, int streams, long chunk_states, int split_tail, int aos_direct);
 
 /* ---- device-resident batch evaluation (pointers are device pointers on the
  *      current HIP device; stream is a hipStream_t or NULL) ---- */

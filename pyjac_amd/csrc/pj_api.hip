@@ -281,6 +281,34 @@ struct pj_mech {
     int (*spec_rates)(long, const double*, const double*, long, long, double*, double*, double*, double*, double*,
                       double*, void*) = nullptr;   // rate outputs (pj_lane.hip), optional
     bool spec_aos = false;       // the attached library writes AoS Jacobians efficiently
+    // libraries that own device state (pj_rblk.hip: hand-over arrays, internal streams, staging blocks) keep it in a
+    // context; this handle's own one, so that two handles of one mechanism never share scratch
+    void* spec_ctx = nullptr;
+    void (*spec_ctx_destroy)(void*) = nullptr;
+    int (*spec_ctx_config)(void*, int, long, int, int) = nullptr;
+    int (*spec_jac_c)(void*, long, const double*, const double*, long, long, double*, long, long, int, void*) = nullptr;
+    int (*spec_jv_c)(void*, long, const double*, const double*, long, long, const double*, long, long, double*, long, long,
+                     int, void*) = nullptr;
+    int (*spec_rates_c)(void*, long, const double*, const double*, long, long, double*, double*, double*, double*, double*,
+                        double*, void*) = nullptr;
+    int do_spec_jac(long n, const double* p, const double* y, long y_si, long y_ss, double* j, long j_si, long j_ss, int sl,
+                    void* st) const
+    {
+        return spec_jac_c ? spec_jac_c(spec_ctx, n, p, y, y_si, y_ss, j, j_si, j_ss, sl, st)
+                          : spec_jac(n, p, y, y_si, y_ss, j, j_si, j_ss, sl, st);
+    }
+    int do_spec_jv(long n, const double* p, const double* y, long y_si, long y_ss, const double* v, long v_si, long v_ss,
+                   double* w, long w_si, long w_ss, int sl, void* st) const
+    {
+        return spec_jv_c ? spec_jv_c(spec_ctx, n, p, y, y_si, y_ss, v, v_si, v_ss, w, w_si, w_ss, sl, st)
+                         : spec_jv(n, p, y, y_si, y_ss, v, v_si, v_ss, w, w_si, w_ss, sl, st);
+    }
+    int do_spec_rates(long n, const double* p, const double* y, long y_si, long y_ss, double* c, double* f, double* r,
+                      double* pm, double* sr, double* dy, void* st) const
+    {
+        return spec_rates_c ? spec_rates_c(spec_ctx, n, p, y, y_si, y_ss, c, f, r, pm, sr, dy, st)
+                            : spec_rates(n, p, y, y_si, y_ss, c, f, r, pm, sr, dy, st);
+    }
     double* jv_tmp = nullptr;    // Jacobian chunk of the unfused J*v path
     size_t jv_tmp_doubles = 0;
     int use_spec = 1;          // 0: never, 1: SoA Jacobians (default), 2: every layout
@@ -584,6 +612,16 @@ int pj_mech_load(const char* path, pj_mech** out)
     }
 }
 
+static void detach_spec(pj_mech* m)
+{
+    if (m->spec_ctx && m->spec_ctx_destroy) m->spec_ctx_destroy(m->spec_ctx);      // synchronises, frees its device state
+    m->spec_ctx = nullptr; m->spec_ctx_destroy = nullptr; m->spec_ctx_config = nullptr;
+    m->spec_jac_c = nullptr; m->spec_jv_c = nullptr; m->spec_rates_c = nullptr;
+    m->spec_jac = nullptr; m->spec_jv = nullptr; m->spec_rates = nullptr;
+    if (m->spec_lib) dlclose(m->spec_lib);
+    m->spec_lib = nullptr;
+}
+
 void pj_mech_destroy(pj_mech* m)
 {
     if (m && m->jv_tmp) { (void)hipFree(m->jv_tmp); m->jv_tmp = nullptr; }
@@ -599,7 +637,7 @@ void pj_mech_destroy(pj_mech* m)
         if (m->d_bad) (void)hipFree(m->d_bad);
         m->ws.release(); m->ws1.release();
     }
-    if (m->spec_lib) dlclose(m->spec_lib);
+    detach_spec(m);
     delete m;
 }
 
@@ -704,11 +742,24 @@ int pj_mech_attach_spec(pj_mech* m, const char* library_path)
         dlclose(lib);
         return fail(PJ_EINVAL, "specialisation was built for a different mechanism (hash mismatch)");
     }
-    if (m->spec_lib) dlclose(m->spec_lib);
+    detach_spec(m);
     m->spec_lib = lib;
     m->spec_jac = jac;
     m->spec_jv = (decltype(m->spec_jv))dlsym(lib, "pj_spec_jacvec");
     m->spec_rates = (decltype(m->spec_rates))dlsym(lib, "pj_spec_rates");
+    // a library with device state of its own (pj_rblk.hip) gives this handle a context of its own
+    auto ctx_create = (void* (*)(void))dlsym(lib, "pj_spec_ctx_create");
+    m->spec_ctx_destroy = (decltype(m->spec_ctx_destroy))dlsym(lib, "pj_spec_ctx_destroy");
+    m->spec_jac_c = (decltype(m->spec_jac_c))dlsym(lib, "pj_spec_jacobian_ctx");
+    if (ctx_create && m->spec_ctx_destroy && m->spec_jac_c) {
+        m->spec_ctx = ctx_create();
+        if (!m->spec_ctx) { detach_spec(m); return fail(PJ_ENOMEM, "specialisation context"); }
+        m->spec_ctx_config = (decltype(m->spec_ctx_config))dlsym(lib, "pj_spec_ctx_config");
+        m->spec_jv_c = (decltype(m->spec_jv_c))dlsym(lib, "pj_spec_jacvec_ctx");
+        m->spec_rates_c = (decltype(m->spec_rates_c))dlsym(lib, "pj_spec_rates_ctx");
+    } else {
+        m->spec_ctx_destroy = nullptr; m->spec_jac_c = nullptr;
+    }
     auto fast_aos = (int (*)(void))dlsym(lib, "pj_spec_fast_aos");
     m->spec_aos = fast_aos && fast_aos();
     return PJ_OK;
@@ -719,6 +770,15 @@ int pj_mech_use_spec(pj_mech* m, int on)
 {
     if (on < 0 || on > 2) return fail(PJ_EINVAL, "use_spec: 0, 1 or 2");
     m->use_spec = on;
+    return PJ_OK;
+}
+
+int pj_mech_set_spec_launch(pj_mech* m, int streams, long chunk_states, int split_tail, int aos_direct)
+{
+    if (!m) return fail(PJ_EINVAL, "bad argument");
+    if (!m->spec_ctx_config) return fail(PJ_EINVAL, "the attached library has no launch settings (none attached, or pj_lane)");
+    if (m->spec_ctx_config(m->spec_ctx, streams, chunk_states, split_tail, aos_direct))
+        return fail(PJ_EINVAL, "spec launch settings: at most 8 internal streams");
     return PJ_OK;
 }
 
@@ -762,7 +822,7 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
                         (m->use_spec == 1 && (jac_layout == PJ_LAYOUT_SOA || m->spec_aos)))) {
         int rc = ensure_device(m);
         if (rc) return rc;
-        if (m->spec_jac(n, d_pres, d_y, B.y_si, B.y_ss, d_jac, B.j_si, B.j_ss, m->M.sum_last, stream))
+        if (m->do_spec_jac(n, d_pres, d_y, B.y_si, B.y_ss, d_jac, B.j_si, B.j_ss, m->M.sum_last, stream))
             return fail(PJ_EHIP, "specialised kernel launch failed");
         return PJ_OK;
     }
@@ -784,7 +844,7 @@ int pj_eval_jacobian_vec_dev(pj_mech* m, long n, const double* d_pres, const dou
     int rc = ensure_device(m);
     if (rc) return rc;
     if (m->spec_jv && m->use_spec) {
-        if (m->spec_jv(n, d_pres, d_y, y_si, y_ss, d_v, v_si, v_ss, d_w, v_si, v_ss, m->M.sum_last, stream))
+        if (m->do_spec_jv(n, d_pres, d_y, y_si, y_ss, d_v, v_si, v_ss, d_w, v_si, v_ss, m->M.sum_last, stream))
             return fail(PJ_EHIP, "specialised kernel launch failed");
         return PJ_OK;
     }
@@ -802,7 +862,7 @@ int pj_eval_jacobian_vec_dev(pj_mech* m, long n, const double* d_pres, const dou
     for (long s0 = 0; s0 < n; s0 += chunk) {
         const long c = s0 + chunk < n ? chunk : n - s0;
         if (m->spec_jac && m->use_spec) {
-            if (m->spec_jac(c, d_pres + s0, d_y + s0 * y_ss, y_si, y_ss, m->jv_tmp, c, 1, m->M.sum_last, stream))
+            if (m->do_spec_jac(c, d_pres + s0, d_y + s0 * y_ss, y_si, y_ss, m->jv_tmp, c, 1, m->M.sum_last, stream))
                 return fail(PJ_EHIP, "specialised kernel launch failed");
         } else {
             Batch B;
@@ -836,7 +896,7 @@ int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_
     if (m->spec_rates && m->use_spec) {
         int rc = ensure_device(m);
         if (rc) return rc;
-        if (m->spec_rates(n, d_pres, d_y, B.y_si, B.y_ss, d_conc, d_fwd, d_rev, d_pres_mod, d_spec_rates, d_dy, stream))
+        if (m->do_spec_rates(n, d_pres, d_y, B.y_si, B.y_ss, d_conc, d_fwd, d_rev, d_pres_mod, d_spec_rates, d_dy, stream))
             return fail(PJ_EHIP, "specialised kernel launch failed");
         return PJ_OK;
     }
@@ -948,13 +1008,13 @@ static int run_ws(pj_mech* m, Workspace& w, int num, const double* pres, const d
     const bool spec = jac && m->spec_jac && m->use_spec;
     int rc = PJ_OK;
     if (!aux && m->spec_rates && m->use_spec && (spec || !jac)) {
-        if (m->spec_rates(num, w.pres, w.y, B.y_si, B.y_ss, w.conc, w.fwd, w.rev, w.pm, w.sr, w.dy, nullptr))
+        if (m->do_spec_rates(num, w.pres, w.y, B.y_si, B.y_ss, w.conc, w.fwd, w.rev, w.pm, w.sr, w.dy, nullptr))
             return fail(PJ_EHIP, "specialised kernel launch failed");
     } else {
         rc = launch(m, B, (jac && !spec) ? MODE_JAC : 0, nullptr, nullptr, aux ? w.aux : nullptr, 0);
     }
     if (rc) return rc;
-    if (spec && m->spec_jac(num, w.pres, w.y, B.y_si, B.y_ss, w.jac, B.j_si, B.j_ss, m->M.sum_last, nullptr))
+    if (spec && m->do_spec_jac(num, w.pres, w.y, B.y_si, B.y_ss, w.jac, B.j_si, B.j_ss, m->M.sum_last, nullptr))
         return fail(PJ_EHIP, "specialised kernel launch failed");
     HIPCHK(hipDeviceSynchronize());
     if (conc) HIPCHK(hipMemcpy(conc, w.conc, 8 * n * nsp, hipMemcpyDeviceToHost));

@@ -46,6 +46,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
+#include <new>
 #include <type_traits>
 #include <utility>
 
@@ -1403,22 +1404,71 @@ struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_FULL ? 8 : 7, launch_rate); } } re
 constexpr int MAXPARTS = 256;
 pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_rows_gen[MAXPARTS], g_rows_jv[MAXPARTS], g_timing[MAXPARTS];
 pjq_launch_fn g_rate_lean[MAXPARTS], g_rate_full[MAXPARTS];
-double* g_rate_scr = nullptr;           // omega_k between the rate kernels of a library that has several
-long g_rate_scr_ld = 0;
-double* g_rate_dummy = nullptr;         // one row that takes the per-reaction outputs the caller does not want
-long g_rate_dummy_ld = 0;
-// The hand-over arrays, internal streams and events are per library, i.e. per process: host threads enqueue one
-// batch at a time (two Evaluators of one mechanism, or two threads, serialise here instead of racing; on the
-// device a batch on another stream is ordered behind the previous one by enter_batch's event)
-std::mutex g_batch_mutex;
 constexpr int MAXSTREAMS = 8;
-double* g_scr[MAXSTREAMS] = {};
-long g_scr_ld[MAXSTREAMS] = {};
-hipStream_t g_streams[MAXSTREAMS] = {};
-hipEvent_t g_events[MAXSTREAMS + 1];
-int g_device = -1;
-hipEvent_t g_last_event = nullptr;      // recorded after every batch, on the caller's stream
-void* g_last_stream = nullptr;
+// Everything a batch needs beyond the caller's arrays belongs to a CONTEXT: hand-over arrays, internal streams and
+// events, the AoS staging block, the rate kernels' scratch, and the launch settings.  pj_api.hip creates one per
+// mechanism handle (pj_spec_ctx_create at attach time), so two handles of one mechanism -- two Evaluators, two host
+// threads -- run independently; callers of the plain entry points (tests, tools) share the library's default context.
+// A context serves one batch at a time (its mutex serialises host threads; on the device a batch on another stream
+// is ordered behind the previous one by enter_batch's event) and belongs to the device of its first batch.
+struct Ctx {
+    std::mutex batch_mutex;
+    std::mutex aos_mutex;                // the staging block of the AoS path (taken before batch_mutex)
+    double* scr[MAXSTREAMS] = {};
+    long scr_ld[MAXSTREAMS] = {};
+    hipStream_t streams[MAXSTREAMS] = {};
+    hipEvent_t events[MAXSTREAMS + 1] = {};
+    bool have_streams = false;
+    int device = -1;
+    int cus = 0;
+    hipEvent_t last_event = nullptr;     // recorded after every batch, on the caller's stream
+    void* last_stream = nullptr;
+    double* aos_tmp = nullptr;
+    long aos_tmp_states = 0;
+    double* rate_scr = nullptr;          // omega_k between the rate kernels of a library that has several
+    long rate_scr_ld = 0;
+    double* rate_dummy = nullptr;        // one row that takes the per-reaction outputs the caller does not want
+    long rate_dummy_ld = 0;
+    // launch settings: the environment is read ONCE, when the context is created (PJ_RBLK_STREAMS, PJ_RBLK_CHUNK,
+    // PJ_RBLK_SPLIT, PJ_RBLK_AOS_DIRECT); pj_spec_ctx_config overrides them
+    int cfg_streams = 0;                 // 0: the build's default (PJQ_STREAMS)
+    long cfg_chunk = 0;                  // < 256: the build's default (PJQ_CHUNK)
+    int cfg_split = 1;                   // two unequal parts on two streams for a partially filled last round
+    int cfg_aos_direct = 0;              // AoS Jacobians by strided lane stores instead of SoA chunks + transpose
+    Ctx()
+    {
+        if (const char* e = getenv("PJ_RBLK_STREAMS")) cfg_streams = atoi(e);
+        if (const char* e = getenv("PJ_RBLK_CHUNK")) cfg_chunk = atol(e);
+        if (const char* e = getenv("PJ_RBLK_SPLIT")) cfg_split = atoi(e) != 0;
+        cfg_aos_direct = getenv("PJ_RBLK_AOS_DIRECT") != nullptr;
+    }
+    void release()
+    {
+#ifndef PJR_HOST_EMU
+        if (device >= 0) {
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (cur != device) (void)hipSetDevice(device);
+            (void)hipDeviceSynchronize();
+            for (auto& p : scr) if (p) { (void)hipFree(p); p = nullptr; }
+            if (aos_tmp) (void)hipFree(aos_tmp);
+            if (rate_scr) (void)hipFree(rate_scr);
+            if (rate_dummy) (void)hipFree(rate_dummy);
+            if (have_streams) {
+                for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
+                for (auto& e : events) if (e) (void)hipEventDestroy(e);
+            }
+            if (last_event) (void)hipEventDestroy(last_event);
+            if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+        }
+#endif
+    }
+};
+Ctx& default_ctx()
+{
+    static Ctx* c = new Ctx();           // never destroyed: the library stays resident (RTLD_NODELETE)
+    return *c;
+}
 #endif
 
 }  // namespace
@@ -1449,96 +1499,100 @@ int pj_spec_kind(void) { return 4; }   // 1: pj_lane.hip, 4: pj_rblk.hip (2, 3: 
 long pj_spec_scratch_doubles_per_state(void) { return NSLOTS; }
 
 // layouts as in include/pyjac_amd.h: element (i, s) at base[i*si + s*ss].  One batch at a time per
-// library (the hand-over arrays are shared): calls on different streams must not overlap.
+// context (its hand-over arrays are shared by its batches): calls on different streams are ordered.
 //
 // The batch runs in chunks, chunk c on internal stream c % S with its own hand-over array: all
 // wavefronts of one launch move through "compute a block / store its rows" in step, so a single
 // stream alternates between a busy memory system with idle SIMDs and the reverse; kernels of
 // different chunks are out of step with each other.  The internal streams are forked from and joined
 // to the caller's stream with events: the call is asynchronous and ordered like one kernel launch on
-// `stream`.  PJ_RBLK_STREAMS=1: everything on the caller's stream.
-// The hand-over arrays (and the AoS staging block) are per library instance, i.e. per process: one device per
-// process (a second device is refused), and a batch on another stream is ordered behind the previous batch
-// with an event instead of racing on them.
-static int enter_batch(void* stream)
+// `stream`.  streams = 1: everything on the caller's stream.
+static int enter_batch(Ctx& C, void* stream)
 {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return -3;
-    if (g_device < 0) g_device = dev;
-    else if (dev != g_device) return -6;
-    if (!g_last_event) {
-        if (hipEventCreateWithFlags(&g_last_event, hipEventDisableTiming) != hipSuccess) return -3;
-    } else if (g_last_stream != stream) {
-        (void)hipStreamWaitEvent((hipStream_t)stream, g_last_event, 0);
+    if (C.device < 0) C.device = dev;
+    else if (dev != C.device) return -6;
+    if (!C.last_event) {
+        if (hipEventCreateWithFlags(&C.last_event, hipEventDisableTiming) != hipSuccess) return -3;
+    } else if (C.last_stream != stream) {
+        (void)hipStreamWaitEvent((hipStream_t)stream, C.last_event, 0);
     }
     return 0;
 }
-static void leave_batch(void* stream)
+static void leave_batch(Ctx& C, void* stream)
 {
-    (void)hipEventRecord(g_last_event, (hipStream_t)stream);
-    g_last_stream = stream;
+    (void)hipEventRecord(C.last_event, (hipStream_t)stream);
+    C.last_stream = stream;
 }
 
-static int run_batch(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac, long j_si,
+// a scratch array that only grows (geometrically: a caller that sweeps batch sizes upwards does not pay a
+// device synchronisation + reallocation per call)
+static int grow(double*& p, long& have, long want, size_t doubles_per_unit)
+{
+    if (have >= want) return 0;
+    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; }
+    long cap = want;
+    if (have > 0 && cap < have + have / 2) cap = have + have / 2;
+    have = 0;
+    if (hipMalloc((void**)&p, sizeof(double) * doubles_per_unit * (size_t)cap) != hipSuccess) {
+        if (cap == want || hipMalloc((void**)&p, sizeof(double) * doubles_per_unit * (size_t)want) != hipSuccess) return -4;
+        cap = want;
+    }
+    have = cap;
+    return 0;
+}
+
+static int run_batch(Ctx& C, long n, const double* pres, const double* y, long y_si, long y_ss, double* jac, long j_si,
                      long j_ss, const double* v, long v_si, long v_ss, double* w, long w_si, long w_ss, int sum_last,
                      void* stream)
 {
     if (n <= 0) return 0;
     const bool jv = w != nullptr;
     if (jv && !g_rows_jv[0]) return -5;
-    std::lock_guard<std::mutex> lock(g_batch_mutex);
-    if (const int rc = enter_batch(stream)) return rc;
-    int nstreams = PJQ_STREAMS;
-    long chunk_env = 0;
-    if (const char* e = getenv("PJ_RBLK_STREAMS")) nstreams = atoi(e);
-    if (nstreams < 1) nstreams = 1;
+    std::lock_guard<std::mutex> lock(C.batch_mutex);
+    if (const int rc = enter_batch(C, stream)) return rc;
+    int nstreams = C.cfg_streams > 0 ? C.cfg_streams : PJQ_STREAMS;
     if (nstreams > MAXSTREAMS) nstreams = MAXSTREAMS;
-    if (const char* c = getenv("PJ_RBLK_CHUNK")) chunk_env = atol(c);
+    const long chunk_cfg = C.cfg_chunk;
     // chunks: a multiple of the tile, at least 2 per stream when the batch fills the device several times
-    long chunk = chunk_env >= 256 ? chunk_env : PJQ_CHUNK;
+    long chunk = chunk_cfg >= 256 ? chunk_cfg : PJQ_CHUNK;
     // Every kernel of a step ends with a partially filled round of workgroups (one workgroup per CU is
     // resident; GRI-shaped 1e6 states = 15.26 rounds, USC-shaped 2e5 = 6.1), and kernels of one stream
     // do not overlap: 16 and 7 rounds are paid, per kernel.  Two unequal parts on two streams drift
     // apart, so one part's kernel fills the CUs the other part's last round leaves idle (measured:
-    // 7.66 -> 7.37 ms and 10.56 -> 9.40 ms, tools/r02_tail.sh).  PJ_RBLK_SPLIT=0 switches it off;
-    // explicit PJ_RBLK_STREAMS / PJ_RBLK_CHUNK take precedence.
-    if (!getenv("PJ_RBLK_STREAMS") && chunk_env < 256 && PJQ_STREAMS == 1 && PJQ_SPLIT_TAIL) {
-        const char* e = getenv("PJ_RBLK_SPLIT");
-        if (!e || atoi(e) != 0) {
-            static int cus = 0;
-            if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device) != hipSuccess) cus = 256;
-            const long lds_wg = (long)NSP * PJQ_BLOCK * 8 + 4096;
-            long per_cu = 256 / (PJQ_BLOCK * PJQ_HALVES);           // one wavefront per SIMD (512 registers)
-            if (per_cu > (160L << 10) / lds_wg) per_cu = (160L << 10) / lds_wg;
-            if (per_cu < 1) per_cu = 1;
-            const long slots = (long)cus * per_cu, wgs = (n + PJQ_BLOCK - 1) / PJQ_BLOCK;
-            const long rounds = (wgs + slots - 1) / slots;
-            if (n <= PJQ_CHUNK && wgs >= 2 * slots && (double)(rounds * slots - wgs) > 0.02 * (double)(rounds * slots)) {
-                chunk = (long)(0.525 * (double)n);
-                nstreams = 2;
-            }
+    // 7.66 -> 7.37 ms and 10.56 -> 9.40 ms, tools/r02_tail.sh).  split = 0 switches it off;
+    // explicit streams / chunk settings take precedence.
+    if (C.cfg_streams <= 0 && chunk_cfg < 256 && PJQ_STREAMS == 1 && PJQ_SPLIT_TAIL && C.cfg_split) {
+        if (!C.cus && hipDeviceGetAttribute(&C.cus, hipDeviceAttributeMultiprocessorCount, C.device) != hipSuccess) C.cus = 256;
+        const long lds_wg = (long)NSP * PJQ_BLOCK * 8 + 4096;
+        long per_cu = 256 / (PJQ_BLOCK * PJQ_HALVES);           // one wavefront per SIMD (512 registers)
+        if (per_cu > (160L << 10) / lds_wg) per_cu = (160L << 10) / lds_wg;
+        if (per_cu < 1) per_cu = 1;
+        const long slots = (long)C.cus * per_cu, wgs = (n + PJQ_BLOCK - 1) / PJQ_BLOCK;
+        const long rounds = (wgs + slots - 1) / slots;
+        if (n <= PJQ_CHUNK && wgs >= 2 * slots && (double)(rounds * slots - wgs) > 0.02 * (double)(rounds * slots)) {
+            chunk = (long)(0.525 * (double)n);
+            nstreams = 2;
         }
     }
     chunk = (chunk + PJQ_TILE - 1) / PJQ_TILE * PJQ_TILE;
     if (chunk > n) chunk = (n + PJQ_TILE - 1) / PJQ_TILE * PJQ_TILE;
     const long nchunks = (n + chunk - 1) / chunk;
     const int S = (int)(nchunks < nstreams ? nchunks : nstreams);
-    for (int b = 0; b < S; ++b) {
-        if (g_scr_ld[b] >= chunk) continue;
-        if (g_scr[b]) { (void)hipDeviceSynchronize(); (void)hipFree(g_scr[b]); g_scr[b] = nullptr; g_scr_ld[b] = 0; }
-        if (hipMalloc((void**)&g_scr[b], sizeof(double) * (size_t)NSLOTS * (size_t)chunk) != hipSuccess) return -4;
-        g_scr_ld[b] = chunk;
-    }
+    for (int b = 0; b < S; ++b)
+        if (const int rc = grow(C.scr[b], C.scr_ld[b], chunk, (size_t)NSLOTS)) return rc;
     hipStream_t user = (hipStream_t)stream;
     if (S > 1) {
-        if (!g_streams[0]) {
-            for (auto& st : g_streams)
+        if (!C.have_streams) {
+            for (auto& st : C.streams)
                 if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -3;
-            for (auto& e : g_events)
+            for (auto& e : C.events)
                 if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -3;
+            C.have_streams = true;
         }
-        (void)hipEventRecord(g_events[MAXSTREAMS], user);
-        for (int b = 0; b < S; ++b) (void)hipStreamWaitEvent(g_streams[b], g_events[MAXSTREAMS], 0);
+        (void)hipEventRecord(C.events[MAXSTREAMS], user);
+        for (int b = 0; b < S; ++b) (void)hipStreamWaitEvent(C.streams[b], C.events[MAXSTREAMS], 0);
     }
     // the pair-store kernels need lane-contiguous (SoA) output, whole workgroups and column offsets
     // that fit 32 bits; everything else goes to the general kernels of the library
@@ -1548,8 +1602,8 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
     for (long s0 = 0; s0 < n; s0 += chunk, ++c) {
         const long m = s0 + chunk < n ? chunk : n - s0;
         const int b = (int)(c % S);
-        void* st = S > 1 ? (void*)g_streams[b] : stream;
-        PjqArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jv ? nullptr : jac + s0 * j_ss, j_si, j_ss, g_scr[b], sum_last,
+        void* st = S > 1 ? (void*)C.streams[b] : stream;
+        PjqArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jv ? nullptr : jac + s0 * j_ss, j_si, j_ss, C.scr[b], sum_last,
                   jv ? v + s0 * v_ss : nullptr, v_si, v_ss, jv ? w + s0 * w_ss : nullptr, w_si, w_ss};
         const bool fast = fast_ok && m >= PJQ_BLOCK;
         if (!jv && !fast && !have_gen) return -5;
@@ -1559,10 +1613,10 @@ static int run_batch(long n, const double* pres, const double* y, long y_si, lon
     }
     if (S > 1)
         for (int b = 0; b < S; ++b) {
-            (void)hipEventRecord(g_events[b], g_streams[b]);
-            (void)hipStreamWaitEvent(user, g_events[b], 0);
+            (void)hipEventRecord(C.events[b], C.streams[b]);
+            (void)hipStreamWaitEvent(user, C.events[b], 0);
         }
-    leave_batch(stream);
+    leave_batch(C, stream);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -1591,81 +1645,103 @@ __global__ void __launch_bounds__(256) k_soa2aos(const double* __restrict__ src,
     }
 }
 
-double* g_aos_tmp = nullptr;
-long g_aos_tmp_states = 0;
-std::mutex g_aos_mutex;                 // the staging block of the AoS path (taken before g_batch_mutex)
-
 int pj_spec_fast_aos(void) { return 1; }   // AoS Jacobians: SoA chunks + transpose, not strided lane stores
 
-int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
-                     long j_si, long j_ss, int sum_last, void* stream)
+// contexts (see struct Ctx): created by pj_api.hip per mechanism handle; a null ctx means the library's default one
+void* pj_spec_ctx_create(void) { return new (std::nothrow) Ctx(); }
+void pj_spec_ctx_destroy(void* ctx)
 {
+    Ctx* C = (Ctx*)ctx;
+    if (!C) return;
+    { std::lock_guard<std::mutex> l1(C->aos_mutex); std::lock_guard<std::mutex> l2(C->batch_mutex); C->release(); }
+    delete C;
+}
+// launch settings of a context; a negative value leaves a setting as it is.  streams: 0 = the build's default,
+// chunk: states per chunk (< 256: the build's default), split: two unequal parts on two streams for batches whose
+// last round of workgroups is partially filled, aos_direct: AoS Jacobians by strided lane stores
+int pj_spec_ctx_config(void* ctx, int streams, long chunk, int split, int aos_direct)
+{
+    Ctx& C = ctx ? *(Ctx*)ctx : default_ctx();
+    std::lock_guard<std::mutex> lock(C.batch_mutex);
+    if (streams > MAXSTREAMS) return -1;
+    if (streams >= 0) C.cfg_streams = streams;
+    if (chunk >= 0) C.cfg_chunk = chunk;
+    if (split >= 0) C.cfg_split = split != 0;
+    if (aos_direct >= 0) C.cfg_aos_direct = aos_direct != 0;
+    return 0;
+}
+
+int pj_spec_jacobian_ctx(void* ctx, long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
+                         long j_si, long j_ss, int sum_last, void* stream)
+{
+    Ctx& C = ctx ? *(Ctx*)ctx : default_ctx();
 #ifndef PJR_HOST_EMU
     constexpr long NE = (long)NSP * NSP;
-    if (n >= PJQ_BLOCK && j_si == 1 && j_ss == NE && g_rows[0] && !getenv("PJ_RBLK_AOS_DIRECT")) {
-        std::lock_guard<std::mutex> lock(g_aos_mutex);
+    if (n >= PJQ_BLOCK && j_si == 1 && j_ss == NE && g_rows[0] && !C.cfg_aos_direct) {
+        std::lock_guard<std::mutex> lock(C.aos_mutex);
         // chunks that fill the device once (one workgroup per CU): 256 workgroups
         long chunk = 256L * PJQ_BLOCK;
         if (chunk > n) chunk = n;
-        if (g_aos_tmp_states < chunk) {
-            if (g_aos_tmp) { (void)hipDeviceSynchronize(); (void)hipFree(g_aos_tmp); g_aos_tmp = nullptr; g_aos_tmp_states = 0; }
-            if (hipMalloc((void**)&g_aos_tmp, sizeof(double) * (size_t)NE * (size_t)chunk) != hipSuccess) return -4;
-            g_aos_tmp_states = chunk;
-        }
+        if (const int rc = grow(C.aos_tmp, C.aos_tmp_states, chunk, (size_t)NE)) return rc;
         for (long s0 = 0; s0 < n; s0 += chunk) {
             long m = s0 + chunk < n ? chunk : n - s0;
             long sb = s0;
             if (m < PJQ_BLOCK) { sb = n - PJQ_BLOCK; m = PJQ_BLOCK; }      // short tail: redo a whole workgroup's worth
-            const int rc = run_batch(m, pres + sb, y + sb * y_ss, y_si, y_ss, g_aos_tmp, m, 1, nullptr, 0, 0, nullptr, 0, 0,
+            const int rc = run_batch(C, m, pres + sb, y + sb * y_ss, y_si, y_ss, C.aos_tmp, m, 1, nullptr, 0, 0, nullptr, 0, 0,
                                      sum_last, stream);
             if (rc) return rc;
             hipLaunchKernelGGL(k_soa2aos, dim3((unsigned)((m + 63) / 64), (unsigned)((NE + 63) / 64)), dim3(256), 0,
-                               (hipStream_t)stream, (const double*)g_aos_tmp, m, jac + sb * NE);
+                               (hipStream_t)stream, (const double*)C.aos_tmp, m, jac + sb * NE);
         }
-        (void)hipEventRecord(g_last_event, (hipStream_t)stream);      // the staging block is busy until here
+        (void)hipEventRecord(C.last_event, (hipStream_t)stream);      // the staging block is busy until here
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
 #endif
-    return run_batch(n, pres, y, y_si, y_ss, jac, j_si, j_ss, nullptr, 0, 0, nullptr, 0, 0, sum_last, stream);
+    return run_batch(C, n, pres, y, y_si, y_ss, jac, j_si, j_ss, nullptr, 0, 0, nullptr, 0, 0, sum_last, stream);
+}
+int pj_spec_jacobian(long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
+                     long j_si, long j_ss, int sum_last, void* stream)
+{
+    return pj_spec_jacobian_ctx(nullptr, n, pres, y, y_si, y_ss, jac, j_si, j_ss, sum_last, stream);
 }
 
 // w_s = J(Phi_s) v_s per state, the Jacobian consumed in registers (include/pyjac_amd.h:
 // pj_eval_jacobian_vec_dev; pyJac's consumer: sparse_multiplier, create_jacobian.py:3301-3404)
+int pj_spec_jacvec_ctx(void* ctx, long n, const double* pres, const double* y, long y_si, long y_ss, const double* v,
+                       long v_si, long v_ss, double* w, long w_si, long w_ss, int sum_last, void* stream)
+{
+    if (!v || !w) return -1;
+    return run_batch(ctx ? *(Ctx*)ctx : default_ctx(), n, pres, y, y_si, y_ss, nullptr, 0, 0, v, v_si, v_ss, w, w_si, w_ss,
+                     sum_last, stream);
+}
 int pj_spec_jacvec(long n, const double* pres, const double* y, long y_si, long y_ss, const double* v,
                    long v_si, long v_ss, double* w, long w_si, long w_ss, int sum_last, void* stream)
 {
-    if (!v || !w) return -1;
-    return run_batch(n, pres, y, y_si, y_ss, nullptr, 0, 0, v, v_si, v_ss, w, w_si, w_ss, sum_last, stream);
+    return pj_spec_jacvec_ctx(nullptr, n, pres, y, y_si, y_ss, v, v_si, v_ss, w, w_si, w_ss, sum_last, stream);
 }
 
 // Rate outputs of one pass (pyjacob.cu:18-35 k_dydt): conc, fwd, rev, pres_mod, spec_rates, dydt; any pointer
 // may be null; SoA, leading dimension n.  One k_rate kernel per reaction range of the library (one for
 // mechanisms whose K_c rows fit the LDS): omega_k stays in registers, or travels from kernel to kernel through
 // the caller's spec_rates array (a chunk-sized scratch array when the caller does not want it).
-int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y_ss, double* conc, double* fwd,
-                  double* rev, double* pres_mod, double* spec_rates, double* dy, void* stream)
+int pj_spec_rates_ctx(void* ctx, long n, const double* pres, const double* y, long y_si, long y_ss, double* conc,
+                      double* fwd, double* rev, double* pres_mod, double* spec_rates, double* dy, void* stream)
 {
     if (n <= 0) return 0;
+    Ctx& C = ctx ? *(Ctx*)ctx : default_ctx();
     const bool full = fwd || rev || pres_mod;
     pjq_launch_fn* parts = full ? g_rate_full : g_rate_lean;
     if (!parts[0]) return -5;
-    std::lock_guard<std::mutex> lock(g_batch_mutex);
-    if (const int rc = enter_batch(stream)) return rc;
-    if (full && !(fwd && rev && pres_mod) && g_rate_dummy_ld < n) {
-        if (g_rate_dummy) { (void)hipDeviceSynchronize(); (void)hipFree(g_rate_dummy); g_rate_dummy = nullptr; g_rate_dummy_ld = 0; }
-        if (hipMalloc((void**)&g_rate_dummy, sizeof(double) * (size_t)n) != hipSuccess) return -4;
-        g_rate_dummy_ld = n;
-    }
+    std::lock_guard<std::mutex> lock(C.batch_mutex);
+    if (const int rc = enter_batch(C, stream)) return rc;
+    if (full && !(fwd && rev && pres_mod))
+        if (const int rc = grow(C.rate_dummy, C.rate_dummy_ld, n, 1)) return rc;
     int nparts = 0;
     while (nparts < MAXPARTS && parts[nparts]) ++nparts;
     long chunk = n;
     if (nparts > 1 && !spec_rates) {
         chunk = n < 262144 ? n : 262144;
-        if (g_rate_scr_ld < chunk) {
-            if (g_rate_scr) { (void)hipDeviceSynchronize(); (void)hipFree(g_rate_scr); g_rate_scr = nullptr; g_rate_scr_ld = 0; }
-            if (hipMalloc((void**)&g_rate_scr, sizeof(double) * (size_t)NSP * (size_t)chunk) != hipSuccess) return -4;
-            g_rate_scr_ld = chunk;
-        }
+        if (const int rc = grow(C.rate_scr, C.rate_scr_ld, chunk, (size_t)NSP)) return rc;
     }
     for (long s0 = 0; s0 < n; s0 += chunk) {
         PjqArgs A{};
@@ -1673,16 +1749,21 @@ int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y
         A.pres = pres + s0; A.y = y + s0 * y_ss; A.y_si = y_si; A.y_ss = y_ss;
         A.conc = conc ? conc + s0 : nullptr; A.spec_rates = spec_rates ? spec_rates + s0 : nullptr;
         if (full) {
-            A.fwd = fwd ? fwd + s0 : g_rate_dummy + s0; A.fwd_ld = fwd ? n : 0;
-            A.rev = rev ? rev + s0 : g_rate_dummy + s0; A.rev_ld = rev ? n : 0;
-            A.pres_mod = pres_mod ? pres_mod + s0 : g_rate_dummy + s0; A.pm_ld = pres_mod ? n : 0;
+            A.fwd = fwd ? fwd + s0 : C.rate_dummy + s0; A.fwd_ld = fwd ? n : 0;
+            A.rev = rev ? rev + s0 : C.rate_dummy + s0; A.rev_ld = rev ? n : 0;
+            A.pres_mod = pres_mod ? pres_mod + s0 : C.rate_dummy + s0; A.pm_ld = pres_mod ? n : 0;
         }
         A.dy = dy ? dy + s0 : nullptr; A.o_ld = n;
-        A.sr = spec_rates ? spec_rates + s0 : g_rate_scr; A.sr_ld = spec_rates ? n : g_rate_scr_ld;
+        A.sr = spec_rates ? spec_rates + s0 : C.rate_scr; A.sr_ld = spec_rates ? n : C.rate_scr_ld;
         for (int i = 0; i < nparts; ++i) parts[i](A, stream);
     }
-    leave_batch(stream);
+    leave_batch(C, stream);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int pj_spec_rates(long n, const double* pres, const double* y, long y_si, long y_ss, double* conc, double* fwd,
+                  double* rev, double* pres_mod, double* spec_rates, double* dy, void* stream)
+{
+    return pj_spec_rates_ctx(nullptr, n, pres, y, y_si, y_ss, conc, fwd, rev, pres_mod, spec_rates, dy, stream);
 }
 
 }  // extern "C"

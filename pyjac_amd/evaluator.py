@@ -111,6 +111,11 @@ class Evaluator:
         2: attached kernels for every layout."""
         check(_lib.lib().pj_mech_use_spec(self._h, int(on)))
 
+    def set_spec_launch(self, streams: int = -1, chunk_states: int = -1, split_tail: int = -1, aos_direct: int = -1):
+        """Launch settings of the attached row-block library, per evaluator (include/pyjac_amd.h:
+        pj_mech_set_spec_launch); -1 leaves a setting unchanged."""
+        check(_lib.lib().pj_mech_set_spec_launch(self._h, int(streams), int(chunk_states), int(split_tail), int(aos_direct)))
+
     def close(self):
         if getattr(self, '_h', None):
             _lib.lib().pj_mech_destroy(self._h)

@@ -19,6 +19,9 @@ MECHS = {
     'synth_srichb': os.path.join(GOLDEN, 'synth_srichb.inp'),   # SRI falloff (3 / 5 parameters) + Chebyshev
     # fractional stoichiometric coefficients, more than three molecules / species on a reaction side
     'synth_fracnu': os.path.join(GOLDEN, 'synth_fracnu.inp'),
+    # 72 species / 260 reactions, 200 of them irreversible: the second mechanism of the two-lane-group row kernels
+    # (57..120 species), with row kernels that touch only a handful of K_c groups
+    'synth_irrev72': os.path.join(GOLDEN, 'synth_irrev72.inp'),
 }
 
 

@@ -30,6 +30,8 @@ CASES = {
     'synth_mid24': os.path.join(HERE, 'synth_mid24.inp'),
     'synth_srichb': os.path.join(HERE, 'synth_srichb.inp'),     # SRI falloff + Chebyshev rate forms
     'synth_fracnu': os.path.join(HERE, 'synth_fracnu.inp'),     # fractional nu, > 3 molecules per side
+    # synth_mech.generate(72, 260, 6, 10, 4, 200, 2, seed=20240915): mostly irreversible, two lane groups per workgroup
+    'synth_irrev72': os.path.join(HERE, 'synth_irrev72.inp'),
 }
 
 
@@ -43,8 +45,8 @@ def states_for(name, nsp):
         sel = slice(3, None, 17)
         P, T = P[sel], T[sel]
         Y = Y[sel, :9] / Y[sel, :9].sum(axis=1, keepdims=True)
-    elif name in ('gri30_shaped', 'usc2_shaped', 'synth_mid24'):
-        n = {'gri30_shaped': 64, 'usc2_shaped': 16, 'synth_mid24': 40}[name]
+    elif name in ('gri30_shaped', 'usc2_shaped', 'synth_mid24', 'synth_irrev72'):
+        n = {'gri30_shaped': 64, 'usc2_shaped': 16, 'synth_mid24': 40, 'synth_irrev72': 24}[name]
         P, ysoa = synth.dist_b(n, nsp, seed=77, Tlo=600, Thi=2500)
         return P, np.ascontiguousarray(ysoa.T)
     else:

@@ -16,7 +16,7 @@ RTOL = 1e-6
 # row / column scale carry its rounding error: 4e-6 GRI-shaped, 2e-3 USC-shaped; tests/test_conditioning.py), so
 # kernel-vs-reference under the reference tester's metric is bounded by 3x those measured values, and every
 # entry where the two differ by more than RTOL must be explained by the reference's distance from the truth.
-MX_BIG = {'gri30_shaped': 1.2e-5, 'usc2_shaped': 7e-3}
+MX_BIG = {'gri30_shaped': 1.2e-5, 'usc2_shaped': 7e-3, 'synth_irrev72': 5e-3}
 _truth_cache = {}
 
 
@@ -206,12 +206,14 @@ def test_empty_and_single_state(torch_cuda):
     assert torch.isfinite(j).all()
 
 
-@pytest.mark.parametrize('name,n', [('gri30_shaped', 300), ('usc2_shaped', 160), ('usc2_shaped', 60)])
+@pytest.mark.parametrize('name,n', [('gri30_shaped', 300), ('usc2_shaped', 160), ('usc2_shaped', 60), ('synth_irrev72', 300),
+                                    ('synth_irrev72', 60)])
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
 @pytest.mark.parametrize('kernel', ['row_blocks', 'k_tab', 'k_eval'])
 def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda):
     """Configs 3-5 (GRI-3.0-shaped 53 sp / 325 rxn; USC-II-shaped 111 sp / 784 rxn
-    with PLOG; the species order is permuted so N2 ends up last), through the state-per-lane
+    with PLOG; the species order is permuted so N2 ends up last; and a 72-species, mostly irreversible
+    mechanism -- the second one on the two-lane-group kernels, with only 60 K_c groups), through the state-per-lane
     row-block kernels (csrc/pj_rblk.hip, prebuilt by __graft_entry__.build(); n = 300 runs the
     pair-store kernels for SoA output, n = 60 and AoS the general ones) and through the table-driven
     kernel.  The reference tester's thresholded relative error (test.py:1446-1463) is bounded too."""
@@ -401,16 +403,26 @@ def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
     pres, y = synth.dist_b(n, ev.nsp, seed=77)
     d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
     whole = ev.jacobian(d_p, d_y).clone()
-    monkeypatch.setenv('PJ_ROWS_CHUNK', '1024')
-    monkeypatch.setenv('PJ_RBLK_CHUNK', '1024')
+    ev.set_spec_launch(chunk_states=1024)
     parts = ev.jacobian(d_p, d_y).clone()
     assert torch.equal(whole, parts)
     # chunks dealt to three internal streams, last chunk smaller than a workgroup (general kernels)
-    monkeypatch.setenv('PJ_RBLK_STREAMS', '3')
-    monkeypatch.setenv('PJ_RBLK_CHUNK', '512')
+    ev.set_spec_launch(streams=3, chunk_states=512)
     n2 = 512 * 5 + 100
     parts = ev.jacobian(d_p[:n2].contiguous(), d_y[:, :n2].contiguous())
     assert torch.equal(whole[:, :n2], parts)
+    # the settings belong to the handle: a second evaluator of the same mechanism has its own context (scratch,
+    # streams, settings read from the environment when its library was attached) and runs interleaved with this one
+    monkeypatch.setenv('PJ_RBLK_CHUNK', '768')
+    ev2 = _ev('gri30_shaped')
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        other = ev2.jacobian(d_p, d_y)
+    parts = ev.jacobian(d_p[:n2].contiguous(), d_y[:, :n2].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(whole, other) and torch.equal(whole[:, :n2], parts)
+    ev2.close()
 
 
 @pytest.mark.parametrize('name,fused', [('h2o2_n2', True), ('synth_alltypes', True), ('h2o2_n2', False),
@@ -473,7 +485,7 @@ def test_finite_difference_arm(tables, torch_cuda):
     assert np.median(rel) < 1e-6 and np.percentile(rel, 90) < 1e-3
 
 
-@pytest.mark.parametrize('name', ['gri30_shaped', 'usc2_shaped'])
+@pytest.mark.parametrize('name', ['gri30_shaped', 'usc2_shaped', 'synth_irrev72'])
 def test_large_mechanisms_vs_reference_golden(name, golden, tables, torch_cuda):
     """GPU Jacobians of the 53- and 111-species synthetic mechanisms against vectors
     produced by pyJac's own generated C (tests/golden/make_golden.py)."""
@@ -556,7 +568,7 @@ def test_rblk_kernels_all_reaction_types(layout, n, tables, torch_cuda):
         assert mx < RTOL and fro < 1e-9, ('rblk vs table-driven', sum_last, mx, fro)
 
 
-@pytest.mark.parametrize('name,n', [('gri30_shaped', 700), ('usc2_shaped', 200)])
+@pytest.mark.parametrize('name,n', [('gri30_shaped', 700), ('usc2_shaped', 200), ('synth_irrev72', 300)])
 def test_large_mechanism_rate_outputs_vs_oracle(name, n, tables, torch_cuda):
     """a4 / a6 on configs 3 and 5: spec_rates and dydt (and conc, fwd, rev, pres_mod) of the
     state-per-lane rate kernels AND of the table-driven kernel against the CPU oracle."""
@@ -621,8 +633,7 @@ def test_full_size_large_mechanism_properties(name, n, tables, torch_cuda, monke
     cs = jac.sum(dim=1).clone()
     del jac, small, sample
     torch.cuda.empty_cache()
-    monkeypatch.setenv('PJ_RBLK_STREAMS', '3')
-    monkeypatch.setenv('PJ_RBLK_CHUNK', '131072')
+    ev.set_spec_launch(streams=3, chunk_states=131072)
     jac2 = ev.jacobian(d_p, d_y)
     assert torch.equal(cs, jac2.sum(dim=1))
 

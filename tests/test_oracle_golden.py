@@ -11,7 +11,7 @@ KEYS = ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')
 
 
 @pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24',
-                                  'synth_srichb', 'synth_fracnu'])
+                                  'synth_srichb', 'synth_fracnu', 'synth_irrev72'])
 def test_oracle_matches_reference_golden(name, golden, tables):
     g = golden(name)
     tab = tables(name)
@@ -41,7 +41,7 @@ def test_oracle_writes_full_jacobian_block(tables):
 
 
 @pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24', 'synth_srichb',
-                                  'synth_fracnu'])
+                                  'synth_fracnu', 'synth_irrev72'])
 def test_oracle_matches_reference_live(name, tables):
     if not Reference.available(name):
         pytest.skip('oracle/_ref not built (no /root/reference here)')

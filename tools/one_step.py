@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Exactly <steps> evaluations of <n> synthetic states (for rocprofv3 passes):
-one_step.py <mech> <n> <steps> [lane|rblk|table] [jac|rates|dydt]"""
+one_step.py <mech> <n> <steps> [lane|rblk|table] [jac|aos|rates|dydt]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -18,6 +18,18 @@ if what == 'jac':
     out = torch.empty((ev.nsp**2, n), dtype=torch.float64, device='cuda')
     for _ in range(steps):
         ev.jacobian(d_p, d_y, out=out)
+elif what == 'aos':
+    # pyJac's per-state C layout (state-major NSP x NSP blocks), forced through the attached library
+    ev.use_spec(2)
+    out = torch.empty((n, ev.nsp**2), dtype=torch.float64, device='cuda')
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev.jacobian(d_p, d_y, out=out, jac_layout=pyjac_amd.LAYOUT_AOS)
+    t0.record()
+    for _ in range(steps):
+        ev.jacobian(d_p, d_y, out=out, jac_layout=pyjac_amd.LAYOUT_AOS)
+    t1.record(); torch.cuda.synchronize()
+    print('aos: %.3f ms per step' % (t0.elapsed_time(t1) / steps))
+    out = out.T
 else:
     import ctypes
     from pyjac_amd import _lib
