@@ -150,6 +150,24 @@ int pj_eval_rates_dev(pj_mech* m, long n, const double* d_pres, const double* d_
  * increment r_j = max(sqrt(eps)|y_j|, r0/ewt_j)); NSP+1 dydt launches.  y must be SoA. */
 int pj_eval_fd_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y,
                             double* d_jac, int jac_layout, void* stream);
+/* ---- batched LU and Newton solves on per-state NSP x NSP blocks (the "batched LU" consumer).
+ * pyJac hands one state's Jacobian to the caller's dense solver (docs/examples.rst:106-170: the per-state
+ * integrator loop); there is no batched form in the reference -- these entry points take the blocks where
+ * pj_eval_jacobian_dev(..., PJ_LAYOUT_AOS) leaves them: state-major, each block column-major
+ * (a[s*NSP*NSP + r + NSP*c], pyJac's per-state C layout).  One wavefront per block, one lane per row: NSP <= 64
+ * (PJ_EUNSUPPORTED beyond).  gamma != 0: the matrix factored is I - gamma * A (the Newton matrix of an implicit
+ * step); gamma == 0: A itself.  Partial pivoting (first row of maximum magnitude, as LAPACK dgetf2); the
+ * result is P A = L U with L unit lower triangular below the diagonal of d_lu, U on and above it, and
+ * d_perm[s*NSP + k] = the row of A that became row k.  A singular block yields non-finite factors (no info
+ * array).  d_lu may alias d_a.  Device pointers, asynchronous on `stream`. */
+int pj_lu_factor_dev(int nsp, long n, const double* d_a, double gamma, double* d_lu, int* d_perm, void* stream);
+/* x_s = A_s^-1 b_s from the factors: d_b, d_x are [n][NSP] (state-major); d_x may alias d_b */
+int pj_lu_solve_dev(int nsp, long n, const double* d_lu, const int* d_perm, const double* d_b, double* d_x, void* stream);
+/* factor and solve in one pass over the blocks: x_s = (I - gamma A_s)^-1 b_s (or A_s^-1 b_s); the factors stay in
+ * registers and are written only if d_lu / d_perm are given (both or neither) */
+int pj_newton_solve_dev(int nsp, long n, const double* d_a, double gamma, const double* d_b, double* d_x, double* d_lu,
+                        int* d_perm, void* stream);
+
 /* Launch the Jacobian kernel `iters` times on `stream` bracketed by HIP events
  * recorded on that stream; *ms_per_launch receives the average. */
 int pj_time_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y,

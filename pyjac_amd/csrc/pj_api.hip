@@ -12,6 +12,7 @@
 #define PJ_DEV __device__ __forceinline__
 #include "pj_kernel.h"
 #include "pj_tab.h"
+#include "pj_lu.h"
 #include "../../include/pyjac_amd.h"
 
 using namespace pj;
@@ -949,6 +950,47 @@ int pj_debug_phase_cycles(pj_mech* m, long n, const double* d_pres, const double
     return launch(m, B, MODE_JAC, nullptr, d_dbg, nullptr, nullptr);
 }
 #endif
+
+// ---- batched LU / Newton solves on per-state blocks (pj_lu.h) ----
+static int lu_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
+}
+static int lu_call(int nsp, long n, const double* a, double gamma, double* lu, int* perm, const double* b, double* x, int mode,
+                   void* stream)
+{
+    if (n < 0 || nsp < 1) return fail(PJ_EINVAL, "bad argument");
+    if (nsp > 64) return fail(PJ_EUNSUPPORTED, "batched LU: one lane per row, at most 64 rows");
+    if (n == 0) return PJ_OK;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(PJ_ENODEV, "no HIP device");
+    if (pj::lu_launch(nsp, n, a, gamma, lu, perm, b, x, mode, lu_cus(), (hipStream_t)stream)) return fail(PJ_EINVAL, "bad argument");
+    return hipGetLastError() == hipSuccess ? PJ_OK : fail(PJ_EHIP, "batched LU launch failed");
+}
+int pj_lu_factor_dev(int nsp, long n, const double* d_a, double gamma, double* d_lu, int* d_perm, void* stream)
+{
+    if (n > 0 && (!d_a || !d_lu || !d_perm)) return fail(PJ_EINVAL, "null device pointer");
+    return lu_call(nsp, n, d_a, gamma, d_lu, d_perm, nullptr, nullptr, pj::LU_FACTOR, stream);
+}
+int pj_lu_solve_dev(int nsp, long n, const double* d_lu, const int* d_perm, const double* d_b, double* d_x, void* stream)
+{
+    if (n > 0 && (!d_lu || !d_perm || !d_b || !d_x)) return fail(PJ_EINVAL, "null device pointer");
+    return lu_call(nsp, n, nullptr, 0.0, const_cast<double*>(d_lu), const_cast<int*>(d_perm), d_b, d_x,
+                   pj::LU_PREFACTORED | pj::LU_SOLVE, stream);
+}
+int pj_newton_solve_dev(int nsp, long n, const double* d_a, double gamma, const double* d_b, double* d_x, double* d_lu,
+                        int* d_perm, void* stream)
+{
+    if (n > 0 && (!d_a || !d_b || !d_x)) return fail(PJ_EINVAL, "null device pointer");
+    if ((d_lu == nullptr) != (d_perm == nullptr)) return fail(PJ_EINVAL, "d_lu and d_perm: both or neither");
+    return lu_call(nsp, n, d_a, gamma, d_lu, d_perm, d_b, d_x, pj::LU_FACTOR | pj::LU_SOLVE, stream);
+}
 
 int pj_time_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
                          double* d_jac, int jac_layout, void* stream, int iters, double* ms_per_launch)

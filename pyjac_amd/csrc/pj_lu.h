@@ -1,0 +1,222 @@
+// pj_lu.h -- batched dense LU (partial pivoting) and triangular solves on per-state NSP x NSP blocks: the consumer
+// of the Jacobians an implicit integrator's Newton iteration needs (SURVEY 8f N2 "fused consumer: batched LU";
+// the reference hands its per-state Jacobian to such a solver, docs/examples.rst:106-170, and has no batched
+// form of it).  The blocks are pyJac's per-state C layout (column-major, state-major: A[s*NSP*NSP + r + NSP*c]).
+//
+// One wavefront per matrix, one LANE PER ROW, the row's entries in registers with compile-time indices:
+//  * column k's pivot is a wavefront reduction (6 DPP steps on |a_k|, then a ballot picks the first lane that holds
+//    the maximum -- LAPACK's choice);
+//  * rows are never swapped: a lane remembers the position its row was chosen for (implicit pivoting) and rows are
+//    written out at their positions, so the result is the usual P A = L U block with the row permutation next to it;
+//  * the pivot row reaches the other lanes through v_readlane (lane index in a scalar register), i.e. as scalar
+//    operands of the update FMAs: no LDS, no shuffles.
+// Elimination step k costs 3 instructions per remaining column (two v_readlane, one fused multiply-add over all
+// rows at once) + ~40 for the pivot search: 6.4 k instructions for a 53 x 53 block.  Bound: HBM (reads and writes
+// 8 NSP^2 bytes per state) for large NSP, instruction issue below that.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+namespace pj {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void lu_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        lu_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ double lu_readlane(const double v, const int lane)
+{
+    const long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double lu_dpp_max(const double v)
+{
+    // lanes without a source lane (or in rows outside ROWMASK) keep their own value: max(v, v) = v
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)u, (int)(unsigned)u, CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(u >> 32), (int)(unsigned)(u >> 32), CTRL, ROWMASK, 0xf, false);
+    const double o = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));     // (fmax() would canonicalise both operands first)
+    return r;
+}
+
+// 1 / u correctly rounded in all but pathological cases (v_rcp_f64 + three Newton steps: 8 instructions instead of
+// the 25 of an IEEE division sequence); LAPACK's dgetf2 scales the column by the reciprocal of the pivot as well
+__device__ __forceinline__ double lu_rcp(const double u)
+{
+    double r = __builtin_amdgcn_rcp(u);
+    r = __builtin_fma(__builtin_fma(-u, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-u, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-u, r, 1.0), r, r);
+    return r;
+}
+// b / u from r = 1 / u with one residual correction
+__device__ __forceinline__ double lu_div(const double b, const double u, const double r)
+{
+    const double q = b * r;
+    return __builtin_fma(__builtin_fma(-q, u, b), r, q);
+}
+
+// maximum over the 64 lanes (values >= -1, no NaN handling beyond fmax's): row_shr 1, 2, 4, 8 inside the rows of 16,
+// then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
+__device__ __forceinline__ double lu_wave_max(double v)
+{
+    v = lu_dpp_max<0x111, 0xf>(v);
+    v = lu_dpp_max<0x112, 0xf>(v);
+    v = lu_dpp_max<0x114, 0xf>(v);
+    v = lu_dpp_max<0x118, 0xf>(v);
+    v = lu_dpp_max<0x142, 0xa>(v);
+    v = lu_dpp_max<0x143, 0xc>(v);
+    return lu_readlane(v, 63);
+}
+
+enum { LU_FACTOR = 1, LU_SOLVE = 2, LU_PREFACTORED = 4 };
+
+// NP: NSP rounded up to a multiple of 8 (rows / columns beyond NSP are the identity's: they are never pivots of a
+// real column and contribute zeros).  mode: LU_FACTOR (A -> lu, perm), LU_FACTOR | LU_SOLVE (A, b -> x, and lu / perm
+// if given), LU_PREFACTORED | LU_SOLVE (lu, perm, b -> x).  gamma != 0: the matrix is I - gamma A (the Newton
+// matrix of an implicit step).
+template <int NP>
+__global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const double* A, const double gamma,
+                                            double* lu, int* __restrict__ perm, const double* __restrict__ b,
+                                            double* __restrict__ x, const int mode)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const long nw = (long)gridDim.x * 4;
+    const long ne = (long)nsp * nsp;
+    const int lane0 = lane, nsp0 = nsp;
+    for (long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6); s < n; s += nw) {
+        // Every predicate of the body (j < nsp, lane == j, lane > k ...) is invariant across matrices, and the
+        // optimiser knows: it computes hundreds of lane masks once, in front of the loop, and spills them.  Opaque
+        // copies of `nsp` and `lane` per phase keep each predicate next to its use.
+        int nsp = nsp0, lane = lane0;
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        const bool act = lane < nsp;
+        double a[NP];
+        const double* As = ((mode & LU_PREFACTORED) ? lu : A) + s * ne;
+        lu_for<0, NP>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const double id = (j == lane) ? 1.0 : 0.0;
+            double v = id;
+            if (act && j < nsp) {
+                v = As[lane + (long)nsp * j];
+                if (!(mode & LU_PREFACTORED) && gamma != 0.0) v = id - gamma * v;
+            }
+            a[j] = v;
+        });
+        // pos: the position this lane's row was chosen for (-1: not yet); a prefactored block is read row by position
+        int pos = (mode & LU_PREFACTORED) ? lane : -1;
+        double bb = 0.0;
+        if (mode & LU_SOLVE) {
+            if (mode & LU_PREFACTORED) bb = act ? b[s * nsp + perm[s * nsp + lane]] : 0.0;
+            else bb = act ? b[s * nsp + lane] : 0.0;
+        }
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        if (!(mode & LU_PREFACTORED)) {
+            lu_for<0, NP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k < nsp) {                                   // wavefront-uniform
+                    const bool open = pos < 0 && act;           // rows not chosen yet (nsp - k of them)
+                    const double cand = open ? fabs(a[k]) : -1.0;
+                    const double mx = lu_wave_max(cand);
+                    const unsigned long long avail = __builtin_amdgcn_ballot_w64(open);
+                    unsigned long long hit = __builtin_amdgcn_ballot_w64(cand == mx) & avail;
+                    if (hit == 0) hit = avail;                   // a column of NaNs: any open row, never a chosen one
+                    const int p = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
+                    if (lane == p) pos = k;
+                    const double ukk = lu_readlane(a[k], p);
+                    const double inv = lu_rcp(ukk);
+                    const bool below = pos < 0;                  // rows not chosen yet: eliminated by this pivot
+                    const double l = below ? a[k] * inv : 0.0;
+                    if (below) a[k] = l;
+                    lu_for<k + 1, NP>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const double ukj = lu_readlane(a[j], p);
+                        a[j] = __builtin_fma(-l, ukj, a[j]);     // l = 0 in the rows already chosen
+                        // the broadcasts of a step are independent of its updates: left alone the scheduler issues
+                        // them all first and spills a thousand scalar registers; four columns at a time
+                        if constexpr (((j - k) & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                    });
+                    // forward substitution rides along: y_k is the pivot row's right-hand side
+                    if (mode & LU_SOLVE) {
+                        const double yk = lu_readlane(bb, p);
+                        bb = __builtin_fma(-l, yk, bb);
+                    }
+                }
+            });
+        } else {
+            // L y = P b, column by column: position k's lane is lane k
+            lu_for<0, NP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k < nsp) {
+                    const double yk = lu_readlane(bb, k);
+                    if (lane > k) bb = __builtin_fma(-a[k], yk, bb);
+                }
+            });
+        }
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        if (!(mode & LU_PREFACTORED) && lu != nullptr && act) {
+            double* Ls = lu + s * ne;
+            lu_for<0, NP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j < nsp) Ls[pos + (long)nsp * j] = a[j];
+            });
+            if (perm != nullptr) perm[s * nsp + pos] = lane;
+        }
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        if (mode & LU_SOLVE) {
+            // U x = y, last column first: the lane at position k owns x_k
+            lu_for<0, NP>([&](auto kr) {
+                constexpr int k = NP - 1 - decltype(kr)::value;
+                if (k < nsp) {
+                    const unsigned long long own = __builtin_amdgcn_ballot_w64(pos == k);
+                    const int p = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(own));
+                    const double ukk = lu_readlane(a[k], p);
+                    const double xk = lu_div(lu_readlane(bb, p), ukk, lu_rcp(ukk));
+                    if (pos == k) bb = xk;
+                    else if (pos < k && pos >= 0) bb = __builtin_fma(-a[k], xk, bb);
+                }
+            });
+            if (act) x[s * nsp + pos] = bb;
+        }
+    }
+}
+
+template <int NP>
+inline void lu_launch_np(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
+                         int mode, int cus, hipStream_t st)
+{
+    long blocks = (n + 3) / 4;
+    const long cap = (long)cus * 8;         // grid-stride beyond a few workgroups per CU
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_lu<NP>, dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, gamma, lu, perm, b, x, mode);
+}
+
+inline int lu_launch(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
+                     int mode, int cus, hipStream_t st)
+{
+    if (nsp < 1 || nsp > 64) return -1;
+    switch ((nsp + 7) / 8) {
+    case 1: lu_launch_np<8>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 2: lu_launch_np<16>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 3: lu_launch_np<24>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 4: lu_launch_np<32>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 5: lu_launch_np<40>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 6: lu_launch_np<48>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 7: lu_launch_np<56>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    default: lu_launch_np<64>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    }
+    return 0;
+}
+
+}  // namespace pj
