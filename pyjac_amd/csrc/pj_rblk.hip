@@ -103,6 +103,8 @@ using namespace pj;
 #endif
 #define PJQ_TILE 256        // states per scratch tile
 #if defined(PJR_HOST_EMU)
+#define PJQ_E_ADD(ptr, val) (*(ptr) += (val))
+#define PJQ_E_READ(ptr) (*(ptr))
 #define PJQ_STORE(ptr, val) (*(ptr) = (val))
 #define PJQ_LOAD_NT(ptr) (*(ptr))
 #define PJQ_SCHED_BARRIER()
@@ -124,6 +126,9 @@ using namespace pj;
 #endif
 #define PJQ_LOAD_NT(ptr) __builtin_nontemporal_load(ptr)
 #define PJQ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// energy-row sums: no-return fp64 atomic add performed in the L2 (global_atomic_add_f64), read back past the L1
+#define PJQ_E_ADD(ptr, val) ((void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)(ptr), (val)))
+#define PJQ_E_READ(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 // debug builds (-DPJQ_TIMING): shader cycles per phase and wavefront, summed over a kernel
@@ -171,7 +176,21 @@ constexpr int NSUM = 5 + (pjs::NSP - 1);   // H, SCP, SJT, HP, HQ, E_j
 #ifdef PJQ_ID
 constexpr int SUM_IN = pjs::NSCQ + (PJQ_ID % 2) * NSUM, SUM_OUT = pjs::NSCQ + ((PJQ_ID + 1) % 2) * NSUM;
 #endif
-constexpr int NSLOTS = pjs::NSCQ + 2 * PJQ_HALVES * NSUM;     // with two halves: a pair of sets per half
+// PJQ_E_ATOMIC = 1 (experiment, measured and switched off): the LAST partial sums E_j of the energy row are not
+// carried in registers (52 / 110 doubles per lane: the AGPRs of the 53-species kernels, spills in the 111-species
+// ones, five instructions per update) -- every update is one no-return fp64 atomic add (global_atomic_add_f64,
+// performed in the L2) into a per-state array behind the slot sets: [lane group][real | trash][wavefront of the
+// tile][j][64 lanes].  One lane owns a state's sums within a kernel and kernels of a batch run in stream order, so
+// the sums are deterministic; lanes that evaluate a state a second time (shifted last workgroup) add to the trash
+// copy, lanes past the end to the slots of the state index they would have had.  The first row kernel zeroes the
+// sums, the last one reads them back.  Results agree with the register form to rounding, 8 % fewer instructions
+// and half the AGPRs -- and 7.0 -> 11.1 ms (GRI-shaped), 6.5 -> 8.8 ms (USC-shaped): 1.8 k / 5.7 k atomic adds per
+// state are more than the L2 takes next to the Jacobian stores (profiles/r03_rblk_energy_row_atomics.txt).
+#ifndef PJQ_E_ATOMIC
+#define PJQ_E_ATOMIC 0
+#endif
+constexpr int E_BASE = pjs::NSCQ + 2 * PJQ_HALVES * NSUM;     // with two halves: a pair of sets per half
+constexpr int NSLOTS = E_BASE + (PJQ_E_ATOMIC ? PJQ_HALVES * 2 * (pjs::NSP - 1) : 0);
 
 // reactions evaluated once per state by k_pre and handed over
 constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG | F_CHEB)) != 0; }
@@ -555,8 +574,14 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     if (s0_wg + PJQ_BLOCK > A.n) s0_wg = A.n - PJQ_BLOCK;
     // lanes 0..31 of a wavefront: its even states, lanes 32..63: the odd ones (swap_halves)
     const long s = s0_wg + (tid & ~63) + 2 * (tid & 31) + ((tid >> 5) & 1);
+    // a state of the shifted workgroup that its neighbour evaluates too: its energy-row sums go to the trash copy
+    const long e_state = s;
+    const bool e_dup = s < (long)blockIdx.x * PJQ_BLOCK;
 #else
     long s = (long)blockIdx.x * PJQ_BLOCK + tid;
+    // lanes past the end accumulate their energy-row sums in the (unused) slots of the state index they would have
+    const long e_state = s;
+    const bool e_dup = false;
     if (s >= A.n) s = A.n - 1;
 #endif
 #ifdef PJQ_NO_STORE
@@ -622,16 +647,22 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     }
     double* const wp = A.w + s * A.w_ss;
 #endif
+#define PJQ_E_AT (PJQ_E_ATOMIC && !PJQ_JV)
+#if !PJQ_E_AT
     // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
     double E[LAST > 0 ? LAST : 1];
+#endif
     double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
     const double* const scr = scr_of(A, s);
     const long hset = (long)half * (2 * NSUM) * PJQ_TILE;      // this half's pair of slot sets
     if constexpr (FIRST_) {
+#if !PJQ_E_AT
         static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] = 0.0; });
+#endif
     } else {
         // partial sums of the previous row kernel: fetched here, next to the state loads, so that no
         // kernel ever waits for a load behind its own Jacobian stores
+#if !PJQ_E_AT
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
@@ -640,6 +671,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             E[j] = 0.0;
 #endif
         });
+#endif
         H = scr[hset + (long)SUM_IN * PJQ_TILE];
         SCP = scr[hset + (long)(SUM_IN + 1) * PJQ_TILE];
         SJT = scr[hset + (long)(SUM_IN + 2) * PJQ_TILE];
@@ -658,6 +690,19 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     double* const Jw = A.jac + s_wave * A.j_ss;
     const unsigned jvo = (unsigned)((s - s_wave) * A.j_ss) * 8u;
 #define J_(e) (*(double*)((char*)(Jw + (long)(e) * A.j_si) + jvo))
+#if PJQ_E_AT
+    // energy-row sum j of this lane's state: wavefront-uniform base of the tile's array + j * 64 doubles + a 32-bit
+    // per-lane byte offset (tile relative to the wavefront's, lane group, real | trash copy, wavefront and lane of
+    // the state within its tile): sums of consecutive j are 512 bytes apart, eight per immediate-offset range
+    const long e_tile_w = s_wave / PJQ_TILE;
+    double* const Eb = A.scr + e_tile_w * ((long)NSLOTS * PJQ_TILE) + (long)E_BASE * PJQ_TILE;
+    const long e_t = e_state % PJQ_TILE;
+    const unsigned evo = (unsigned)(((e_state / PJQ_TILE - e_tile_w) * ((long)NSLOTS * PJQ_TILE) +
+                                     ((long)half * 2 + (e_dup ? 1 : 0)) * ((long)LAST * PJQ_TILE) +
+                                     (e_t / 64) * ((long)LAST * 64) + (e_t % 64)) * 8);
+#define E_(j) ((double*)((char*)(Eb + (long)(j) * 64) + evo))
+    if constexpr (FIRST_) static_for<LAST>([&](auto jc) PJR_INL { *E_(decltype(jc)::value) = 0.0; });
+#endif
 #if PJQ_PAIR
     // pair stores (SoA only, host-checked: j_ss == 1, 8 * NSP * j_si < 2^32): a lane of the lower half
     // addresses its own (even) state in column c, its partner in the upper half that state in column c + 1
@@ -981,7 +1026,11 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 constexpr int si = pjs::SLOC[k][j];
                 if constexpr (si >= 0) {
 #ifndef PJQ_NO_E      // experiment: what the energy-row partial sums cost (results wrong)
+#if PJQ_E_AT
+                    PJQ_E_ADD(E_(j), hW[r] * S[si]);
+#else
                     E[j] += hW[r] * S[si];
+#endif
 #endif
                     return INVW(j) * (WP[r] + pjs::SP[k][1] * S[si]) - WQN[r];
                 } else {
@@ -1043,12 +1092,14 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         sw[(long)(SUM_OUT + 2) * PJQ_TILE] = SJT;
         sw[(long)(SUM_OUT + 3) * PJQ_TILE] = HP;
         sw[(long)(SUM_OUT + 4) * PJQ_TILE] = HQ;
+#if !PJQ_E_AT
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
             sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = E[j];
 #endif
         });
+#endif
     } else {
         // rate_subs.py:2171-2335 / create_jacobian.py:2940-3120: mass-fraction weighted c_p sums
         // from the concentrations, Y_k c_p,k = C_k R (a0 + ...) / rho
@@ -1078,22 +1129,43 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         if constexpr (PJQ_HALVES == 2) {
             // half 1 hands its sums to half 0 through the concentration columns (nobody reads them any more)
             static_assert(!(PJQ_HALVES == 2 && LASTK_) || sizeof(LTK) >= sizeof(double) * 4 * PJQ_BLOCK, "exchange buffer");
+#if PJQ_E_AT
+            __threadfence();        // the other lane group's atomic adds have been performed before its sums are read
+#endif
             __syncthreads();
             if (half == 1) {
+#if !PJQ_E_AT
                 static_for<LAST>([&](auto jc) PJR_INL { CL[decltype(jc)::value][tid] = E[decltype(jc)::value]; });
+#endif
                 CL[LAST][tid] = H;
                 LTK[0 * PJQ_BLOCK + tid] = SCP; LTK[1 * PJQ_BLOCK + tid] = SJT;
                 LTK[2 * PJQ_BLOCK + tid] = HP; LTK[3 * PJQ_BLOCK + tid] = HQ;
             }
             __syncthreads();
             if (half == 0) {
+#if !PJQ_E_AT
                 static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] += CL[decltype(jc)::value][tid]; });
+#endif
                 H += CL[LAST][tid];
                 SCP += LTK[0 * PJQ_BLOCK + tid]; SJT += LTK[1 * PJQ_BLOCK + tid];
                 HP += LTK[2 * PJQ_BLOCK + tid]; HQ += LTK[3 * PJQ_BLOCK + tid];
             }
         }
         if (PJQ_HALVES == 1 || half == 0) {
+#if PJQ_E_AT
+        // the finished sums (this lane group's own atomic adds precede these loads in program order; the other
+        // group's were fenced before the barrier above); half 0's lanes never have half != 0 in evo
+        double E[LAST > 0 ? LAST : 1];
+        static_for<LAST>([&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+#ifndef PJQ_NO_E
+            E[j] = PJQ_E_READ(E_(j));
+            if constexpr (PJQ_HALVES == 2) E[j] += PJQ_E_READ(E_(j) + 2L * LAST * PJQ_TILE);
+#else
+            E[j] = 0.0;
+#endif
+        });
+#endif
 #if PJQ_JV
         double w0 = (-(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg)) * V[0];
         static_for<LAST>([&](auto jc) PJR_INL {

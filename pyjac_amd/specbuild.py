@@ -32,6 +32,8 @@ LANE_FLAGS = ('-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal
 RBLK_FLAGS = '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math -mllvm -amdgpu-schedule-relaxed-occupancy=1'
 
 RBLK_BUDGET = 56          # accumulator doubles per row block of pj_rblk.hip (4 dense + non-zero S per row)
+RBLK_BUDGET_HALVES = 40   # ... of the two-lane-group builds (57..120 species: 110 energy-row sums per lane leave less
+                          # room; USC-shaped 6.46 ms at 56, 6.35 at 48, 6.28 at 40: profiles/r03_rblk_energy_row_atomics.txt)
 RBLK_FUSE = 13            # row blocks per kernel and lane group (at most)
 
 _src_digest = {}
@@ -106,7 +108,6 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     hdr = so[:-3] + '.%d.h' % pid
     work = so[:-3] + '.%d.obj' % pid
     os.makedirs(work, exist_ok=True)
-    budget = int(budget or os.environ.get('PJ_RBLK_BUDGET', RBLK_BUDGET))
     fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', RBLK_FUSE))
     # states per workgroup of the row kernels: the concentration columns (8 NSP bytes per lane) + the K_c rows of
     # the kernel's reactions must fit the LDS
@@ -115,6 +116,7 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on the
     # same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
     halves = int(os.environ.get('PJ_RBLK_HALVES', 2 if block == 128 else 1))
+    budget = int(budget or os.environ.get('PJ_RBLK_BUDGET', RBLK_BUDGET_HALVES if halves == 2 else RBLK_BUDGET))
     c_lds = int(nsp > 64)
     # rate kernels: concentrations in registers up to 64 species (256 states per workgroup), in LDS columns beyond
     # (128 states, two lane groups)

@@ -19,6 +19,7 @@
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 static thread_local dim3 threadIdx(0), blockIdx(0), blockDim(1), gridDim(1);
 inline void __syncthreads() {}
+inline void __threadfence() {}
 typedef void* hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0, hipDeviceAttributeMultiprocessorCount = 0 };
