@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
         });
         // pos: the position this lane's row was chosen for (-1: not yet); a prefactored block is read row by position
         int pos = (mode & LU_PREFACTORED) ? lane : -1;
-        double bb = 0.0;
+        double bb = 0.0, myinv = 1.0;             // myinv: 1 / u_kk in the lane whose row became row k
         if (mode & LU_SOLVE) {
             if (mode & LU_PREFACTORED) bb = act ? b[s * nsp + perm[s * nsp + lane]] : 0.0;
             else bb = act ? b[s * nsp + lane] : 0.0;
@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
                     if (lane == p) pos = k;
                     const double ukk = lu_readlane(a[k], p);
                     const double inv = lu_rcp(ukk);
+                    if (lane == p) myinv = inv;
                     const bool below = pos < 0;                  // rows not chosen yet: eliminated by this pivot
                     const double l = below ? a[k] * inv : 0.0;
                     if (below) a[k] = l;
@@ -181,8 +182,10 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
                 if (k < nsp) {
                     const unsigned long long own = __builtin_amdgcn_ballot_w64(pos == k);
                     const int p = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(own));
-                    const double ukk = lu_readlane(a[k], p);
-                    const double xk = lu_div(lu_readlane(bb, p), ukk, lu_rcp(ukk));
+                    // every lane divides its own right-hand side by its own a[k] (u_kk in the owner lane, whose
+                    // quotient is the one that is broadcast)
+                    if (mode & LU_PREFACTORED) myinv = lu_rcp(a[k]);
+                    const double xk = lu_readlane(lu_div(bb, a[k], myinv), p);
                     if (pos == k) bb = xk;
                     else if (pos < k && pos >= 0) bb = __builtin_fma(-a[k], xk, bb);
                 }

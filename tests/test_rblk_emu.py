@@ -74,6 +74,8 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('h2o2_n2', 12, dict(blocks_per_part=100, rates_per_part=5)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_DEPTH=1',))),
+    # the build option that keeps the energy-row sums in a per-state array (atomic adds on the device) instead of registers
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_E_ATOMIC=1',))),
     # SRI falloff (3 / 5 parameters, LOW / HIGH, collider) and Chebyshev reactions: evaluated by the pre-pass
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
     # N1: fractional stoichiometric coefficients (pow), more than three molecules / species per side, also on
