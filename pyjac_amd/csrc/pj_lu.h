@@ -37,6 +37,19 @@ __device__ __forceinline__ double lu_readlane(const double v, const int lane)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// the same broadcast through the LDS crossbar (ds_bpermute_b32: no LDS memory, no VALU issue slot; the value arrives
+// in a vector register)
+__device__ __forceinline__ double lu_bpermute(const double v, const int byte_addr)
+{
+    const long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#ifndef PJ_LU_BPERM
+#define PJ_LU_BPERM 2       // broadcasts of the pivot row: 0 all v_readlane, 1 all ds_bpermute, 2 every other column
+#endif
+
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double lu_dpp_max(const double v)
 {
@@ -104,16 +117,23 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
         const bool act = lane < nsp;
         double a[NP];
         const double* As = ((mode & LU_PREFACTORED) ? lu : A) + s * ne;
+        // every load is issued before anything depends on one (clamped, always valid addresses instead of
+        // predicates: a branch per column would serialise 53 memory round trips); the identity padding and the Newton
+        // matrix I - gamma A are applied afterwards, branch-free
+        const int lane_c = lane < nsp ? lane : nsp - 1;
         lu_for<0, NP>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            const double id = (j == lane) ? 1.0 : 0.0;
-            double v = id;
-            if (act && j < nsp) {
-                v = As[lane + (long)nsp * j];
-                if (!(mode & LU_PREFACTORED) && gamma != 0.0) v = id - gamma * v;
-            }
-            a[j] = v;
+            a[j] = As[lane_c + (long)nsp * (j < nsp ? j : nsp - 1)];
         });
+        {
+            const bool newton = !(mode & LU_PREFACTORED) && gamma != 0.0;
+            const double sc = newton ? -gamma : 1.0, sh = newton ? 1.0 : 0.0;     // a -> sh * delta_ij + sc * a
+            lu_for<0, NP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const double id = (j == lane) ? 1.0 : 0.0;
+                a[j] = (act && j < nsp) ? __builtin_fma(sc, a[j], sh * id) : id;
+            });
+        }
         // pos: the position this lane's row was chosen for (-1: not yet); a prefactored block is read row by position
         int pos = (mode & LU_PREFACTORED) ? lane : -1;
         double bb = 0.0, myinv = 1.0;             // myinv: 1 / u_kk in the lane whose row became row k
@@ -142,7 +162,9 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
                     if (below) a[k] = l;
                     lu_for<k + 1, NP>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
-                        const double ukj = lu_readlane(a[j], p);
+                        // (the VALU issues the v_readlane pairs and the updates, the LDS pipeline the other broadcasts)
+                        const double ukj = (PJ_LU_BPERM == 1 || (PJ_LU_BPERM == 2 && ((j - k) & 1) == 0))
+                                               ? lu_bpermute(a[j], p * 4) : lu_readlane(a[j], p);
                         a[j] = __builtin_fma(-l, ukj, a[j]);     // l = 0 in the rows already chosen
                         // the broadcasts of a step are independent of its updates: left alone the scheduler issues
                         // them all first and spills a thousand scalar registers; four columns at a time
