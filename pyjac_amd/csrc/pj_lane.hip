@@ -60,6 +60,21 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
 
 #include "pj_math.h"
+// 1 / u without the IEEE division sequence (div_scale x2, rcp, five FMAs, div_fmas, div_fixup: ~17 issue slots at one
+// wavefront per SIMD): v_rcp_f64 (>= 24 bits) + two Newton steps, within an ulp of the correctly rounded value; the
+// arguments here (T, rho, 1 + Pr, F_cent ...) are far from the range ends the sequence exists for.
+#ifdef PJL_HOST_EMU
+#define PJL_RCP(u) (1.0 / (u))
+#else
+__device__ __forceinline__ double pjl_rcp(const double u)
+{
+    double r = __builtin_amdgcn_rcp(u);
+    r = __builtin_fma(__builtin_fma(-u, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-u, r, 1.0), r, r);
+    return r;
+}
+#define PJL_RCP(u) pjl_rcp(u)
+#endif
 
 template <int J>
 constexpr std::integral_constant<int, J + 1> jc_plus1(std::integral_constant<int, J>) { return {}; }
@@ -176,7 +191,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     const double (*SPT)[4] = (const double (*)[4])((const char*)SPL + zoff);
     const double T = nxT;
     const double p = nxP;
-    const double logT = log(T), invT = 1.0 / T, logp = log(p);
+    const double logT = log(T), invT = PJL_RCP(T), logp = log(p);
 
     // ---- eval_conc + NASA properties ----
     double C[NSP + 1], hW[NSP], cpk[NSP];
@@ -191,9 +206,9 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     const double yN = 1.0 - sumY;
     C[LAST] = yN;
     sumYW += yN * SPT[LAST][0];
-    const double Wbar = 1.0 / sumYW;
-    const double rho = p * Wbar / (RU_ * T), invrho = 1.0 / rho;
-    const double mconc = p / (RU_ * T);
+    const double Wbar = PJL_RCP(sumYW);
+    const double mconc = p * (invT * (1.0 / RU_));
+    const double rho = mconc * Wbar, invrho = PJL_RCP(rho);
     double cpavg = 0.0, dcpavg = 0.0;
 #pragma unroll
     for (int k = 0; k < NSP; ++k) {
@@ -236,7 +251,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
                                  B2 = pjs::PLOG[pp + q][3], E2 = pjs::PLOG[pp + q][4];
                 const double k1 = A1 + B1 * logT - E1 * invT;
                 const double k2 = A2 + B2 * logT - E2 * invT;
-                const double f = (logp - L1) / (L2 - L1);
+                const double f = (logp - L1) * PJL_RCP(L2 - L1);
                 const bool in = p > P1 && p <= P2;
                 lnk = in ? k1 + (k2 - k1) * f : lnk;
                 dlnk = in ? B1 + E1 * invT + ((B2 - B1) + (E2 - E1) * invT) * f : dlnk;
@@ -302,14 +317,15 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
                 const double e0T = RDT[i][RD_E0] * invT;
                 const double k0kinf = exp(RDT[i][RD_LNAR] + RDT[i][RD_B0] * logT - e0T);
                 const double Pr = conc_temp * k0kinf;
-                const double i1Pr = 1.0 / (1.0 + Pr);
+                const double i1Pr = PJL_RCP(1.0 + Pr);
                 double F = 1.0, extra = 0.0, Xtroe = 0.0;
                 if constexpr ((fl & F_TROE) != 0) {
                     const double ta = RDT[i][RD_TRA], T3 = RDT[i][RD_T3], T1 = RDT[i][RD_T1],
                                  T2 = RDT[i][RD_T2];
-                    const double e3 = exp(-T / T3), e1 = exp(-T / T1);
+                    const double iT3 = PJL_RCP(T3), iT1 = PJL_RCP(T1);
+                    const double e3 = exp(-T * iT3), e1 = exp(-T * iT1);
                     double Fcent = (1.0 - ta) * e3 + ta * e1;
-                    double dF = -((1.0 - ta) / T3) * e3 - (ta / T1) * e1;
+                    double dF = -((1.0 - ta) * iT3) * e3 - (ta * iT1) * e1;
                     if constexpr ((fl & F_TROE4) != 0) {
                         const double e2 = exp(-T2 * invT);
                         Fcent += e2;
@@ -320,11 +336,11 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
                     const double lgPr = log(fmax(Pr, 1.0e-300)) * INV_LN10;
                     const double At = lgPr - 0.67 * lgF - 0.4;
                     const double Bt = 0.806 - 1.1762 * lgF - 0.14 * lgPr;
-                    const double iB = 1.0 / Bt;
-                    const double iden = 1.0 / (1.0 + At * At * iB * iB);
+                    const double iB = PJL_RCP(Bt);
+                    const double iden = PJL_RCP(1.0 + At * At * iB * iB);
                     F = exp(lF * iden);
                     const double lnF_AB = 2.0 * lF * At * iB * iB * iB * iden * iden;
-                    const double iFc = 1.0 / Fcent;
+                    const double iFc = PJL_RCP(Fcent);
                     Xtroe = lnF_AB * (INV_LN10 * Bt + (0.14 * INV_LN10) * At);
                     extra = (iFc * iden - lnF_AB * (-(0.67 * INV_LN10) * Bt + (1.1762 * INV_LN10) * At) * iFc) * dF -
                             Xtroe * (RDT[i][RD_B0] + e0T - 1.0) * invT;
@@ -417,7 +433,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             if (A.spec_rates) __builtin_nontemporal_store(om[k], &A.spec_rates[k * A.o_ld + s]);
             if (A.dy && k < LAST) __builtin_nontemporal_store(om[k] * SPT[k][1] * invrho, &A.dy[(k + 1) * A.o_ld + s]);
         }
-        if (A.dy) __builtin_nontemporal_store(-Hs / (rho * cpavg), &A.dy[s]);
+        if (A.dy) __builtin_nontemporal_store(-Hs * (invrho * PJL_RCP(cpavg)), &A.dy[s]);
         continue;
     }
     // reference quirk (create_jacobian.py:2786-2818), see pj_kernel.h phase 3
@@ -509,7 +525,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         else JMEM(e, v);
     };
 #define PJL_E(e_) std::integral_constant<int, (e_)>{}
-    const double icp = 1.0 / cpavg;
+    const double icp = PJL_RCP(cpavg);
     // one column: val(k) -> row k + 1 for k = 0 .. LAST-1 (called in order), then row 0
     auto column = [&](auto colc, auto&& val, auto&& row0) PJL_INL {
         constexpr int col = decltype(colc)::value;
@@ -534,7 +550,7 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
         flush(colc);
     };
     column(PJL_E(0), [&](auto kc) PJL_INL { return SPT[decltype(kc)::value][1] * jt[decltype(kc)::value]; },
-           [&]() PJL_INL { return -(scp - (dcpavg * icp) * H + rho * sjt) / (rho * cpavg); });
+           [&]() PJL_INL { return -(scp - (dcpavg * icp) * H + rho * sjt) * (invrho * icp); });
     static_for<LAST>([&](auto jc) PJL_INL {
         constexpr int j = decltype(jc)::value;
         const double wj = SPT[j][3], iWj = SPT[j][0];

@@ -792,7 +792,9 @@ def test_per_state_cache_serves_the_testers_call_sequence(golden, torch_cuda):
             mx, _ = thresholded_rel_err(cached[k], plain[k])
             assert mx < 1e-12, (k, mx)
         assert abs(cached['yN'] - plain['yN']) < 1e-15
-        sc = np.abs(plain['fwd']).max() + 1e-300
+        # (the cached state comes from the mechanism-specific kernel, the uncached calls from the table-driven one:
+        # equal to rounding, judged against the largest rate -- pres_mod can make a net rate far larger than max |fwd|)
+        sc = max(np.abs(plain['fwd']).max(), np.abs(plain['sr']).max()) + 1e-300
         assert np.abs(cached['sr'] - plain['sr']).max() <= 1e-10 * sc
         assert np.allclose(cached['dy'][:nsp], plain['dy'][:nsp], rtol=1e-9, atol=1e-10 * np.abs(plain['dy'][:nsp]).max())
         # another pressure: not served from the cache
