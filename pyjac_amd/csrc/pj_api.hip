@@ -966,11 +966,11 @@ static int lu_call(int nsp, long n, const double* a, double gamma, double* lu, i
                    void* stream)
 {
     if (n < 0 || nsp < 1) return fail(PJ_EINVAL, "bad argument");
-    if (nsp > 64) return fail(PJ_EUNSUPPORTED, "batched LU: one lane per row, at most 64 rows");
+    if (nsp > pj::LU_MAX_LDS) return fail(PJ_EUNSUPPORTED, "batched LU: at most 140 rows (the block has to fit the LDS)");
     if (n == 0) return PJ_OK;
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(PJ_ENODEV, "no HIP device");
-    if (pj::lu_launch(nsp, n, a, gamma, lu, perm, b, x, mode, lu_cus(), (hipStream_t)stream)) return fail(PJ_EINVAL, "bad argument");
+    if (pj::lu_launch(nsp, n, a, gamma, lu, perm, b, x, mode, lu_cus(), (hipStream_t)stream)) return fail(PJ_EHIP, "batched LU launch failed");
     return hipGetLastError() == hipSuccess ? PJ_OK : fail(PJ_EHIP, "batched LU launch failed");
 }
 int pj_lu_factor_dev(int nsp, long n, const double* d_a, double gamma, double* d_lu, int* d_perm, void* stream)

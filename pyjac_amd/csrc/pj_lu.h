@@ -12,7 +12,7 @@
 //    operands of the update FMAs: no LDS, no shuffles.
 // Elimination step k costs 3 instructions per remaining column (two v_readlane, one fused multiply-add over all
 // rows at once) + ~40 for the pivot search: 6.4 k instructions for a 53 x 53 block.  Bound: HBM (reads and writes
-// 8 NSP^2 bytes per state) for large NSP, instruction issue below that.
+// 8 NSP^2 bytes per state) for large NSP, instruction issue below that.  Blocks of 65 .. 140 rows: k_lu_lds below.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -217,6 +217,126 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
     }
 }
 
+
+// ---- blocks of 65 .. LU_MAX_LDS rows: the matrix in LDS, one workgroup per block -------------------------------
+// A lane per row stops at 64 rows.  Larger blocks (the 111-species mechanisms) take the textbook right-looking
+// factorisation on an LDS-resident copy: column-major with an odd leading dimension (bank-conflict free down a
+// column), pivot search by a wavefront argmax per 64 rows + a four-entry exchange, physical row exchange, 32 x 8
+// thread tiles over the trailing block with the multipliers of the thread's rows in registers.  Same results and
+// same (lu, perm) convention as k_lu; latency-bound by its ~4 barriers per column.
+constexpr int LU_MAX_LDS = 140;        // (140 | 1) * 140 + 3 * 140 doubles = 159 KB of the 160 KB
+
+__global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, const double* A, const double gamma, double* lu,
+                                                int* __restrict__ perm, const double* __restrict__ b,
+                                                double* __restrict__ x, const int mode)
+{
+    extern __shared__ double lds_lu[];
+    const int ld = nsp | 1;
+    double* const M = lds_lu;                       // M[c * ld + r]
+    double* const bv = M + (long)ld * nsp;          // right-hand side / solution
+    double* const red_v = bv + nsp;                 // per-wavefront pivot candidates
+    int* const red_i = (int*)(red_v + 4);
+    int* const pm = red_i + 4;                      // row permutation
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long ne = (long)nsp * nsp;
+    const bool pre = (mode & LU_PREFACTORED) != 0, solve = (mode & LU_SOLVE) != 0;
+    for (long s = blockIdx.x; s < n; s += gridDim.x) {
+        const double* As = (pre ? lu : A) + s * ne;
+        const bool newton = !pre && gamma != 0.0;
+        for (int idx = tid; idx < (int)ne; idx += 256) {
+            const int r = idx % nsp, c = idx / nsp;
+            double v = As[idx];
+            if (newton) v = (r == c ? 1.0 : 0.0) - gamma * v;
+            M[c * ld + r] = v;
+        }
+        if (tid < nsp) {
+            pm[tid] = pre ? perm[s * nsp + tid] : tid;
+        }
+        __syncthreads();
+        if (solve && tid < nsp) bv[tid] = b[s * nsp + (pre ? pm[tid] : tid)];
+        __syncthreads();
+        if (!pre) {
+            for (int k = 0; k < nsp; ++k) {
+                // pivot: first row of maximum magnitude in column k, rows k .. nsp-1
+                {
+                    const int r = k + tid;
+                    const double v = r < nsp ? fabs(M[k * ld + r]) : -1.0;
+                    const double mx = lu_wave_max(v);                   // DPP reduction: no LDS round trips
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(v == mx);
+                    if (lane == 0) { red_v[wave] = mx; red_i[wave] = k + 64 * wave + (hit ? (int)__builtin_ctzll(hit) : 0); }
+                }
+                __syncthreads();
+                int p = k;
+                {
+                    double best = -1.0;
+                    const int nw = (nsp - k + 63) / 64;
+                    for (int w = 0; w < nw && w < 4; ++w)
+                        if (red_v[w] > best) { best = red_v[w]; p = red_i[w]; }       // waves cover increasing rows: first maximum
+                    if (!(best >= 0.0) || p < k || p >= nsp) p = k;                   // a column of NaNs
+                }
+                if (p != k) {
+                    if (tid < nsp) { const double t = M[tid * ld + k]; M[tid * ld + k] = M[tid * ld + p]; M[tid * ld + p] = t; }
+                    if (tid == 255) { const int t = pm[k]; pm[k] = pm[p]; pm[p] = t; }
+                    if (solve && tid == 254) { const double t = bv[k]; bv[k] = bv[p]; bv[p] = t; }
+                }
+                __syncthreads();
+                const double inv = lu_rcp(M[k * ld + k]);
+                const double bk = solve ? bv[k] : 0.0;
+                // multipliers of this thread's rows (kept for the trailing update), forward substitution rides along
+                const int tr = tid & 31, tc = tid >> 5;
+                double lr[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const int r = k + 1 + tr + 32 * q;
+                    lr[q] = r < nsp ? M[k * ld + r] * inv : 0.0;
+                }
+                __syncthreads();            // pivot, b_k and every multiplier read before column k and b change
+                if (tc == 0) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        const int r = k + 1 + tr + 32 * q;
+                        if (r < nsp) { M[k * ld + r] = lr[q]; if (solve) bv[r] = __builtin_fma(-lr[q], bk, bv[r]); }
+                    }
+                }
+                for (int c = k + 1 + tc; c < nsp; c += 8) {
+                    const double ukc = M[c * ld + k];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        const int r = k + 1 + tr + 32 * q;
+                        if (r < nsp) M[c * ld + r] = __builtin_fma(-lr[q], ukc, M[c * ld + r]);
+                    }
+                }
+                __syncthreads();
+            }
+            if (lu != nullptr) {
+                double* Ls = lu + s * ne;
+                for (int idx = tid; idx < (int)ne; idx += 256) Ls[idx] = M[(idx / nsp) * ld + idx % nsp];
+                if (perm != nullptr && tid < nsp) perm[s * nsp + tid] = pm[tid];
+            }
+        } else if (solve) {
+            for (int k = 0; k < nsp; ++k) {          // L y = P b
+                const double yk = bv[k];
+                __syncthreads();
+                const int r = k + 1 + tid;
+                if (r < nsp) bv[r] = __builtin_fma(-M[k * ld + r], yk, bv[r]);
+                __syncthreads();
+            }
+        }
+        if (solve) {
+            for (int k = nsp - 1; k >= 0; --k) {     // U x = y
+                const double ukk = M[k * ld + k];
+                const double xk = lu_div(bv[k], ukk, lu_rcp(ukk));
+                __syncthreads();
+                if (tid == k) bv[k] = xk;
+                else if (tid < k) bv[tid] = __builtin_fma(-M[k * ld + tid], xk, bv[tid]);
+                __syncthreads();
+            }
+            if (tid < nsp) x[s * nsp + tid] = bv[tid];
+        }
+        __syncthreads();
+    }
+}
+
 template <int NP>
 inline void lu_launch_np(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
                          int mode, int cus, hipStream_t st)
@@ -230,7 +350,19 @@ inline void lu_launch_np(int nsp, long n, const double* A, double gamma, double*
 inline int lu_launch(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
                      int mode, int cus, hipStream_t st)
 {
-    if (nsp < 1 || nsp > 64) return -1;
+    if (nsp < 1 || nsp > LU_MAX_LDS) return -1;
+    if (nsp > 64) {
+        const int ld = nsp | 1;
+        const size_t lds = sizeof(double) * ((size_t)ld * nsp + nsp + 4) + sizeof(int) * (4 + (size_t)nsp);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_lu_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+            attr_set = true;
+        }
+        long blocks = n < (long)cus * 4 ? n : (long)cus * 4;
+        hipLaunchKernelGGL(k_lu_lds, dim3((unsigned)blocks), dim3(256), lds, st, nsp, n, A, gamma, lu, perm, b, x, mode);
+        return 0;
+    }
     switch ((nsp + 7) / 8) {
     case 1: lu_launch_np<8>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
     case 2: lu_launch_np<16>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;

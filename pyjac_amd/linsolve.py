@@ -4,7 +4,8 @@ pj_lu_solve_dev, pj_newton_solve_dev; kernel: csrc/pj_lu.h).
 The consumer an implicit integrator puts behind ``eval_jacobian``: the reference hands one state's Jacobian
 to the caller's dense solver (docs/examples.rst:106-170) and has no batched form.  Blocks are pyJac's
 per-state C layout -- ``a[s, r + NSP*c]`` -- i.e. what ``Evaluator.jacobian(..., jac_layout=LAYOUT_AOS)``
-returns.  torch tensors carry the device memory; the work is the HIP kernel's.
+returns.  Blocks of up to 64 rows are factored in registers (a lane per row), up to 140 rows in LDS (a workgroup
+per block).  torch tensors carry the device memory; the work is the HIP kernel's.
 """
 import ctypes
 

@@ -41,14 +41,14 @@ def _scipy_perm(piv):
     return perm
 
 
-@pytest.mark.parametrize('nsp', [1, 2, 7, 8, 9, 10, 16, 24, 33, 48, 53, 56, 57, 64])
+@pytest.mark.parametrize('nsp', [1, 2, 7, 8, 9, 10, 16, 24, 33, 48, 53, 56, 57, 64, 65, 100, 111, 128, 129, 140])
 def test_lu_factor_matches_lapack(nsp, torch_cuda):
     """P A = L U with LAPACK's pivot rows; factors agree to rounding; also through I - gamma A."""
     import scipy.linalg
     from pyjac_amd import linsolve
     torch = torch_cuda
     rng = np.random.default_rng(100 + nsp)
-    n = 300 if nsp > 16 else 1000
+    n = 300 if nsp > 16 else 1000          # (65 rows and more: the LDS-resident kernel, a workgroup per block)
     a = _blocks(rng, n, nsp)
     for gamma in (0.0, 0.37):
         m = a if gamma == 0.0 else np.eye(nsp) - gamma * a
@@ -70,7 +70,7 @@ def test_lu_factor_matches_lapack(nsp, torch_cuda):
         assert worst < 1e-13 * nsp, (nsp, gamma, worst)
 
 
-@pytest.mark.parametrize('nsp', [1, 3, 10, 24, 53, 64])
+@pytest.mark.parametrize('nsp', [1, 3, 10, 24, 53, 64, 65, 111, 140])
 def test_solves_match_lapack(nsp, torch_cuda):
     """pj_lu_solve_dev on stored factors and the fused factor + solve agree with numpy.linalg.solve."""
     from pyjac_amd import linsolve
@@ -121,9 +121,9 @@ def test_edge_cases(torch_cuda):
     e = torch.empty((0, 100), dtype=torch.float64, device='cuda')
     lu, perm = linsolve.lu_factor(e)
     assert lu.shape == (0, 100) and perm.shape == (0, 10)
-    # more rows than lanes
+    # more rows than the LDS holds
     with pytest.raises(PyjacError):
-        linsolve.lu_factor(torch.zeros((2, 65 * 65), dtype=torch.float64, device='cuda'))
+        linsolve.lu_factor(torch.zeros((2, 141 * 141), dtype=torch.float64, device='cuda'))
     # a column of NaNs must not corrupt memory: permutation stays a permutation, neighbours untouched
     rng = np.random.default_rng(5)
     a = _blocks(rng, 3, 10)
@@ -139,7 +139,7 @@ def test_edge_cases(torch_cuda):
     assert np.allclose(x.cpu().numpy(), np.linalg.solve(z[0], [2.0, 4.0]))
 
 
-@pytest.mark.parametrize('name,n', [('h2o2_n2', 20000), ('gri30_shaped', 3000)])
+@pytest.mark.parametrize('name,n', [('h2o2_n2', 20000), ('gri30_shaped', 3000), ('usc2_shaped', 600)])
 def test_newton_step_on_jacobians(name, n, torch_cuda):
     """The consumer on real input: Jacobians of the mechanism in pyJac's per-state layout (AoS), Newton matrix
     I - gamma J with an implicit-step-sized gamma, residual of the solve against the matrix rebuilt on the host."""

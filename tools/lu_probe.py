@@ -7,7 +7,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from pyjac_amd import linsolve
 
-cases = [tuple(int(v) for v in a.split(':')) for a in sys.argv[1:]] or [(10, 1000000), (24, 1000000), (53, 1000000), (64, 500000)]
+cases = [tuple(int(v) for v in a.split(':')) for a in sys.argv[1:]] or [(10, 1000000), (24, 1000000), (53, 1000000), (64, 500000), (111, 200000)]
 for nsp, n in cases:
     g = torch.Generator(device='cuda').manual_seed(1)
     a = torch.randn((n, nsp * nsp), dtype=torch.float64, device='cuda', generator=g)
