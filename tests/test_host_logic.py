@@ -81,6 +81,28 @@ def test_product_fails_loudly_without_gpu():
         pyjacob.py_dydt(0.0, 101325.0, np.ones(10), np.zeros(10))
 
 
+def test_linsolve_argument_checks_and_no_cpu_fallback():
+    """pyjac_amd.linsolve (batched LU consumer): shapes, dtypes and devices are refused before a raw pointer reaches
+    the C ABI, and without a HIP device the entry points fail loudly (no host fallback)."""
+    import ctypes as ct
+    import torch
+    from pyjac_amd import PyjacError, _lib, linsolve
+    with pytest.raises(ValueError):
+        linsolve.lu_factor(torch.zeros((4, 9), dtype=torch.float64))            # not on the device
+    with pytest.raises(ValueError):
+        linsolve._blocks(torch.zeros((4, 10), dtype=torch.float64))             # not a device tensor either
+    L = _lib.lib()
+    if not torch.cuda.is_available():
+        buf = (ct.c_double * 16)()
+        prm = (ct.c_int * 4)()
+        rc = L.pj_lu_factor_dev(4, 1, ct.cast(buf, ct.c_void_p), 0.0, ct.cast(buf, ct.c_void_p), ct.cast(prm, ct.c_void_p), None)
+        assert rc == -2                                                          # PJ_ENODEV
+        with pytest.raises(PyjacError):
+            _lib.check(rc)
+    assert L.pj_lu_factor_dev(141, 1, None, 0.0, None, None, None) != 0          # bad arguments never reach a launch
+    assert L.pj_lu_factor_dev(4, 0, None, 0.0, None, None, None) == 0            # empty batch
+
+
 def test_product_package_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, 'pyjac_amd')):
         for f in files:
