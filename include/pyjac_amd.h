@@ -154,8 +154,8 @@ int pj_eval_fd_jacobian_dev(pj_mech* m, long n, const double* d_pres, const doub
  * pyJac hands one state's Jacobian to the caller's dense solver (docs/examples.rst:106-170: the per-state
  * integrator loop); there is no batched form in the reference -- these entry points take the blocks where
  * pj_eval_jacobian_dev(..., PJ_LAYOUT_AOS) leaves them: state-major, each block column-major
- * (a[s*NSP*NSP + r + NSP*c], pyJac's per-state C layout).  NSP <= 64: one wavefront per block, one lane per row,
- * the block in registers; 65 <= NSP <= 140: one workgroup per block, the block in LDS (PJ_EUNSUPPORTED beyond).  gamma != 0: the matrix factored is I - gamma * A (the Newton matrix of an implicit
+ * (a[s*NSP*NSP + r + NSP*c], pyJac's per-state C layout).  NSP <= 16: four blocks per wavefront; NSP <= 64: one
+ * wavefront per block -- a lane per row, the block in registers; 65 <= NSP <= 140: one workgroup per block, the block in LDS (PJ_EUNSUPPORTED beyond).  gamma != 0: the matrix factored is I - gamma * A (the Newton matrix of an implicit
  * step); gamma == 0: A itself.  Partial pivoting (first row of maximum magnitude, as LAPACK dgetf2); the
  * result is P A = L U with L unit lower triangular below the diagonal of d_lu, U on and above it, and
  * d_perm[s*NSP + k] = the row of A that became row k.  A singular block yields non-finite factors (no info

@@ -337,6 +337,148 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
     }
 }
 
+// ---- blocks of up to 16 rows: four blocks per wavefront ---------------------------------------------------------
+// A 10 x 10 block (the H2-size mechanisms) leaves 54 of k_lu's 64 lanes idle.  k_lu16 gives every block one DPP row
+// of 16 lanes: lane = 16 g + i holds row i of block g, the pivot is a maximum over the row of lanes (four DPP
+// rotations: every lane ends up with it), the first lane that holds it comes out of the ballot's 16-bit field of the
+// group, and the pivot row travels through the LDS crossbar (ds_bpermute_b32 with a per-lane source: each group
+// reads its own pivot lane).  Same (lu, perm) results as k_lu.
+template <int CTRL>
+__device__ __forceinline__ double lu_dpp_rot_max(const double v)
+{
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)u, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(u >> 32), (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    const double o = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
+    return r;
+}
+// first lane of this lane's group of 16 for which `pred` holds (garbage if none does)
+__device__ __forceinline__ int lu_group_first(const bool pred, const int lane)
+{
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+    const unsigned f = (unsigned)(m >> (lane & 48)) & 0xffffu;
+    return (lane & 48) + (int)__builtin_ctz(f | 0x10000u);
+}
+
+template <int NP>      // 8 or 16
+__global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const double* A, const double gamma, double* lu,
+                                              int* __restrict__ perm, const double* __restrict__ b, double* __restrict__ x,
+                                              const int mode)
+{
+    const int lane0 = (int)(threadIdx.x & 63);
+    const long nw = (long)gridDim.x * 4;
+    const long ne = (long)nsp * nsp;
+    const int nsp0 = nsp;
+    const bool pre = (mode & LU_PREFACTORED) != 0, solve = (mode & LU_SOLVE) != 0;
+    for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w * 4 < n; w += nw) {
+        int nsp = nsp0, lane = lane0;
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        const int i = lane & 15;
+        const long s = w * 4 + (lane >> 4);
+        const bool act = i < nsp && s < n;
+        const long sc = s < n ? s : n - 1;               // clamped: loads are unconditional
+        const int ic = i < nsp ? i : nsp - 1;
+        const double* As = (pre ? lu : A) + sc * ne;
+        double a[NP];
+        lu_for<0, NP>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            a[j] = As[ic + (long)nsp * (j < nsp ? j : nsp - 1)];
+        });
+        {
+            const bool newton = !pre && gamma != 0.0;
+            const double scl = newton ? -gamma : 1.0, sh = newton ? 1.0 : 0.0;
+            lu_for<0, NP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const double id = (j == i) ? 1.0 : 0.0;
+                a[j] = (act && j < nsp) ? __builtin_fma(scl, a[j], sh * id) : id;
+            });
+        }
+        int pos = pre ? i : -1;
+        double bb = 0.0, myinv = 1.0;
+        if (solve) bb = act ? b[sc * nsp + (pre ? perm[sc * nsp + i] : i)] : 0.0;
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        if (!pre) {
+            lu_for<0, NP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k < nsp) {
+                    const bool open = pos < 0 && act;
+                    double mx = open ? fabs(a[k]) : -1.0;
+                    const double cand = mx;
+                    mx = lu_dpp_rot_max<0x121>(mx);      // row_ror:1, 2, 4, 8: the maximum of the 16 lanes, in all of them
+                    mx = lu_dpp_rot_max<0x122>(mx);
+                    mx = lu_dpp_rot_max<0x124>(mx);
+                    mx = lu_dpp_rot_max<0x128>(mx);
+                    int p = lu_group_first(open && cand == mx, lane);
+                    const int p_any = lu_group_first(open, lane);
+                    if ((p & 15) >= nsp || p > (lane | 15)) p = p_any;        // a column of NaNs: any open row of the group
+                    p = p > 63 ? lane : p;                                     // (a group without blocks: harmless values)
+                    if (lane == p) pos = k;
+                    const int src = p * 4;
+                    const double ukk = lu_bpermute(a[k], src);
+                    const double inv = lu_rcp(ukk);
+                    if (lane == p) myinv = inv;
+                    const bool below = pos < 0;
+                    const double l = below ? a[k] * inv : 0.0;
+                    if (below) a[k] = l;
+                    lu_for<k + 1, NP>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const double ukj = lu_bpermute(a[j], src);
+                        a[j] = __builtin_fma(-l, ukj, a[j]);
+                    });
+                    if (solve) {
+                        const double yk = lu_bpermute(bb, src);
+                        bb = __builtin_fma(-l, yk, bb);
+                    }
+                }
+            });
+        } else if (solve) {
+            lu_for<0, NP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k < nsp) {
+                    const double yk = lu_bpermute(bb, ((lane & 48) + k) * 4);
+                    if (i > k) bb = __builtin_fma(-a[k], yk, bb);
+                }
+            });
+        }
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        if (!pre && lu != nullptr && act) {
+            double* Ls = lu + s * ne;
+            lu_for<0, NP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j < nsp) Ls[pos + (long)nsp * j] = a[j];
+            });
+            if (perm != nullptr) perm[s * nsp + pos] = i;
+        }
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        if (solve) {
+            lu_for<0, NP>([&](auto kr) {
+                constexpr int k = NP - 1 - decltype(kr)::value;
+                if (k < nsp) {
+                    int p = lu_group_first(pos == k, lane);
+                    p = p > 63 ? lane : p;
+                    if (pre) myinv = lu_rcp(a[k]);
+                    const double xk = lu_bpermute(lu_div(bb, a[k], myinv), p * 4);
+                    if (pos == k) bb = xk;
+                    else if (pos < k && pos >= 0) bb = __builtin_fma(-a[k], xk, bb);
+                }
+            });
+            if (act) x[s * nsp + pos] = bb;
+        }
+    }
+}
+
+template <int NP>
+inline void lu_launch16(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
+                        int mode, int cus, hipStream_t st)
+{
+    long blocks = (n + 15) / 16;            // four wavefronts of four blocks per workgroup
+    const long cap = (long)cus * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_lu16<NP>, dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, gamma, lu, perm, b, x, mode);
+}
+
 template <int NP>
 inline void lu_launch_np(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
                          int mode, int cus, hipStream_t st)
@@ -364,8 +506,8 @@ inline int lu_launch(int nsp, long n, const double* A, double gamma, double* lu,
         return 0;
     }
     switch ((nsp + 7) / 8) {
-    case 1: lu_launch_np<8>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 2: lu_launch_np<16>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 1: lu_launch16<8>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 2: lu_launch16<16>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
     case 3: lu_launch_np<24>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
     case 4: lu_launch_np<32>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
     case 5: lu_launch_np<40>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
