@@ -153,20 +153,25 @@ int pj_eval_fd_jacobian_dev(pj_mech* m, long n, const double* d_pres, const doub
 /* ---- batched LU and Newton solves on per-state NSP x NSP blocks (the "batched LU" consumer).
  * pyJac hands one state's Jacobian to the caller's dense solver (docs/examples.rst:106-170: the per-state
  * integrator loop); there is no batched form in the reference -- these entry points take the blocks where
- * pj_eval_jacobian_dev(..., PJ_LAYOUT_AOS) leaves them: state-major, each block column-major
- * (a[s*NSP*NSP + r + NSP*c], pyJac's per-state C layout).  NSP <= 16: four blocks per wavefront; NSP <= 64: one
+ * pj_eval_jacobian_dev leaves them: a_layout = PJ_LAYOUT_AOS: state-major, each block column-major
+ * (a[s*NSP*NSP + r + NSP*c], pyJac's per-state C layout); PJ_LAYOUT_SOA: a[(r + NSP*c)*n + s], pyJac's batch layout
+ * (the one the row-block kernels write at full speed).  Factors (d_lu, d_perm) are always per state.  NSP <= 16: four blocks per wavefront; NSP <= 64: one
  * wavefront per block -- a lane per row, the block in registers; 65 <= NSP <= 140: one workgroup per block, the block in LDS (PJ_EUNSUPPORTED beyond).  gamma != 0: the matrix factored is I - gamma * A (the Newton matrix of an implicit
  * step); gamma == 0: A itself.  Partial pivoting (first row of maximum magnitude, as LAPACK dgetf2); the
  * result is P A = L U with L unit lower triangular below the diagonal of d_lu, U on and above it, and
  * d_perm[s*NSP + k] = the row of A that became row k.  A singular block yields non-finite factors (no info
- * array).  d_lu may alias d_a.  Device pointers, asynchronous on `stream`. */
-int pj_lu_factor_dev(int nsp, long n, const double* d_a, double gamma, double* d_lu, int* d_perm, void* stream);
-/* x_s = A_s^-1 b_s from the factors: d_b, d_x are [n][NSP] (state-major); d_x may alias d_b */
-int pj_lu_solve_dev(int nsp, long n, const double* d_lu, const int* d_perm, const double* d_b, double* d_x, void* stream);
+ * array).  d_lu may alias d_a (per-state layout only).  Device pointers, asynchronous on `stream`. */
+int pj_lu_factor_dev(int nsp, long n, const double* d_a, int a_layout, double gamma, double* d_lu, int* d_perm, void* stream);
+/* x_s = A_s^-1 b_s from the factors: d_b, d_x in vec_layout ([n][NSP] per state, or [NSP][n] state-fastest like y);
+ * d_x may alias d_b */
+int pj_lu_solve_dev(int nsp, long n, const double* d_lu, const int* d_perm, const double* d_b, double* d_x, int vec_layout,
+                    void* stream);
 /* factor and solve in one pass over the blocks: x_s = (I - gamma A_s)^-1 b_s (or A_s^-1 b_s); the factors stay in
- * registers and are written only if d_lu / d_perm are given (both or neither) */
-int pj_newton_solve_dev(int nsp, long n, const double* d_a, double gamma, const double* d_b, double* d_x, double* d_lu,
-                        int* d_perm, void* stream);
+ * registers and are written only if d_lu / d_perm are given (both or neither).  With a_layout = vec_layout =
+ * PJ_LAYOUT_SOA this is the Newton step straight from what pj_eval_jacobian_dev(..., PJ_LAYOUT_SOA) wrote -- no
+ * transposed copy of the Jacobians is ever made. */
+int pj_newton_solve_dev(int nsp, long n, const double* d_a, int a_layout, double gamma, const double* d_b, double* d_x,
+                        int vec_layout, double* d_lu, int* d_perm, void* stream);
 
 /* Launch the Jacobian kernel `iters` times on `stream` bracketed by HIP events
  * recorded on that stream; *ms_per_launch receives the average. */

@@ -45,9 +45,10 @@ SIGNATURES = {
     'pj_mech_attach_spec': (ctypes.c_int, [_vp, ctypes.c_char_p]),
     'pj_mech_has_spec': (ctypes.c_int, [_vp]),
     'pj_mech_use_spec': (ctypes.c_int, [_vp, ctypes.c_int]),
-    'pj_lu_factor_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_long, _vp, ctypes.c_double, _vp, _vp, _vp]),
-    'pj_lu_solve_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
-    'pj_newton_solve_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_long, _vp, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
+    'pj_lu_factor_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_long, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp, _vp]),
+    'pj_lu_solve_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_long, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
+    'pj_newton_solve_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_long, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp,
+                                           ctypes.c_int, _vp, _vp, _vp]),
     'pj_mech_set_spec_launch': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int]),
     'pj_eval_jacobian_dev': (ctypes.c_int, [_vp, ctypes.c_long, _vp, _vp, ctypes.c_int, _vp,
                                             ctypes.c_int, _vp]),

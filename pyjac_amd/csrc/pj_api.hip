@@ -962,34 +962,41 @@ static int lu_cus()
     }
     return cus;
 }
-static int lu_call(int nsp, long n, const double* a, double gamma, double* lu, int* perm, const double* b, double* x, int mode,
-                   void* stream)
+static int lu_call(int nsp, long n, const double* a, int a_layout, double gamma, double* lu, int* perm, const double* b, double* x,
+                   int vec_layout, int mode, void* stream)
 {
     if (n < 0 || nsp < 1) return fail(PJ_EINVAL, "bad argument");
+    if ((a_layout != PJ_LAYOUT_SOA && a_layout != PJ_LAYOUT_AOS) || (vec_layout != PJ_LAYOUT_SOA && vec_layout != PJ_LAYOUT_AOS))
+        return fail(PJ_EINVAL, "layout: PJ_LAYOUT_SOA or PJ_LAYOUT_AOS");
     if (nsp > pj::LU_MAX_LDS) return fail(PJ_EUNSUPPORTED, "batched LU: at most 140 rows (the block has to fit the LDS)");
     if (n == 0) return PJ_OK;
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(PJ_ENODEV, "no HIP device");
-    if (pj::lu_launch(nsp, n, a, gamma, lu, perm, b, x, mode, lu_cus(), (hipStream_t)stream)) return fail(PJ_EHIP, "batched LU launch failed");
+    pj::LuLay Y;
+    set_layout(n, nsp * nsp, a_layout, &Y.a_si, &Y.a_ss);
+    set_layout(n, nsp, vec_layout, &Y.v_si, &Y.v_ss);
+    if (pj::lu_launch(nsp, n, a, Y, gamma, lu, perm, b, x, mode, lu_cus(), (hipStream_t)stream)) return fail(PJ_EHIP, "batched LU launch failed");
     return hipGetLastError() == hipSuccess ? PJ_OK : fail(PJ_EHIP, "batched LU launch failed");
 }
-int pj_lu_factor_dev(int nsp, long n, const double* d_a, double gamma, double* d_lu, int* d_perm, void* stream)
+int pj_lu_factor_dev(int nsp, long n, const double* d_a, int a_layout, double gamma, double* d_lu, int* d_perm, void* stream)
 {
     if (n > 0 && (!d_a || !d_lu || !d_perm)) return fail(PJ_EINVAL, "null device pointer");
-    return lu_call(nsp, n, d_a, gamma, d_lu, d_perm, nullptr, nullptr, pj::LU_FACTOR, stream);
+    if (d_a == d_lu && a_layout != PJ_LAYOUT_AOS) return fail(PJ_EINVAL, "in-place factorisation needs the per-state layout");
+    return lu_call(nsp, n, d_a, a_layout, gamma, d_lu, d_perm, nullptr, nullptr, PJ_LAYOUT_AOS, pj::LU_FACTOR, stream);
 }
-int pj_lu_solve_dev(int nsp, long n, const double* d_lu, const int* d_perm, const double* d_b, double* d_x, void* stream)
+int pj_lu_solve_dev(int nsp, long n, const double* d_lu, const int* d_perm, const double* d_b, double* d_x, int vec_layout,
+                    void* stream)
 {
     if (n > 0 && (!d_lu || !d_perm || !d_b || !d_x)) return fail(PJ_EINVAL, "null device pointer");
-    return lu_call(nsp, n, nullptr, 0.0, const_cast<double*>(d_lu), const_cast<int*>(d_perm), d_b, d_x,
+    return lu_call(nsp, n, nullptr, PJ_LAYOUT_AOS, 0.0, const_cast<double*>(d_lu), const_cast<int*>(d_perm), d_b, d_x, vec_layout,
                    pj::LU_PREFACTORED | pj::LU_SOLVE, stream);
 }
-int pj_newton_solve_dev(int nsp, long n, const double* d_a, double gamma, const double* d_b, double* d_x, double* d_lu,
-                        int* d_perm, void* stream)
+int pj_newton_solve_dev(int nsp, long n, const double* d_a, int a_layout, double gamma, const double* d_b, double* d_x,
+                        int vec_layout, double* d_lu, int* d_perm, void* stream)
 {
     if (n > 0 && (!d_a || !d_b || !d_x)) return fail(PJ_EINVAL, "null device pointer");
     if ((d_lu == nullptr) != (d_perm == nullptr)) return fail(PJ_EINVAL, "d_lu and d_perm: both or neither");
-    return lu_call(nsp, n, d_a, gamma, d_lu, d_perm, d_b, d_x, pj::LU_FACTOR | pj::LU_SOLVE, stream);
+    return lu_call(nsp, n, d_a, a_layout, gamma, d_lu, d_perm, d_b, d_x, vec_layout, pj::LU_FACTOR | pj::LU_SOLVE, stream);
 }
 
 int pj_time_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,

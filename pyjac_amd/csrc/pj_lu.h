@@ -94,21 +94,28 @@ __device__ __forceinline__ double lu_wave_max(double v)
 }
 
 enum { LU_FACTOR = 1, LU_SOLVE = 2, LU_PREFACTORED = 4 };
+// where the input blocks and the vectors live: entry (r, c) of block s at a[(r + NSP c) * a_si + s * a_ss], entry i of
+// vector s at v[i * v_si + s * v_ss] -- pyJac's per-state layout (a_si = 1, a_ss = NSP^2; v_si = 1, v_ss = NSP) or the
+// state-fastest batch layout the row kernels write (a_si = n, a_ss = 1; v_si = n, v_ss = 1).  Factors are always
+// written / read per state (P A = L U blocks are consumed by these kernels only).
+struct LuLay { long a_si, a_ss, v_si, v_ss; };
 
 // NP: NSP rounded up to a multiple of 8 (rows / columns beyond NSP are the identity's: they are never pivots of a
 // real column and contribute zeros).  mode: LU_FACTOR (A -> lu, perm), LU_FACTOR | LU_SOLVE (A, b -> x, and lu / perm
 // if given), LU_PREFACTORED | LU_SOLVE (lu, perm, b -> x).  gamma != 0: the matrix is I - gamma A (the Newton
 // matrix of an implicit step).
 template <int NP>
-__global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const double* A, const double gamma,
+__global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const double* A, const LuLay Y, const double gamma,
                                             double* lu, int* __restrict__ perm, const double* __restrict__ b,
                                             double* __restrict__ x, const int mode)
 {
     const int lane = (int)(threadIdx.x & 63);
-    const long nw = (long)gridDim.x * 4;
     const long ne = (long)nsp * nsp;
     const int lane0 = lane, nsp0 = nsp;
-    for (long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6); s < n; s += nw) {
+    // a workgroup takes runs of 16 consecutive blocks (its four wavefronts, four rounds each, then the next run): in
+    // the batch layout the 16 states of a 128-byte line are then read by one workgroup, i.e. through one L2
+    for (long s = (long)blockIdx.x * 16 + (threadIdx.x >> 6); s < n + 12; s += (s & 15) < 12 ? 4 : (long)gridDim.x * 16 - 12) {
+        if (s >= n) continue;
         // Every predicate of the body (j < nsp, lane == j, lane > k ...) is invariant across matrices, and the
         // optimiser knows: it computes hundreds of lane masks once, in front of the loop, and spills them.  Opaque
         // copies of `nsp` and `lane` per phase keep each predicate next to its use.
@@ -116,14 +123,16 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
         asm volatile("" : "+s"(nsp), "+v"(lane));
         const bool act = lane < nsp;
         double a[NP];
-        const double* As = ((mode & LU_PREFACTORED) ? lu : A) + s * ne;
+        const bool pre_ = (mode & LU_PREFACTORED) != 0;
+        const long a_si = pre_ ? 1 : Y.a_si;
+        const double* As = pre_ ? lu + s * ne : A + s * Y.a_ss;
         // every load is issued before anything depends on one (clamped, always valid addresses instead of
         // predicates: a branch per column would serialise 53 memory round trips); the identity padding and the Newton
         // matrix I - gamma A are applied afterwards, branch-free
         const int lane_c = lane < nsp ? lane : nsp - 1;
         lu_for<0, NP>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            a[j] = As[lane_c + (long)nsp * (j < nsp ? j : nsp - 1)];
+            a[j] = As[(lane_c + (long)nsp * (j < nsp ? j : nsp - 1)) * a_si];
         });
         {
             const bool newton = !(mode & LU_PREFACTORED) && gamma != 0.0;
@@ -138,8 +147,8 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
         int pos = (mode & LU_PREFACTORED) ? lane : -1;
         double bb = 0.0, myinv = 1.0;             // myinv: 1 / u_kk in the lane whose row became row k
         if (mode & LU_SOLVE) {
-            if (mode & LU_PREFACTORED) bb = act ? b[s * nsp + perm[s * nsp + lane]] : 0.0;
-            else bb = act ? b[s * nsp + lane] : 0.0;
+            if (mode & LU_PREFACTORED) bb = act ? b[perm[s * nsp + lane] * Y.v_si + s * Y.v_ss] : 0.0;
+            else bb = act ? b[lane * Y.v_si + s * Y.v_ss] : 0.0;
         }
         asm volatile("" : "+s"(nsp), "+v"(lane));
         if (!(mode & LU_PREFACTORED)) {
@@ -212,7 +221,7 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
                     else if (pos < k && pos >= 0) bb = __builtin_fma(-a[k], xk, bb);
                 }
             });
-            if (act) x[s * nsp + pos] = bb;
+            if (act) x[pos * Y.v_si + s * Y.v_ss] = bb;
         }
     }
 }
@@ -226,8 +235,8 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
 // same (lu, perm) convention as k_lu; latency-bound by its ~4 barriers per column.
 constexpr int LU_MAX_LDS = 140;        // (140 | 1) * 140 + 3 * 140 doubles = 159 KB of the 160 KB
 
-__global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, const double* A, const double gamma, double* lu,
-                                                int* __restrict__ perm, const double* __restrict__ b,
+__global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, const double* A, const LuLay Y, const double gamma,
+                                                double* lu, int* __restrict__ perm, const double* __restrict__ b,
                                                 double* __restrict__ x, const int mode)
 {
     extern __shared__ double lds_lu[];
@@ -240,12 +249,17 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long ne = (long)nsp * nsp;
     const bool pre = (mode & LU_PREFACTORED) != 0, solve = (mode & LU_SOLVE) != 0;
-    for (long s = blockIdx.x; s < n; s += gridDim.x) {
-        const double* As = (pre ? lu : A) + s * ne;
+    // workgroups b, b + 8, ... b + 120 sit on one XCD (round-robin dispatch) and take 16 consecutive blocks: in the
+    // batch layout a 128-byte line of 16 states is fetched into one L2 instead of eight
+    for (long t = blockIdx.x; t < ((n + 127) / 128) * 128; t += gridDim.x) {
+        const long s = (t / 128) * 128 + 16 * (t % 8) + (t % 128) / 8;
+        if (s >= n) continue;                            // (uniform in the workgroup)
+        const long a_si = pre ? 1 : Y.a_si;
+        const double* As = pre ? lu + s * ne : A + s * Y.a_ss;
         const bool newton = !pre && gamma != 0.0;
         for (int idx = tid; idx < (int)ne; idx += 256) {
             const int r = idx % nsp, c = idx / nsp;
-            double v = As[idx];
+            double v = As[idx * a_si];
             if (newton) v = (r == c ? 1.0 : 0.0) - gamma * v;
             M[c * ld + r] = v;
         }
@@ -253,7 +267,7 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
             pm[tid] = pre ? perm[s * nsp + tid] : tid;
         }
         __syncthreads();
-        if (solve && tid < nsp) bv[tid] = b[s * nsp + (pre ? pm[tid] : tid)];
+        if (solve && tid < nsp) bv[tid] = b[(pre ? pm[tid] : tid) * Y.v_si + s * Y.v_ss];
         __syncthreads();
         if (!pre) {
             for (int k = 0; k < nsp; ++k) {
@@ -331,7 +345,7 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
                 else if (tid < k) bv[tid] = __builtin_fma(-M[k * ld + tid], xk, bv[tid]);
                 __syncthreads();
             }
-            if (tid < nsp) x[s * nsp + tid] = bv[tid];
+            if (tid < nsp) x[tid * Y.v_si + s * Y.v_ss] = bv[tid];
         }
         __syncthreads();
     }
@@ -363,9 +377,9 @@ __device__ __forceinline__ int lu_group_first(const bool pred, const int lane)
 }
 
 template <int NP>      // 8 or 16
-__global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const double* A, const double gamma, double* lu,
-                                              int* __restrict__ perm, const double* __restrict__ b, double* __restrict__ x,
-                                              const int mode)
+__global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const double* A, const LuLay Y, const double gamma,
+                                              double* lu, int* __restrict__ perm, const double* __restrict__ b,
+                                              double* __restrict__ x, const int mode)
 {
     const int lane0 = (int)(threadIdx.x & 63);
     const long nw = (long)gridDim.x * 4;
@@ -380,11 +394,12 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
         const bool act = i < nsp && s < n;
         const long sc = s < n ? s : n - 1;               // clamped: loads are unconditional
         const int ic = i < nsp ? i : nsp - 1;
-        const double* As = (pre ? lu : A) + sc * ne;
+        const long a_si = pre ? 1 : Y.a_si;
+        const double* As = pre ? lu + sc * ne : A + sc * Y.a_ss;
         double a[NP];
         lu_for<0, NP>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            a[j] = As[ic + (long)nsp * (j < nsp ? j : nsp - 1)];
+            a[j] = As[(ic + (long)nsp * (j < nsp ? j : nsp - 1)) * a_si];
         });
         {
             const bool newton = !pre && gamma != 0.0;
@@ -397,7 +412,7 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
         }
         int pos = pre ? i : -1;
         double bb = 0.0, myinv = 1.0;
-        if (solve) bb = act ? b[sc * nsp + (pre ? perm[sc * nsp + i] : i)] : 0.0;
+        if (solve) bb = act ? b[(pre ? perm[sc * nsp + ic] : ic) * Y.v_si + sc * Y.v_ss] : 0.0;
         asm volatile("" : "+s"(nsp), "+v"(lane));
         if (!pre) {
             lu_for<0, NP>([&](auto kc) {
@@ -464,32 +479,32 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
                     else if (pos < k && pos >= 0) bb = __builtin_fma(-a[k], xk, bb);
                 }
             });
-            if (act) x[s * nsp + pos] = bb;
+            if (act) x[pos * Y.v_si + s * Y.v_ss] = bb;
         }
     }
 }
 
 template <int NP>
-inline void lu_launch16(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
+inline void lu_launch16(int nsp, long n, const double* A, LuLay Y, double gamma, double* lu, int* perm, const double* b, double* x,
                         int mode, int cus, hipStream_t st)
 {
     long blocks = (n + 15) / 16;            // four wavefronts of four blocks per workgroup
     const long cap = (long)cus * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_lu16<NP>, dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, gamma, lu, perm, b, x, mode);
+    hipLaunchKernelGGL(k_lu16<NP>, dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
 }
 
 template <int NP>
-inline void lu_launch_np(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
+inline void lu_launch_np(int nsp, long n, const double* A, LuLay Y, double gamma, double* lu, int* perm, const double* b, double* x,
                          int mode, int cus, hipStream_t st)
 {
-    long blocks = (n + 3) / 4;
+    long blocks = (n + 15) / 16;            // runs of 16 blocks per workgroup
     const long cap = (long)cus * 8;         // grid-stride beyond a few workgroups per CU
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_lu<NP>, dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, gamma, lu, perm, b, x, mode);
+    hipLaunchKernelGGL(k_lu<NP>, dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
 }
 
-inline int lu_launch(int nsp, long n, const double* A, double gamma, double* lu, int* perm, const double* b, double* x,
+inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, double* lu, int* perm, const double* b, double* x,
                      int mode, int cus, hipStream_t st)
 {
     if (nsp < 1 || nsp > LU_MAX_LDS) return -1;
@@ -501,19 +516,20 @@ inline int lu_launch(int nsp, long n, const double* A, double gamma, double* lu,
             if (hipFuncSetAttribute((const void*)k_lu_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
             attr_set = true;
         }
-        long blocks = n < (long)cus * 4 ? n : (long)cus * 4;
-        hipLaunchKernelGGL(k_lu_lds, dim3((unsigned)blocks), dim3(256), lds, st, nsp, n, A, gamma, lu, perm, b, x, mode);
+        const long slots = (n + 127) / 128 * 128;
+        long blocks = slots < (long)cus * 4 ? slots : (long)cus * 4;
+        hipLaunchKernelGGL(k_lu_lds, dim3((unsigned)blocks), dim3(256), lds, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
         return 0;
     }
     switch ((nsp + 7) / 8) {
-    case 1: lu_launch16<8>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 2: lu_launch16<16>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 3: lu_launch_np<24>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 4: lu_launch_np<32>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 5: lu_launch_np<40>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 6: lu_launch_np<48>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 7: lu_launch_np<56>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
-    default: lu_launch_np<64>(nsp, n, A, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 1: lu_launch16<8>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 2: lu_launch16<16>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 3: lu_launch_np<24>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 4: lu_launch_np<32>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 5: lu_launch_np<40>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 6: lu_launch_np<48>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 7: lu_launch_np<56>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    default: lu_launch_np<64>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
     }
     return 0;
 }

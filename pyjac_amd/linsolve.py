@@ -18,58 +18,73 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _blocks(a, name='a'):
+def _blocks(a, name='a', layout=None):
+    """(n, NSP) of a batch of blocks: (n, NSP*NSP) per state (LAYOUT_AOS) or (NSP*NSP, n) state-fastest (LAYOUT_SOA)."""
     import torch
+    from ._lib import LAYOUT_SOA
     if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.float64 and a.is_contiguous() and a.dim() == 2):
-        raise ValueError('%s: expected a contiguous float64 CUDA tensor of shape (n, NSP*NSP)' % name)
-    nsp = int(round(a.shape[1] ** 0.5))
-    if nsp * nsp != a.shape[1]:
-        raise ValueError('%s: second dimension is not a square' % name)
-    return a.shape[0], nsp
+        raise ValueError('%s: expected a contiguous 2-D float64 CUDA tensor' % name)
+    n, ne = (a.shape[1], a.shape[0]) if layout == LAYOUT_SOA else (a.shape[0], a.shape[1])
+    nsp = int(round(ne ** 0.5))
+    if nsp * nsp != ne:
+        raise ValueError('%s: the block dimension is not a square' % name)
+    return n, nsp
 
 
-def _vectors(b, n, nsp, device, name):
+def _vectors(b, n, nsp, device, name, layout=None):
     import torch
+    from ._lib import LAYOUT_SOA
+    shape = (nsp, n) if layout == LAYOUT_SOA else (n, nsp)
     if not (isinstance(b, torch.Tensor) and b.is_cuda and b.dtype == torch.float64 and b.is_contiguous() and
-            tuple(b.shape) == (n, nsp) and b.device == device):
-        raise ValueError('%s: expected a contiguous float64 CUDA tensor of shape (%d, %d) on %s' % (name, n, nsp, device))
+            tuple(b.shape) == shape and b.device == device):
+        raise ValueError('%s: expected a contiguous float64 CUDA tensor of shape %s on %s' % (name, shape, device))
 
 
-def lu_factor(a, gamma: float = 0.0, overwrite: bool = False):
-    """P A = L U (or of I - gamma A) for every block; returns (lu, perm): lu like a (L unit lower below the
-    diagonal, U on and above), perm (n, NSP) int32 with perm[s, k] = the row of A that became row k."""
+def lu_factor(a, gamma: float = 0.0, overwrite: bool = False, layout: int = None):
+    """P A = L U (or of I - gamma A) for every block; a: (n, NSP*NSP) per state, or (NSP*NSP, n) with
+    layout=LAYOUT_SOA.  Returns (lu, perm): lu (n, NSP*NSP) per state (L unit lower below the diagonal, U on and
+    above), perm (n, NSP) int32 with perm[s, k] = the row of A that became row k."""
     import torch
-    n, nsp = _blocks(a)
-    lu = a if overwrite else torch.empty_like(a)
+    from ._lib import LAYOUT_AOS, LAYOUT_SOA
+    layout = LAYOUT_AOS if layout is None else layout
+    n, nsp = _blocks(a, 'a', layout)
+    if overwrite and layout == LAYOUT_SOA:
+        raise ValueError('in-place factorisation needs the per-state layout')
+    lu = a if overwrite else torch.empty((n, nsp * nsp), dtype=torch.float64, device=a.device)
     perm = torch.empty((n, nsp), dtype=torch.int32, device=a.device)
-    check(_lib.lib().pj_lu_factor_dev(nsp, n, a.data_ptr(), float(gamma), lu.data_ptr(), perm.data_ptr(), _stream()))
+    check(_lib.lib().pj_lu_factor_dev(nsp, n, a.data_ptr(), layout, float(gamma), lu.data_ptr(), perm.data_ptr(), _stream()))
     return lu, perm
 
 
-def lu_solve(lu, perm, b, out=None):
-    """x_s = A_s^-1 b_s from lu_factor's result; b: (n, NSP)."""
+def lu_solve(lu, perm, b, out=None, layout: int = None):
+    """x_s = A_s^-1 b_s from lu_factor's result; b: (n, NSP), or (NSP, n) with layout=LAYOUT_SOA."""
     import torch
+    from ._lib import LAYOUT_AOS
+    layout = LAYOUT_AOS if layout is None else layout
     n, nsp = _blocks(lu, 'lu')
-    _vectors(b, n, nsp, lu.device, 'b')
+    _vectors(b, n, nsp, lu.device, 'b', layout)
     if not (perm.is_cuda and perm.dtype == torch.int32 and perm.is_contiguous() and tuple(perm.shape) == (n, nsp)):
         raise ValueError('perm: expected lu_factor\'s int32 (n, NSP) tensor')
     x = torch.empty_like(b) if out is None else out
-    _vectors(x, n, nsp, lu.device, 'out')
-    check(_lib.lib().pj_lu_solve_dev(nsp, n, lu.data_ptr(), perm.data_ptr(), b.data_ptr(), x.data_ptr(), _stream()))
+    _vectors(x, n, nsp, lu.device, 'out', layout)
+    check(_lib.lib().pj_lu_solve_dev(nsp, n, lu.data_ptr(), perm.data_ptr(), b.data_ptr(), x.data_ptr(), layout, _stream()))
     return x
 
 
-def newton_solve(a, b, gamma: float = 0.0, out=None, keep_factors: bool = False):
+def newton_solve(a, b, gamma: float = 0.0, out=None, keep_factors: bool = False, layout: int = None):
     """x_s = (I - gamma A_s)^-1 b_s (gamma = 0: A_s^-1 b_s) in one pass over the blocks; the factors stay in
-    registers unless keep_factors (then returns (x, lu, perm))."""
+    registers unless keep_factors (then returns (x, lu, perm)).  layout=LAYOUT_SOA: a is (NSP*NSP, n) and b, x are
+    (NSP, n) -- what Evaluator.jacobian returns by default: the Newton step without a transposed copy."""
     import torch
-    n, nsp = _blocks(a)
-    _vectors(b, n, nsp, a.device, 'b')
+    from ._lib import LAYOUT_AOS
+    layout = LAYOUT_AOS if layout is None else layout
+    n, nsp = _blocks(a, 'a', layout)
+    _vectors(b, n, nsp, a.device, 'b', layout)
     x = torch.empty_like(b) if out is None else out
-    _vectors(x, n, nsp, a.device, 'out')
-    lu = torch.empty_like(a) if keep_factors else None
+    _vectors(x, n, nsp, a.device, 'out', layout)
+    lu = torch.empty((n, nsp * nsp), dtype=torch.float64, device=a.device) if keep_factors else None
     perm = torch.empty((n, nsp), dtype=torch.int32, device=a.device) if keep_factors else None
-    check(_lib.lib().pj_newton_solve_dev(nsp, n, a.data_ptr(), float(gamma), b.data_ptr(), x.data_ptr(),
+    check(_lib.lib().pj_newton_solve_dev(nsp, n, a.data_ptr(), layout, float(gamma), b.data_ptr(), x.data_ptr(), layout,
                                          lu.data_ptr() if keep_factors else None,
                                          perm.data_ptr() if keep_factors else None, _stream()))
     return (x, lu, perm) if keep_factors else x

@@ -114,6 +114,32 @@ def test_solves_match_lapack(nsp, torch_cuda):
     assert (np.abs(res) <= 1e-14 * nsp * bound.max(axis=1, keepdims=True)).all()
 
 
+@pytest.mark.parametrize('nsp', [3, 10, 16, 24, 53, 64, 72, 111])
+def test_batch_layout_inputs(nsp, torch_cuda):
+    """The state-fastest batch layout (what the Jacobian kernels write at full speed): factors and solutions are the
+    same as from the per-state layout, bit for bit; n is not a multiple of anything."""
+    import pyjac_amd
+    from pyjac_amd import linsolve
+    torch = torch_cuda
+    rng = np.random.default_rng(300 + nsp)
+    n = 997 if nsp <= 64 else 203
+    a = _blocks(rng, n, nsp, dominant=True)
+    b = rng.standard_normal((n, nsp))
+    d_a, d_b = torch.from_numpy(_to_aos(a)).cuda(), torch.from_numpy(b).cuda()
+    d_as, d_bs = d_a.T.contiguous(), d_b.T.contiguous()           # (NSP*NSP, n), (NSP, n)
+    S = pyjac_amd.LAYOUT_SOA
+    lu, perm = linsolve.lu_factor(d_a, 0.0037)
+    lus, perms = linsolve.lu_factor(d_as, 0.0037, layout=S)
+    assert torch.equal(lu, lus) and torch.equal(perm, perms)
+    x = linsolve.newton_solve(d_a, d_b, gamma=0.0037)
+    xs, lu2, perm2 = linsolve.newton_solve(d_as, d_bs, gamma=0.0037, layout=S, keep_factors=True)
+    assert xs.shape == (nsp, n) and torch.equal(xs.T.contiguous(), x) and torch.equal(lu2, lu) and torch.equal(perm2, perm)
+    x2 = linsolve.lu_solve(lu, perm, d_bs, layout=S)
+    assert torch.equal(x2.T.contiguous(), linsolve.lu_solve(lu, perm, d_b))
+    with pytest.raises(ValueError):
+        linsolve.lu_factor(d_as, overwrite=True, layout=S)
+
+
 def test_edge_cases(torch_cuda):
     from pyjac_amd import PyjacError, linsolve
     torch = torch_cuda
@@ -165,3 +191,9 @@ def test_newton_step_on_jacobians(name, n, torch_cuda):
     ref = np.linalg.solve(M, b[:400, :, None])[:, :, 0]
     cond = np.linalg.cond(M)[:, None]
     assert (np.abs(x[:400] - ref) <= 1e-13 * ev.nsp * cond * np.abs(ref).max(axis=1, keepdims=True)).all()
+    # the same step straight from the batch layout (SoA Jacobians, SoA vectors): no transposed copy
+    ev.use_spec(1)
+    jac_soa = ev.jacobian(d_p, torch.from_numpy(y).cuda())
+    xs = linsolve.newton_solve(jac_soa, torch.from_numpy(np.ascontiguousarray(b.T)).cuda(), gamma=gamma,
+                               layout=pyjac_amd.LAYOUT_SOA).cpu().numpy().T
+    assert (np.abs(xs[:400] - ref) <= 1e-13 * ev.nsp * cond * np.abs(ref).max(axis=1, keepdims=True)).all()

@@ -95,12 +95,12 @@ def test_linsolve_argument_checks_and_no_cpu_fallback():
     if not torch.cuda.is_available():
         buf = (ct.c_double * 16)()
         prm = (ct.c_int * 4)()
-        rc = L.pj_lu_factor_dev(4, 1, ct.cast(buf, ct.c_void_p), 0.0, ct.cast(buf, ct.c_void_p), ct.cast(prm, ct.c_void_p), None)
+        rc = L.pj_lu_factor_dev(4, 1, ct.cast(buf, ct.c_void_p), 1, 0.0, ct.cast(buf, ct.c_void_p), ct.cast(prm, ct.c_void_p), None)
         assert rc == -2                                                          # PJ_ENODEV
         with pytest.raises(PyjacError):
             _lib.check(rc)
-    assert L.pj_lu_factor_dev(141, 1, None, 0.0, None, None, None) != 0          # bad arguments never reach a launch
-    assert L.pj_lu_factor_dev(4, 0, None, 0.0, None, None, None) == 0            # empty batch
+    assert L.pj_lu_factor_dev(141, 1, None, 1, 0.0, None, None, None) != 0          # bad arguments never reach a launch
+    assert L.pj_lu_factor_dev(4, 0, None, 1, 0.0, None, None, None) == 0            # empty batch
 
 
 def test_product_package_never_imports_oracle():
