@@ -114,8 +114,12 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
     const int lane0 = lane, nsp0 = nsp;
     // a workgroup takes runs of 16 consecutive blocks (its four wavefronts, four rounds each, then the next run): in
     // the batch layout the 16 states of a 128-byte line are then read by one workgroup, i.e. through one L2
-    for (long s = (long)blockIdx.x * 16 + (threadIdx.x >> 6); s < n + 12; s += (s & 15) < 12 ? 4 : (long)gridDim.x * 16 - 12) {
-        if (s >= n) continue;
+    // (a wavefront past the end repeats the last block -- the batch-layout path below has workgroup barriers -- and
+    // stores nothing)
+    __shared__ double stage[4][8][64];
+    for (long s_ = (long)blockIdx.x * 16 + (threadIdx.x >> 6); (s_ & ~3L) < n; s_ += (s_ & 15) < 12 ? 4 : (long)gridDim.x * 16 - 12) {
+        const bool valid = s_ < n;
+        const long s = valid ? s_ : n - 1;
         // Every predicate of the body (j < nsp, lane == j, lane > k ...) is invariant across matrices, and the
         // optimiser knows: it computes hundreds of lane masks once, in front of the loop, and spills them.  Opaque
         // copies of `nsp` and `lane` per phase keep each predicate next to its use.
@@ -130,10 +134,41 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
         // predicates: a branch per column would serialise 53 memory round trips); the identity padding and the Newton
         // matrix I - gamma A are applied afterwards, branch-free
         const int lane_c = lane < nsp ? lane : nsp - 1;
-        lu_for<0, NP>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            a[j] = As[(lane_c + (long)nsp * (j < nsp ? j : nsp - 1)) * a_si];
-        });
+        if (!pre_ && Y.a_ss == 1) {
+            // Batch layout: entry (r, c) of the workgroup's four blocks is 32 contiguous bytes, a lane-per-row load
+            // would touch a different line in every lane.  The four wavefronts fetch eight columns of the four
+            // blocks together (a thread: one entry of one block, lanes 4 e .. 4 e + 3 = the four states) into LDS
+            // and each wavefront picks its block's values up from there.
+            const long s4 = s_ & ~3L;                         // first block of this round's four
+            const int tid = (int)threadIdx.x, w4 = tid & 3, e0 = tid >> 2;
+            const long sl = s4 + w4 < n ? s4 + w4 : n - 1;
+            lu_for<0, (NP + 7) / 8>([&](auto cc) {
+                constexpr int j0 = 8 * decltype(cc)::value;
+                double v[(8 * 64 + 63) / 64];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {                  // 8 columns x 64 rows = 512 entries, 64 per pass
+                    const int e = e0 + 64 * q, r = e & 63, c = j0 + (e >> 6);
+                    const int rc = r < nsp ? r : nsp - 1, ccl = c < nsp ? c : nsp - 1;
+                    v[q] = A[((long)rc + (long)nsp * ccl) * Y.a_si + sl];
+                }
+                __syncthreads();                               // the previous chunk has been picked up
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + 64 * q;
+                    stage[w4][e >> 6][e & 63] = v[q];
+                }
+                __syncthreads();
+                lu_for<0, 8>([&](auto jj) {
+                    constexpr int j = j0 + decltype(jj)::value;
+                    if constexpr (j < NP) a[j] = stage[threadIdx.x >> 6][decltype(jj)::value][lane_c];
+                });
+            });
+        } else {
+            lu_for<0, NP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                a[j] = As[(lane_c + (long)nsp * (j < nsp ? j : nsp - 1)) * a_si];
+            });
+        }
         {
             const bool newton = !(mode & LU_PREFACTORED) && gamma != 0.0;
             const double sc = newton ? -gamma : 1.0, sh = newton ? 1.0 : 0.0;     // a -> sh * delta_ij + sc * a
@@ -197,7 +232,7 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
             });
         }
         asm volatile("" : "+s"(nsp), "+v"(lane));
-        if (!(mode & LU_PREFACTORED) && lu != nullptr && act) {
+        if (!(mode & LU_PREFACTORED) && lu != nullptr && act && valid) {
             double* Ls = lu + s * ne;
             lu_for<0, NP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -221,7 +256,7 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
                     else if (pos < k && pos >= 0) bb = __builtin_fma(-a[k], xk, bb);
                 }
             });
-            if (act) x[pos * Y.v_si + s * Y.v_ss] = bb;
+            if (act && valid) x[pos * Y.v_si + s * Y.v_ss] = bb;
         }
     }
 }

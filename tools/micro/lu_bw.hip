@@ -27,7 +27,7 @@ int main(int argc, char** argv)
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0, 0);
             for (int it = 0; it < 5; ++it)
-                pj::lu_launch(nsp, n, a, gamma, mode == pj::LU_FACTOR ? lu : nullptr, mode == pj::LU_FACTOR ? perm : nullptr, b, x, mode, 256, 0);
+                pj::lu_launch(nsp, n, a, pj::LuLay{1, (long)nsp * nsp, 1, (long)nsp}, gamma, mode == pj::LU_FACTOR ? lu : nullptr, mode == pj::LU_FACTOR ? perm : nullptr, b, x, mode, 256, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rep) printf("BPERM=%d nsp %d n %ld mode %d: %.3f ms\n", PJ_LU_BPERM, nsp, n, mode, ms / 5);
