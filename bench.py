@@ -408,6 +408,29 @@ def main():
                     step()          # leave the headline kernel's output in `jac`
                 except Exception as ex:
                     line['also']['no_compile_path'] = {'error': repr(ex)}
+                # the consumer of the Jacobians: one Newton update (I - gamma J_s) dx_s = r_s per state,
+                # factor + solve fused (csrc/pj_lu.h), straight from the batch-layout Jacobians of this step
+                try:
+                    from pyjac_amd import linsolve
+                    lay = pyjac_amd.LAYOUT_SOA if L == pyjac_amd.LAYOUT_SOA else pyjac_amd.LAYOUT_AOS
+                    rhs = torch.ones((ev.nsp, n) if lay == pyjac_amd.LAYOUT_SOA else (n, ev.nsp), dtype=torch.float64, device='cuda')
+                    dx = torch.empty_like(rhs)
+                    linsolve.newton_solve(jac, rhs, gamma=1e-7, out=dx, layout=lay)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        linsolve.newton_solve(jac, rhs, gamma=1e-7, out=dx, layout=lay)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms_lu = e0.elapsed_time(e1) / 3
+                    line['also']['newton_step'] = dict(
+                        states=n, solve_ms=ms_lu, jacobian_ms=ms_kernel, total_ms=ms_kernel + ms_lu,
+                        steps_per_s=n / (ms_kernel + ms_lu) * 1e3, finite=bool(torch.isfinite(dx[:, ::997] if lay == pyjac_amd.LAYOUT_SOA else dx[::997]).all()),
+                        note='batched LU with partial pivoting + solve of (I - 1e-7 J) dx = 1, one pass over the %d x %d '
+                             'blocks (pj_newton_solve_dev); jacobian_ms = the headline kernel' % (ev.nsp, ev.nsp))
+                    del rhs, dx
+                except Exception as ex:
+                    line['also']['newton_step'] = {'error': repr(ex)}
                 # configs[1] "spec_rates + Jacobian": the rate pass (pyjacob.cu k_dydt) on the same batch,
                 # with every intermediate array written (conc, fwd, rev, pres_mod, spec_rates, dy) and
                 # with dy only
