@@ -53,10 +53,18 @@ __device__ __forceinline__ double lu_bpermute(const double v, const int byte_add
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double lu_dpp_max(const double v)
 {
-    // lanes without a source lane (or in rows outside ROWMASK) keep their own value: max(v, v) = v
+    // Every row takes part (ROWMASK 0xf): lanes without a source lane read 0.0, which never beats a candidate
+    // (|a| >= 0) -- no `old` operand, i.e. no register copies in front of the DPP moves.  Otherwise lanes in rows outside
+    // ROWMASK keep their own value: max(v, v) = v.
     const long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)u, (int)(unsigned)u, CTRL, ROWMASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(u >> 32), (int)(unsigned)(u >> 32), CTRL, ROWMASK, 0xf, false);
+    int lo, hi;
+    if constexpr (ROWMASK == 0xf) {
+        lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp((int)(unsigned)u, (int)(unsigned)u, CTRL, ROWMASK, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp((int)(unsigned)(u >> 32), (int)(unsigned)(u >> 32), CTRL, ROWMASK, 0xf, false);
+    }
     const double o = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));     // (fmax() would canonicalise both operands first)
@@ -396,8 +404,8 @@ template <int CTRL>
 __device__ __forceinline__ double lu_dpp_rot_max(const double v)
 {
     const long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)u, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(u >> 32), (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);       // a rotation: every lane has a source
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
     const double o = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
