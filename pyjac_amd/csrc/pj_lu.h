@@ -300,11 +300,14 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
         const long a_si = pre ? 1 : Y.a_si;
         const double* As = pre ? lu + s * ne : A + s * Y.a_ss;
         const bool newton = !pre && gamma != 0.0;
-        for (int idx = tid; idx < (int)ne; idx += 256) {
-            const int r = idx % nsp, c = idx / nsp;
-            double v = As[idx * a_si];
-            if (newton) v = (r == c ? 1.0 : 0.0) - gamma * v;
-            M[c * ld + r] = v;
+        for (int c = wave; c < nsp; c += 4) {              // a wavefront per column: no index divisions
+            const double* Ac = As + (long)c * nsp * a_si;
+            double* Mc = M + c * ld;
+            for (int r = lane; r < nsp; r += 64) {
+                double v = Ac[r * a_si];
+                if (newton) v = (r == c ? 1.0 : 0.0) - gamma * v;
+                Mc[r] = v;
+            }
         }
         if (tid < nsp) {
             pm[tid] = pre ? perm[s * nsp + tid] : tid;
@@ -355,19 +358,27 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
                         if (r < nsp) { M[k * ld + r] = lr[q]; if (solve) bv[r] = __builtin_fma(-lr[q], bk, bv[r]); }
                     }
                 }
-                for (int c = k + 1 + tc; c < nsp; c += 8) {
-                    const double ukc = M[c * ld + k];
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        const int r = k + 1 + tr + 32 * q;
-                        if (r < nsp) M[c * ld + r] = __builtin_fma(-lr[q], ukc, M[c * ld + r]);
+                {
+                    // rows k + 1 + tr + 32 q < nsp: the first nq of the five (fewer as k grows)
+                    const int rows = nsp - (k + 1 + tr);
+                    const int nq = rows <= 0 ? 0 : (rows + 31) >> 5;
+                    double* col = M + (k + 1 + tc) * ld + (k + 1 + tr);
+                    const int step8 = 8 * ld;
+                    for (int c = k + 1 + tc; c < nsp; c += 8, col += step8) {
+                        const double ukc = col[-(1 + tr)];               // M[c * ld + k]
+                        if (nq > 0) col[0] = __builtin_fma(-lr[0], ukc, col[0]);
+                        if (nq > 1) col[32] = __builtin_fma(-lr[1], ukc, col[32]);
+                        if (nq > 2) col[64] = __builtin_fma(-lr[2], ukc, col[64]);
+                        if (nq > 3) col[96] = __builtin_fma(-lr[3], ukc, col[96]);
+                        if (nq > 4) col[128] = __builtin_fma(-lr[4], ukc, col[128]);
                     }
                 }
                 __syncthreads();
             }
             if (lu != nullptr) {
                 double* Ls = lu + s * ne;
-                for (int idx = tid; idx < (int)ne; idx += 256) Ls[idx] = M[(idx / nsp) * ld + idx % nsp];
+                for (int c = wave; c < nsp; c += 4)
+                    for (int r = lane; r < nsp; r += 64) Ls[c * nsp + r] = M[c * ld + r];
                 if (perm != nullptr && tid < nsp) perm[s * nsp + tid] = pm[tid];
             }
         } else if (solve) {
