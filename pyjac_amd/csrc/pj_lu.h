@@ -422,15 +422,36 @@ __device__ __forceinline__ double lu_dpp_rot_max(const double v)
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
     return r;
 }
-// first lane of this lane's group of 16 for which `pred` holds (garbage if none does)
+// first lane of this lane's group of GW for which `pred` holds (the lane after the group if none does)
+template <int GW>
 __device__ __forceinline__ int lu_group_first(const bool pred, const int lane)
 {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
-    const unsigned f = (unsigned)(m >> (lane & 48)) & 0xffffu;
-    return (lane & 48) + (int)__builtin_ctz(f | 0x10000u);
+    const int base = lane & ~(GW - 1);
+    const unsigned long long f = (m >> base) & ((1ull << GW) - 1ull);
+    return base + (int)__builtin_ctzll(f | (1ull << GW));
+}
+// maximum over the group of GW lanes, in every lane of it: four rotations inside the DPP rows of 16; for groups of
+// 32 the two rows of a group then exchange through v_permlane16_swap (odd rows of one copy <-> even rows of the other)
+template <int GW>
+__device__ __forceinline__ double lu_group_max(double mx)
+{
+    mx = lu_dpp_rot_max<0x121>(mx);      // row_ror:1, 2, 4, 8
+    mx = lu_dpp_rot_max<0x122>(mx);
+    mx = lu_dpp_rot_max<0x124>(mx);
+    mx = lu_dpp_rot_max<0x128>(mx);
+    if constexpr (GW == 32) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(mx);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+        const double e = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));   // even rows' value
+        const double o = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));   // odd rows' value
+        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(e), "v"(o));
+    }
+    return mx;
 }
 
-template <int NP>      // 8 or 16
+template <int NP, int GW>      // NP <= GW: 16 (four blocks per wavefront) or 32 (two)
 __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const double* A, const LuLay Y, const double gamma,
                                               double* lu, int* __restrict__ perm, const double* __restrict__ b,
                                               double* __restrict__ x, const int mode)
@@ -440,11 +461,12 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
     const long ne = (long)nsp * nsp;
     const int nsp0 = nsp;
     const bool pre = (mode & LU_PREFACTORED) != 0, solve = (mode & LU_SOLVE) != 0;
-    for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w * 4 < n; w += nw) {
+    constexpr int BPW = 64 / GW;
+    for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w * BPW < n; w += nw) {
         int nsp = nsp0, lane = lane0;
         asm volatile("" : "+s"(nsp), "+v"(lane));
-        const int i = lane & 15;
-        const long s = w * 4 + (lane >> 4);
+        const int i = lane & (GW - 1);
+        const long s = w * BPW + lane / GW;
         const bool act = i < nsp && s < n;
         const long sc = s < n ? s : n - 1;               // clamped: loads are unconditional
         const int ic = i < nsp ? i : nsp - 1;
@@ -475,13 +497,10 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
                     const bool open = pos < 0 && act;
                     double mx = open ? fabs(a[k]) : -1.0;
                     const double cand = mx;
-                    mx = lu_dpp_rot_max<0x121>(mx);      // row_ror:1, 2, 4, 8: the maximum of the 16 lanes, in all of them
-                    mx = lu_dpp_rot_max<0x122>(mx);
-                    mx = lu_dpp_rot_max<0x124>(mx);
-                    mx = lu_dpp_rot_max<0x128>(mx);
-                    int p = lu_group_first(open && cand == mx, lane);
-                    const int p_any = lu_group_first(open, lane);
-                    if ((p & 15) >= nsp || p > (lane | 15)) p = p_any;        // a column of NaNs: any open row of the group
+                    mx = lu_group_max<GW>(mx);          // the maximum of the group, in all of its lanes
+                    int p = lu_group_first<GW>(open && cand == mx, lane);
+                    const int p_any = lu_group_first<GW>(open, lane);
+                    if (p > (lane | (GW - 1))) p = p_any;                     // a column of NaNs: any open row of the group
                     p = p > 63 ? lane : p;                                     // (a group without blocks: harmless values)
                     if (lane == p) pos = k;
                     const int src = p * 4;
@@ -506,7 +525,7 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
             lu_for<0, NP>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 if (k < nsp) {
-                    const double yk = lu_bpermute(bb, ((lane & 48) + k) * 4);
+                    const double yk = lu_bpermute(bb, ((lane & ~(GW - 1)) + k) * 4);
                     if (i > k) bb = __builtin_fma(-a[k], yk, bb);
                 }
             });
@@ -525,7 +544,7 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
             lu_for<0, NP>([&](auto kr) {
                 constexpr int k = NP - 1 - decltype(kr)::value;
                 if (k < nsp) {
-                    int p = lu_group_first(pos == k, lane);
+                    int p = lu_group_first<GW>(pos == k, lane);
                     p = p > 63 ? lane : p;
                     if (pre) myinv = lu_rcp(a[k]);
                     const double xk = lu_bpermute(lu_div(bb, a[k], myinv), p * 4);
@@ -538,14 +557,15 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
     }
 }
 
-template <int NP>
+template <int NP, int GW>
 inline void lu_launch16(int nsp, long n, const double* A, LuLay Y, double gamma, double* lu, int* perm, const double* b, double* x,
                         int mode, int cus, hipStream_t st)
 {
-    long blocks = (n + 15) / 16;            // four wavefronts of four blocks per workgroup
+    constexpr int PER_WG = 4 * (64 / GW);   // four wavefronts of four (two) blocks per workgroup
+    long blocks = (n + PER_WG - 1) / PER_WG;
     const long cap = (long)cus * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_lu16<NP>, dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
+    hipLaunchKernelGGL((k_lu16<NP, GW>), dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
 }
 
 template <int NP>
@@ -576,10 +596,10 @@ inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, do
         return 0;
     }
     switch ((nsp + 7) / 8) {
-    case 1: lu_launch16<8>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 2: lu_launch16<16>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 3: lu_launch_np<24>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
-    case 4: lu_launch_np<32>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 1: lu_launch16<8, 16>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 2: lu_launch16<16, 16>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 3: lu_launch16<24, 32>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
+    case 4: lu_launch16<32, 32>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
     case 5: lu_launch_np<40>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
     case 6: lu_launch_np<48>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
     case 7: lu_launch_np<56>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;

@@ -41,7 +41,7 @@ def _scipy_perm(piv):
     return perm
 
 
-@pytest.mark.parametrize('nsp', [1, 2, 7, 8, 9, 10, 16, 24, 33, 48, 53, 56, 57, 64, 65, 100, 111, 128, 129, 140])
+@pytest.mark.parametrize('nsp', [1, 2, 7, 8, 9, 10, 16, 17, 24, 32, 33, 48, 53, 56, 57, 64, 65, 100, 111, 128, 129, 140])
 def test_lu_factor_matches_lapack(nsp, torch_cuda):
     """P A = L U with LAPACK's pivot rows; factors agree to rounding; also through I - gamma A."""
     import scipy.linalg
@@ -70,7 +70,7 @@ def test_lu_factor_matches_lapack(nsp, torch_cuda):
         assert worst < 1e-13 * nsp, (nsp, gamma, worst)
 
 
-@pytest.mark.parametrize('nsp', [1, 3, 10, 24, 53, 64, 65, 111, 140])
+@pytest.mark.parametrize('nsp', [1, 3, 10, 17, 24, 32, 53, 64, 65, 111, 140])
 def test_solves_match_lapack(nsp, torch_cuda):
     """pj_lu_solve_dev on stored factors and the fused factor + solve agree with numpy.linalg.solve."""
     from pyjac_amd import linsolve
@@ -114,7 +114,7 @@ def test_solves_match_lapack(nsp, torch_cuda):
     assert (np.abs(res) <= 1e-14 * nsp * bound.max(axis=1, keepdims=True)).all()
 
 
-@pytest.mark.parametrize('nsp', [3, 10, 16, 24, 53, 64, 72, 111])
+@pytest.mark.parametrize('nsp', [3, 10, 16, 24, 32, 53, 64, 72, 111])
 def test_batch_layout_inputs(nsp, torch_cuda):
     """The state-fastest batch layout (what the Jacobian kernels write at full speed): factors and solutions are the
     same as from the per-state layout, bit for bit; n is not a multiple of anything."""
