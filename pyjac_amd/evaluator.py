@@ -190,6 +190,15 @@ class Evaluator:
                                               out.data_ptr(), jac_layout, self._stream()))
         return out
 
+    def newton_solve(self, pres, y, rhs, gamma: float, layout=LAYOUT_SOA, out=None):
+        """One Newton update per state: dx_s = (I - gamma J(Phi_s))^-1 rhs_s -- the Jacobian kernel followed by the
+        batched LU / solve of csrc/pj_lu.h on the blocks where the kernel left them (no transposed copy; the
+        per-state integrator loop of docs/examples.rst:106-170 as two launches).  y, rhs, dx: SoA (NSP, n) or AoS
+        (n, NSP) according to `layout`."""
+        from . import linsolve
+        jac = self.jacobian(pres, y, y_layout=layout, jac_layout=layout)
+        return linsolve.newton_solve(jac, rhs, gamma=gamma, out=out, layout=layout)
+
     def jacobian_vec(self, pres, y, v, layout=LAYOUT_SOA, out=None):
         """w_s = J(Phi_s) v_s per state (the consumer of pyJac's sparse_multiplier fused into the
         Jacobian kernel when a pj_lane library is attached).  y, v, w: SoA (NSP, n) or AoS (n, NSP)."""

@@ -197,3 +197,6 @@ def test_newton_step_on_jacobians(name, n, torch_cuda):
     xs = linsolve.newton_solve(jac_soa, torch.from_numpy(np.ascontiguousarray(b.T)).cuda(), gamma=gamma,
                                layout=pyjac_amd.LAYOUT_SOA).cpu().numpy().T
     assert (np.abs(xs[:400] - ref) <= 1e-13 * ev.nsp * cond * np.abs(ref).max(axis=1, keepdims=True)).all()
+    # and as one call on the evaluator
+    xe = ev.newton_solve(d_p, torch.from_numpy(y).cuda(), torch.from_numpy(np.ascontiguousarray(b.T)).cuda(), gamma)
+    assert np.array_equal(xe.cpu().numpy().T, xs)
