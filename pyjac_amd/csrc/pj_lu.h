@@ -316,24 +316,28 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
         if (solve && tid < nsp) bv[tid] = b[(pre ? pm[tid] : tid) * Y.v_si + s * Y.v_ss];
         __syncthreads();
         if (!pre) {
+            // pivot of column c0 among rows c0 .. nsp-1, by the lower half of wavefront 0 (lane tr: rows c0 + tr + 32 q --
+            // for c0 = k + 1 exactly the entries those lanes have just updated): maximum magnitude, ties to the lowest
+            // lane.  Left in red_i[0] for the next step: no barrier, no pivot-column read for the other wavefronts.
+            auto search = [&](const int c0) {
+                double best = -1.0; int brow = c0;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const int r = c0 + (tid & 31) + 32 * q;
+                    if (tid < 32 && r < nsp) {
+                        const double v = fabs(M[c0 * ld + r]);
+                        if (v > best) { best = v; brow = r; }
+                    }
+                }
+                const double mx = lu_wave_max(best);
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(best == mx && best >= 0.0);
+                if (hit == 0) { if (tid == 0) red_i[0] = c0; }             // a column of NaNs
+                else if (lane == (int)__builtin_ctzll(hit)) red_i[0] = brow;
+            };
+            if (wave == 0) search(0);
+            __syncthreads();
             for (int k = 0; k < nsp; ++k) {
-                // pivot: first row of maximum magnitude in column k, rows k .. nsp-1
-                {
-                    const int r = k + tid;
-                    const double v = r < nsp ? fabs(M[k * ld + r]) : -1.0;
-                    const double mx = lu_wave_max(v);                   // DPP reduction: no LDS round trips
-                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(v == mx);
-                    if (lane == 0) { red_v[wave] = mx; red_i[wave] = k + 64 * wave + (hit ? (int)__builtin_ctzll(hit) : 0); }
-                }
-                __syncthreads();
-                int p = k;
-                {
-                    double best = -1.0;
-                    const int nw = (nsp - k + 63) / 64;
-                    for (int w = 0; w < nw && w < 4; ++w)
-                        if (red_v[w] > best) { best = red_v[w]; p = red_i[w]; }       // waves cover increasing rows: first maximum
-                    if (!(best >= 0.0) || p < k || p >= nsp) p = k;                   // a column of NaNs
-                }
+                const int p = red_i[0];
                 if (p != k) {
                     if (tid < nsp) { const double t = M[tid * ld + k]; M[tid * ld + k] = M[tid * ld + p]; M[tid * ld + p] = t; }
                     if (tid == 255) { const int t = pm[k]; pm[k] = pm[p]; pm[p] = t; }
@@ -394,6 +398,7 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
                         for (int q = 0; q < 5; ++q) if (q < nq) col[32 * q] = __builtin_fma(-lr[q], ukc, v[q]);
                     }
                 }
+                if (wave == 0 && k + 1 < nsp) search(k + 1);       // (its lanes read back what they wrote themselves)
                 __syncthreads();
             }
             if (lu != nullptr) {
