@@ -46,6 +46,9 @@ __device__ __forceinline__ double lu_bpermute(const double v, const int byte_add
     const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)(u >> 32));
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+#ifndef PJ_LU_ABL
+#define PJ_LU_ABL 0          // timing experiments on k_lu_lds (results wrong): 1 no trailing update, 2 no row exchange, 4 no pivot search
+#endif
 #ifndef PJ_LU_BPERM
 #define PJ_LU_BPERM 2       // broadcasts of the pivot row: 0 all v_readlane, 1 all ds_bpermute, 2 every other column
 #endif
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
             __syncthreads();
             for (int k = 0; k < nsp; ++k) {
                 const int p = red_i[0];
-                if (p != k) {
+                if (p != k && !(PJ_LU_ABL & 2)) {
                     if (tid < nsp) { const double t = M[tid * ld + k]; M[tid * ld + k] = M[tid * ld + p]; M[tid * ld + p] = t; }
                     if (tid == 255) { const int t = pm[k]; pm[k] = pm[p]; pm[p] = t; }
                     if (solve && tid == 254) { const double t = bv[k]; bv[k] = bv[p]; bv[p] = t; }
@@ -363,42 +366,57 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
                     }
                 }
                 {
-                    // rows k + 1 + tr + 32 q < nsp: the first nq of the five (fewer as k grows)
-                    const int rows = nsp - (k + 1 + tr);
-                    const int nq = rows <= 0 ? 0 : (rows + 31) >> 5;
-                    double* col = M + (k + 1 + tc) * ld + (k + 1 + tr);
+                    // Trailing update.  Rows k + 1 + tr + 32 q, q < NQ with NQ the same for every thread (a switch on
+                    // the rows still in play: compile-time trip shapes); reads are unconditional -- a row past the end
+                    // reads the last row instead -- so that all LDS reads of a trip (three columns x NQ rows + three
+                    // pivot-row entries) are in flight before the first multiply; only the writes are predicated.
+                    // (Per-thread row counts as predicates around the reads: 178 ms per 2e5 111 x 111 blocks; one
+                    // column per trip: 206 ms.)
                     const int step8 = 8 * ld;
-                    // three columns per trip, every LDS read of the trip issued before its first use (one read ->
-                    // multiply -> write chain per column would pay the LDS latency once per column): 206 -> 178 ms per
-                    // 2e5 111 x 111 blocks.  (Written out: the same trip as a generic lambda over NC columns compiles to
-                    // 225 ms, six columns per trip to 232 ms.)
-                    int c = k + 1 + tc;
-                    for (; c + 16 < nsp; c += 24, col += 3 * step8) {
-                        double* const c1 = col + step8;
-                        double* const c2 = col + 2 * step8;
-                        const double u0 = col[-(1 + tr)], u1 = c1[-(1 + tr)], u2 = c2[-(1 + tr)];
-                        double v0[5], v1[5], v2[5];
+                    const int r0 = k + 1 + tr;
+                    auto upd = [&](auto nqc) {
+                        constexpr int NQ = decltype(nqc)::value;
+                        int off[NQ]; bool ok[NQ];
 #pragma unroll
-                        for (int q = 0; q < 5; ++q)
-                            if (q < nq) { v0[q] = col[32 * q]; v1[q] = c1[32 * q]; v2[q] = c2[32 * q]; }
+                        for (int q = 0; q < NQ; ++q) { ok[q] = r0 + 32 * q < nsp; off[q] = ok[q] ? 32 * q : nsp - 1 - r0; }
+                        double* col = M + (k + 1 + tc) * ld + r0;
+                        int c = (PJ_LU_ABL & 1) ? nsp : k + 1 + tc;
+                        // (written out on purpose: the same trip as nested generic lambdas over NC columns compiles to
+                        // code that is 10 % (111 rows) to 80 % (65 rows) slower, and 4 / 6 / 8 columns per trip gain nothing)
+                        for (; c + 16 < nsp; c += 24, col += 3 * step8) {
+                            double* const c1 = col + step8;
+                            double* const c2 = col + 2 * step8;
+                            const double u0 = col[-(1 + tr)], u1 = c1[-(1 + tr)], u2 = c2[-(1 + tr)];
+                            double v0[NQ], v1[NQ], v2[NQ];
 #pragma unroll
-                        for (int q = 0; q < 5; ++q)
-                            if (q < nq) {
-                                col[32 * q] = __builtin_fma(-lr[q], u0, v0[q]);
-                                c1[32 * q] = __builtin_fma(-lr[q], u1, v1[q]);
-                                c2[32 * q] = __builtin_fma(-lr[q], u2, v2[q]);
-                            }
-                    }
-                    for (; c < nsp; c += 8, col += step8) {
-                        const double ukc = col[-(1 + tr)];               // M[c * ld + k]
-                        double v[5];
+                            for (int q = 0; q < NQ; ++q) { v0[q] = col[off[q]]; v1[q] = c1[off[q]]; v2[q] = c2[off[q]]; }
 #pragma unroll
-                        for (int q = 0; q < 5; ++q) if (q < nq) v[q] = col[32 * q];
+                            for (int q = 0; q < NQ; ++q)
+                                if (ok[q]) {
+                                    col[32 * q] = __builtin_fma(-lr[q], u0, v0[q]);
+                                    c1[32 * q] = __builtin_fma(-lr[q], u1, v1[q]);
+                                    c2[32 * q] = __builtin_fma(-lr[q], u2, v2[q]);
+                                }
+                        }
+                        for (; c < nsp; c += 8, col += step8) {
+                            const double ukc = col[-(1 + tr)];
+                            double v[NQ];
 #pragma unroll
-                        for (int q = 0; q < 5; ++q) if (q < nq) col[32 * q] = __builtin_fma(-lr[q], ukc, v[q]);
+                            for (int q = 0; q < NQ; ++q) v[q] = col[off[q]];
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) if (ok[q]) col[32 * q] = __builtin_fma(-lr[q], ukc, v[q]);
+                        }
+                    };
+                    switch ((nsp - (k + 1) + 31) >> 5) {
+                    case 5: upd(std::integral_constant<int, 5>{}); break;
+                    case 4: upd(std::integral_constant<int, 4>{}); break;
+                    case 3: upd(std::integral_constant<int, 3>{}); break;
+                    case 2: upd(std::integral_constant<int, 2>{}); break;
+                    case 1: upd(std::integral_constant<int, 1>{}); break;
+                    default: break;
                     }
                 }
-                if (wave == 0 && k + 1 < nsp) search(k + 1);       // (its lanes read back what they wrote themselves)
+                if (wave == 0 && k + 1 < nsp && !(PJ_LU_ABL & 4)) search(k + 1);       // (its lanes read back what they wrote themselves)
                 __syncthreads();
             }
             if (lu != nullptr) {
