@@ -123,12 +123,19 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
     const int lane = (int)(threadIdx.x & 63);
     const long ne = (long)nsp * nsp;
     const int lane0 = lane, nsp0 = nsp;
-    // a workgroup takes runs of 16 consecutive blocks (its four wavefronts, four rounds each, then the next run): in
-    // the batch layout the 16 states of a 128-byte line are then read by one workgroup, i.e. through one L2
-    // (a wavefront past the end repeats the last block -- the batch-layout path below has workgroup barriers -- and
-    // stores nothing)
+    // Blocks s .. s + 3 go to the four wavefronts of a workgroup, and the four workgroups that take the 16 blocks of a
+    // run are b, b + 8, b + 16, b + 24: dispatched together and -- round-robin over the 8 XCDs -- onto the same XCD, so
+    // that in the batch layout the 16 states of a 128-byte line are fetched into one L2 once and hit there three more
+    // times (one workgroup taking the four quarters of a run one after the other: 2.5x the algorithmic HBM bytes,
+    // the lines are evicted in between).  A wavefront past the end repeats the last block -- the batch-layout path
+    // below has workgroup barriers -- and stores nothing.
     __shared__ double stage[4][8][64];
-    for (long s_ = (long)blockIdx.x * 16 + (threadIdx.x >> 6); (s_ & ~3L) < n; s_ += (s_ & 15) < 12 ? 4 : (long)gridDim.x * 16 - 12) {
+    const long nvirt = ((n + 15) / 16 + 7) / 8 * 32;          // runs padded to a multiple of 8, four workgroups each
+    for (long v = blockIdx.x; v < nvirt; v += gridDim.x) {
+        const long slot = v >> 3;
+        const long s4_ = 16 * ((slot >> 2) * 8 + (v & 7)) + 4 * (slot & 3);
+        if (s4_ >= n) continue;                               // (the whole workgroup)
+        const long s_ = s4_ + (threadIdx.x >> 6);
         const bool valid = s_ < n;
         const long s = valid ? s_ : n - 1;
         // Every predicate of the body (j < nsp, lane == j, lane > k ...) is invariant across matrices, and the
@@ -616,8 +623,8 @@ template <int NP>
 inline void lu_launch_np(int nsp, long n, const double* A, LuLay Y, double gamma, double* lu, int* perm, const double* b, double* x,
                          int mode, int cus, hipStream_t st)
 {
-    long blocks = (n + 15) / 16;            // runs of 16 blocks per workgroup
-    const long cap = (long)cus * 8;         // grid-stride beyond a few workgroups per CU
+    long blocks = ((n + 15) / 16 + 7) / 8 * 32;   // four blocks per workgroup, runs of 16 per XCD (k_lu)
+    const long cap = (long)cus * 8;         // grid-stride beyond a few workgroups per CU (a multiple of 32)
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(k_lu<NP>, dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
 }
