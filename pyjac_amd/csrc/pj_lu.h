@@ -513,11 +513,19 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
     const int nsp0 = nsp;
     const bool pre = (mode & LU_PREFACTORED) != 0, solve = (mode & LU_SOLVE) != 0;
     constexpr int BPW = 64 / GW;
-    for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w * BPW < n; w += nw) {
+    // a workgroup takes 4 BPW consecutive blocks; the 16 / (4 BPW) workgroups of a 16-state run are b, b + 8, ... on one
+    // XCD (as in k_lu): a 128-byte line of the batch layout is fetched into one L2 once (2.3x the bytes otherwise)
+    constexpr int HPW = 16 / (4 * BPW);
+    const long nvirt = ((n + 15) / 16 + 7) / 8 * 8 * HPW;
+    (void)nw;
+    for (long v = blockIdx.x; v < nvirt; v += gridDim.x) {
+        const long slot = v >> 3;
+        const long s_base = 16 * ((slot / HPW) * 8 + (v & 7)) + (slot % HPW) * (4 * BPW);
+        if (s_base >= n) continue;
         int nsp = nsp0, lane = lane0;
         asm volatile("" : "+s"(nsp), "+v"(lane));
         const int i = lane & (GW - 1);
-        const long s = w * BPW + lane / GW;
+        const long s = s_base + (long)(threadIdx.x >> 6) * BPW + lane / GW;
         const bool act = i < nsp && s < n;
         const long sc = s < n ? s : n - 1;               // clamped: loads are unconditional
         const int ic = i < nsp ? i : nsp - 1;
@@ -613,7 +621,7 @@ inline void lu_launch16(int nsp, long n, const double* A, LuLay Y, double gamma,
                         int mode, int cus, hipStream_t st)
 {
     constexpr int PER_WG = 4 * (64 / GW);   // four wavefronts of four (two) blocks per workgroup
-    long blocks = (n + PER_WG - 1) / PER_WG;
+    long blocks = ((n + 15) / 16 + 7) / 8 * 8 * (16 / PER_WG);
     const long cap = (long)cus * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_lu16<NP, GW>), dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
