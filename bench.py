@@ -114,8 +114,11 @@ def end_to_end(ev, w, n_sample, np):
     from pyjac_amd.performance_tester import speedtest
     pres, y = make_states(w, ev.nsp, n_sample, seed=7)
     r = speedtest(ev, pres, y, repeats=2, quiet=True)
+    nbytes = n_sample * 8 * (ev.nsp + 1 + ev.nsp * ev.nsp + 3 * ev.nsp + ev.n_fwd + max(ev.n_rev, 1) + max(ev.n_pres_mod, 1))
     return dict(states=n_sample, ms=r['end_to_end_ms'], jacobians_per_s=n_sample / r['end_to_end_ms'] * 1e3,
-                note='H2D + kernels + D2H through pj_run (tester.cu.in:109-156 protocol), pageable host buffers')
+                host_GBps=nbytes / r['end_to_end_ms'] / 1e6,
+                note='H2D + kernels + D2H through pj_run (tester.cu.in:109-156 protocol), every output array of the '
+                     'reference harness copied back; caller buffers are pageable numpy arrays')
 
 
 def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0, build_rblk=False):
@@ -142,7 +145,10 @@ def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0, build_rblk=False):
     return ev
 
 
-def kernel_label(ev):
+def kernel_label(ev, inject=None):
+    if inject:
+        # PJ_BENCH_EVALUATOR: not the HIP path at all (tests/test_bench_gloo.py); the line must say so
+        return 'INJECTED evaluator %s (PJ_BENCH_EVALUATOR): not a measurement of the HIP path' % inject
     return {'pj_lane': 'pj_lane (register-resident state-per-lane kernel)',
             'pj_rblk': 'pj_rblk (state-per-lane row-block kernels that rebuild their rates + falloff/PLOG pre-pass)',
             }.get(
@@ -333,13 +339,16 @@ def main():
         value = total / elapsed
         bj = ev.jacobian_bytes_per_state
         achieved = n * bj / (ms_kernel * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % wl)   # rocprofv3 PMC passes of this round
         if os.path.exists(tpath):
             # PMC-measured HBM bytes of this kernel (profiles/README.md); a streaming map, so
             # a launch over n states moves n / states_per_launch times the profiled bytes
             tj = json.load(open(tpath))
             traffic = tj['hbm_bytes_per_launch'] * n / tj.get('states_per_launch', n)
+            # NOT measured in this run (PMC counters need rocprofv3 around the process): say where it comes from
+            traffic_source = ('committed profile profiles/traffic_%s.json (rocprofv3 --pmc passes of this command, %s), '
+                              'not measured in this run' % (wl, tj.get('collected', 'see profiles/README.md')))
         # the instruction roof of the same step: VALU instructions per state and the share of wave-cycles that
         # issue, from the committed SQ-counter summary of this workload (profiles/valu_<wl>.json, tools/valu_roof.py)
         valu = None
@@ -350,7 +359,9 @@ def main():
             valu = {'instr_per_state': vj['valu_instr_per_state'], 'issue_frac': vj['issue_frac'],
                     'wait_frac': vj.get('wait_frac'), 'achieved_wave_instr_per_s': wave_instr_per_s,
                     'fp64_peak_wave_instr_per_s': VALU_PEAK_WAVE_INSTR_PER_S,
-                    'frac': wave_instr_per_s / VALU_PEAK_WAVE_INSTR_PER_S, 'source': vj.get('source')}
+                    'frac': wave_instr_per_s / VALU_PEAK_WAVE_INSTR_PER_S, 'source': vj.get('source'),
+                    'source_kind': 'committed profile profiles/valu_%s.json (SQ counters of an earlier rocprofv3 run), '
+                                   'not measured in this run; only achieved_wave_instr_per_s uses this run\'s kernel_ms' % wl}
         hbm_frac = achieved / HBM_PEAK_GBPS
         line = {
             'metric': 'fp64 analytical Jacobians/s', 'value': value, 'unit': 'Jacobians/s',
@@ -364,11 +375,13 @@ def main():
             # `frac` is the HBM fraction the metric asks for; `bound` names the roof the kernel is closer to
             'roofline': {'bound': 'valu' if (valu and valu['frac'] > hbm_frac) else 'hbm', 'achieved': achieved,
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': hbm_frac, 'traffic': traffic,
+                         'traffic_source': traffic_source,
                          'bytes_per_state': bj, 'kernel_ms': ms_kernel, 'valu': valu},
         }
         if validation:
             line['validation_allgather'] = validation
-        line['config']['kernel'] = kernel_label(ev)
+        line['config']['kernel'] = kernel_label(ev, inject)
+        line['evaluator'] = ('injected:' + inject) if inject else 'native (pyjac_amd HIP path through the C ABI)'
         if world == 1 and not a.no_also:
             line['also'] = also_workloads(wl, pyjac_amd, torch, np)
             if ev.spec_kernel in ('pj_lane', 'pj_rblk') and L == pyjac_amd.LAYOUT_SOA:

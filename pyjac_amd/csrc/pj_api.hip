@@ -319,6 +319,12 @@ struct pj_mech {
     DevBuf<double> tab_D;
     double* tab_scr = nullptr;
     long tab_scr_ld = 0;
+    // k_tab hands omega_k and the last species' d/dT sum to k_tab_fin through tab_scr (indexed by the batch-local
+    // state): ONE batch at a time per handle.  Host threads are serialised by tab_mutex; on the device a batch
+    // launched on another stream is ordered behind the previous one by tab_event (as pj_rblk's enter_batch does).
+    std::mutex tab_mutex;
+    hipEvent_t tab_event = nullptr;
+    void* tab_last_stream = nullptr;
     int generic = 1;           // Jacobians without an attached library: 1 k_tab for SoA / k_eval for AoS, 0 k_eval, 2 k_tab
     int check_inputs = 0;      // 1: the *_dev entry points verify T > 0, p > 0, finite (one extra pass + a sync)
     unsigned long long* d_bad = nullptr;
@@ -450,6 +456,9 @@ int launch_tab(pj_mech* m, const Batch& B, hipStream_t st)
 {
     const TabProg& T = m->tab;
     const long nsp = m->P.nsp;
+    std::lock_guard<std::mutex> lock(m->tab_mutex);
+    if (!m->tab_event) HIPCHK(hipEventCreateWithFlags(&m->tab_event, hipEventDisableTiming));
+    else if (m->tab_last_stream != (void*)st) HIPCHK(hipStreamWaitEvent(st, m->tab_event, 0));
     if (m->tab_scr_ld < B.n) {
         if (m->tab_scr) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(m->tab_scr); m->tab_scr = nullptr; m->tab_scr_ld = 0; }
         hipError_t e = hipMalloc((void**)&m->tab_scr, sizeof(double) * (size_t)(nsp + 1) * (size_t)B.n);
@@ -475,6 +484,8 @@ int launch_tab(pj_mech* m, const Batch& B, hipStream_t st)
     hipLaunchKernelGGL(k_tab, dim3((unsigned)((B.n + T.L - 1) / T.L)), dim3(256), T.lds_bytes, st, m->M, X, B);
     hipLaunchKernelGGL(k_tab_fin, dim3((unsigned)((B.n + 63) / 64)), dim3(256), lds_fin, st, m->M, X, B);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(m->tab_event, st));       // the scratch is busy until here
+    m->tab_last_stream = (void*)st;
     return PJ_OK;
 }
 

@@ -45,6 +45,9 @@ class Evaluator:
         self.n_rev = L.pj_mech_rev_rates(h)
         self.n_pres_mod = L.pj_mech_pres_mod_rates(h)
         self.attached_spec = None
+        # bumped by every setter that can change results or the kernel that produces them: consumers that cache
+        # results per state (pyjacob.py) key on it
+        self.settings_generation = 0
         if specialize != 'off':
             self.specialize(build=(specialize == 'build'))
 
@@ -93,6 +96,7 @@ class Evaluator:
             else:
                 specbuild.build_rblk(L, self._h, self.nsp, so, **opts)
         check(L.pj_mech_attach_spec(self._h, so.encode()))
+        self.settings_generation += 1
         self.attached_spec = so
         return True
 
@@ -110,11 +114,13 @@ class Evaluator:
         """False/0: table-driven kernel; True/1: attached kernels for SoA Jacobians (default);
         2: attached kernels for every layout."""
         check(_lib.lib().pj_mech_use_spec(self._h, int(on)))
+        self.settings_generation += 1
 
     def set_spec_launch(self, streams: int = -1, chunk_states: int = -1, split_tail: int = -1, aos_direct: int = -1):
         """Launch settings of the attached row-block library, per evaluator (include/pyjac_amd.h:
         pj_mech_set_spec_launch); -1 leaves a setting unchanged."""
         check(_lib.lib().pj_mech_set_spec_launch(self._h, int(streams), int(chunk_states), int(split_tail), int(aos_direct)))
+        self.settings_generation += 1
 
     def close(self):
         if getattr(self, '_h', None):
@@ -130,6 +136,7 @@ class Evaluator:
     # ---- tuning / options ----
     def set_launch(self, tile_states: int = 0, threads: int = 0):
         check(_lib.lib().pj_mech_set_launch(self._h, tile_states, threads))
+        self.settings_generation += 1
 
     def get_launch(self):
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -140,6 +147,7 @@ class Evaluator:
         """'auto' (default: k_tab for SoA Jacobians, k_eval for AoS ones), 'k_tab' (table-driven state-per-lane
         row blocks) or 'k_eval' (cooperative kernel) for Jacobians evaluated without an attached library."""
         check(_lib.lib().pj_mech_set_generic_kernel(self._h, {'k_eval': 0, 'auto': 1, 'k_tab': 2}[name]))
+        self.settings_generation += 1
 
     def set_check_inputs(self, on: bool):
         """Verify T > 0, p > 0 and finite inputs before every device evaluation (one extra pass + a sync)."""
@@ -147,6 +155,7 @@ class Evaluator:
 
     def set_sum_last_species(self, on: bool):
         check(_lib.lib().pj_mech_set_sum_last_species(self._h, int(on)))
+        self.settings_generation += 1
 
     # ---- bytes per unit of work ----
     @property

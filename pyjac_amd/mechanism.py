@@ -509,6 +509,9 @@ def parse_mech(text: str, therm_text: Optional[str] = None,
         tl = therm_text.splitlines()
         start = 0
         for i, l in enumerate(tl):
+            # (blank and comment lines in front of the THERMO keyword are skipped, mech_interpret.py:764-769)
+            if not l.strip() or l.lstrip().startswith('!'):
+                continue
             if 'thermo' in l.lower():
                 start = i + 1
                 break

@@ -11,11 +11,20 @@ read_initial_conditions.cu:9-59).
   printed as the reference's ``"N,milliseconds"`` line; additionally the
   kernel-only time (HIP events), which the reference cannot separate.
 
+* ``sweep``: the reference driver's loop over batch sizes 1, 2, 4, ... N for its GPU arm
+  (performance_tester.py:341-347 ``steplist``, :497-508), ``repeats`` runs each, analytical or
+  finite-difference Jacobian (``finite_diffs``, :280-296), appended as ``"N,milliseconds"`` lines to
+  ``cuda_nco_nosmem_{ajac|fd}_-1_output.txt`` -- the file the reference's plotting scripts read (:388-397).
+  The reference's CPU arm sweeps OpenMP thread counts 1, 2, 4 ... ncpu at the full batch (:276-283); its
+  counterpart here is bench.py's ``cpu_baseline`` (pyJac's generated C at 1 thread and at all cores).
+
     python -m pyjac_amd.performance_tester --mech mech.inp --data data.bin --num 1000000
+    python -m pyjac_amd.performance_tester --mech mech.inp --data data.bin --num 1000000 --sweep [--fd]
 """
 from __future__ import annotations
 
 import argparse
+import os
 import time
 
 import numpy as np
@@ -84,6 +93,74 @@ def speedtest(ev, pres: np.ndarray, y: np.ndarray, repeats: int = 1, quiet: bool
     return dict(end_to_end_ms=best, kernel_ms=kms, num=num, padded=padded)
 
 
+def step_list(num_conditions: int):
+    """Batch sizes of the reference's GPU sweep (performance_tester.py:341-347): powers of two below
+    num_conditions, then num_conditions itself."""
+    steps, step = [], 1
+    while step < num_conditions:
+        steps.append(step)
+        step *= 2
+    if step / 2 != num_conditions:
+        steps.append(num_conditions)
+    return steps
+
+
+def output_name(fd: bool) -> str:
+    """File name of the reference driver for lang=cuda, no cache optimisation, no shared memory, no thread
+    count (performance_tester.py:388-397)."""
+    return 'cuda_nco_nosmem_%s_-1_output.txt' % ('fd' if fd else 'ajac')
+
+
+def sweep(ev, pres: np.ndarray, y: np.ndarray, repeats: int = 10, fd: bool = False, out_dir: str = None,
+          steps=None, quiet: bool = False):
+    """The reference driver's batch-size sweep on the HIP path: for N in 1, 2, 4, ... num, `repeats` runs of
+    the timed region of tester.cu.in:109-156 (H2D, every kernel of pj_run -- or the finite-difference arm,
+    fd_jacob.cu:23-96 --, D2H), one ``"N,milliseconds"`` line per run.  Returns [(N, [ms, ...]), ...]; with
+    out_dir the lines are appended to the reference's output file name."""
+    import torch
+    num, nsp = pres.size, ev.nsp
+    steps = list(steps) if steps is not None else step_list(num)
+    padded = ev.init(num)
+    cap = min(num, padded)
+    jac = np.empty(nsp * nsp * cap)
+    d = lambda r: np.zeros(max(r, 1) * cap)
+    bufs = (d(nsp), d(ev.n_fwd), d(ev.n_rev), d(ev.n_pres_mod), d(nsp), d(nsp))
+    fh = open(os.path.join(out_dir, output_name(fd)), 'a+') if out_dir else None
+    res = []
+    try:
+        for n in steps:
+            times = []
+            for _ in range(repeats):
+                t0 = time.perf_counter()
+                done = 0
+                while done < n:
+                    nc = min(n - done, padded)
+                    if fd:
+                        # the reference's FD arm evaluates dydt NSP + 1 times per state on the device and copies
+                        # the Jacobians back (fd_jacob.cu:23-96 inside tester.cu.in's loop)
+                        d_p = torch.from_numpy(np.ascontiguousarray(pres[done:done + nc])).cuda()
+                        d_y = torch.from_numpy(np.ascontiguousarray(y[:, done:done + nc])).cuda()
+                        out = ev.fd_jacobian(d_p, d_y)
+                        jac[:nsp * nsp * nc] = out.reshape(-1).cpu().numpy()
+                    else:
+                        yc = np.ascontiguousarray(y[:, done:done + nc]).ravel()
+                        ev.run(nc, padded, np.ascontiguousarray(pres[done:done + nc]), yc, *bufs, jac)
+                    done += nc
+                ms = (time.perf_counter() - t0) * 1e3
+                times.append(ms)
+                line = '%d,%.15e' % (n, ms)
+                if fh:
+                    fh.write(line + '\n')
+                if not quiet:
+                    print(line)
+            res.append((n, times))
+    finally:
+        ev.cleanup()
+        if fh:
+            fh.close()
+    return res
+
+
 def main():
     import pyjac_amd
     ap = argparse.ArgumentParser()
@@ -91,10 +168,17 @@ def main():
     ap.add_argument('--data', required=True, help='data.bin (performance_tester.py:320-338 format)')
     ap.add_argument('--num', type=int, required=True)
     ap.add_argument('--repeats', type=int, default=3)
+    ap.add_argument('--sweep', action='store_true',
+                    help='batch sizes 1, 2, 4, ... num, `repeats` runs each (performance_tester.py:341-347, 497-508)')
+    ap.add_argument('--fd', action='store_true', help='the finite-difference arm (fd_jacob.cu) instead of the analytical Jacobian')
+    ap.add_argument('--out-dir', default=None, help='append the lines to the reference\'s output file name there')
     a = ap.parse_args()
     ev = pyjac_amd.Evaluator(a.mech, specialize='build')
     fmap = ev.mechanism.fwd_spec_map if ev.mechanism is not None else None
     pres, y = read_initial_conditions(a.data, a.num, ev.nsp, fmap)
+    if a.sweep:
+        sweep(ev, pres, y, a.repeats, fd=a.fd, out_dir=a.out_dir)
+        return
     r = speedtest(ev, pres, y, a.repeats)
     print('kernel only: %d,%.15e' % (a.num, r['kernel_ms']))
 

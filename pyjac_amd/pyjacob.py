@@ -22,7 +22,9 @@ _ev = None
 # (functional_tester/test.py:1299-1327: eval_conc -> eval_rxn_rates -> get_rxn_pres_mod -> eval_spec_rates -> dydt ->
 # eval_jacobian), so the first call on a state evaluates everything once (pj_eval_state) and the others are served
 # from the cache -- when, and only when, their inputs are bit-identical to what the cache holds (T, pres, the mass
-# fractions; for the functions that take intermediate arrays: those arrays).  cache_states(False) switches it off.
+# fractions; for the functions that take intermediate arrays: those arrays) AND the evaluator's settings have not
+# changed since (Evaluator.settings_generation: set_sum_last_species, use_spec, specialize, set_generic_kernel,
+# set_launch ... change results or the kernel that produces them).  cache_states(False) switches it off.
 _cache = None
 _cache_on = True
 cache_hits = 0
@@ -40,6 +42,14 @@ def use_mechanism(mech, therm=None, last_spec=None) -> Evaluator:
     return _ev
 
 
+def _live_cache():
+    """The cached state if the cache is on and was filled by the current evaluator with its current settings."""
+    if not _cache_on or _cache is None:
+        return None
+    ev = _e()
+    return _cache if _cache['key'][3:] == (id(ev), getattr(ev, 'settings_generation', 0)) else None
+
+
 def _state(T, pres, Y):
     """Cached evaluation of the state (T, pres, Y[0 .. NSP-2]); None when the cache is off."""
     global _cache, cache_hits
@@ -48,7 +58,7 @@ def _state(T, pres, Y):
     ev = _e()
     n = ev.nsp
     Y = np.ascontiguousarray(Y[:n - 1], dtype=np.float64)
-    key = (float(T), float(pres), Y.tobytes())
+    key = (float(T), float(pres), Y.tobytes(), id(ev), getattr(ev, 'settings_generation', 0))
     if _cache is not None and _cache['key'] == key:
         cache_hits += 1
         return _cache
@@ -98,7 +108,7 @@ def py_eval_jacobian(t, pres, y, jac):
 
 
 def py_eval_rxn_rates(T, pres, C, fwd_rxn_rates, rev_rxn_rates):
-    c = _cache if _cache_on else None
+    c = _live_cache()
     if c is not None and c['key'][:2] == (float(T), float(pres)) and _same(_f64(C), c['conc'], _e().nsp):
         global cache_hits
         cache_hits += 1
@@ -110,7 +120,7 @@ def py_eval_rxn_rates(T, pres, C, fwd_rxn_rates, rev_rxn_rates):
 
 
 def py_eval_spec_rates(fwd_rxn_rates, rev_rxn_rates, pres_mod, sp_rates):
-    c = _cache if _cache_on else None
+    c = _live_cache()
     ev = _e()
     if c is not None and _same(_f64(fwd_rxn_rates), c['fwd'], ev.n_fwd) and _same(_f64(rev_rxn_rates), c['rev'], ev.n_rev) \
             and _same(_f64(pres_mod), c['pres_mod'], ev.n_pres_mod):
@@ -126,7 +136,7 @@ def py_eval_spec_rates(fwd_rxn_rates, rev_rxn_rates, pres_mod, sp_rates):
 
 
 def py_get_rxn_pres_mod(T, pres, C, pres_mod):
-    c = _cache if _cache_on else None
+    c = _live_cache()
     if c is not None and c['key'][:2] == (float(T), float(pres)) and _same(_f64(C), c['conc'], _e().nsp):
         global cache_hits
         cache_hits += 1

@@ -22,7 +22,19 @@ MECHS = {
     # 72 species / 260 reactions, 200 of them irreversible: the second mechanism of the two-lane-group row kernels
     # (57..120 species), with row kernels that touch only a handful of K_c groups
     'synth_irrev72': os.path.join(GOLDEN, 'synth_irrev72.inp'),
+    # front-end corners (tests/golden/make_frontend_mechs.py): the 28 H2/O2 reactions with a units keyword on the
+    # REACTIONS line (mech_interpret.py:42-49, 135-159) ...
+    'fe_kcal': os.path.join(GOLDEN, 'fe_kcal.inp'),
+    'fe_kelvins': os.path.join(GOLDEN, 'fe_kelvins.inp'),
+    'fe_kjoules': os.path.join(GOLDEN, 'fe_kjoules.inp'),
+    'fe_joules': os.path.join(GOLDEN, 'fe_joules.inp'),
+    'fe_evolts': os.path.join(GOLDEN, 'fe_evolts.inp'),
+    # ... and with a separate thermodynamic database: plain THERMO header, common middle temperature 1200 K, cards
+    # with / without their own, a foreign and a repeated card (mech_interpret.py:735-883): three different T_mid
+    'fe_septherm': os.path.join(GOLDEN, 'fe_septherm.inp'),
 }
+THERMS = {'fe_septherm': os.path.join(GOLDEN, 'fe_septherm.dat')}
+FRONT_END = ('fe_kcal', 'fe_kelvins', 'fe_kjoules', 'fe_joules', 'fe_evolts', 'fe_septherm')
 
 
 def pytest_configure(config):
@@ -58,7 +70,7 @@ def tables():
 
     def get(name):
         if name not in cache:
-            cache[name] = build_tables(read_mech(MECHS[name]))
+            cache[name] = build_tables(read_mech(MECHS[name], THERMS.get(name)))
         return cache[name]
     return get
 

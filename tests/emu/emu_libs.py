@@ -15,12 +15,12 @@ def rblk_emu_lib(name, budget, tmp, **kw):
     """(Evaluator without attached kernels, ctypes library) of mechanism `name` at accumulator budget
     `budget`; `tmp`: a directory or pytest's tmp_path_factory.  One build per session and option set."""
     import pyjac_amd
-    from conftest import MECHS
+    from conftest import MECHS, THERMS
     from pyjac_amd import _lib
     key = (name, budget, tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in kw.items())))
     if key not in _cache:
         d = str(tmp.mktemp('emu')) if hasattr(tmp, 'mktemp') else str(tmp)
-        ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
+        ev = pyjac_amd.Evaluator(MECHS[name], THERMS.get(name), specialize='off')
         hdr = os.path.join(d, '%s_q%d.h' % (name, budget))
         _lib.check(_lib.lib().pj_mech_emit_rows_spec(ev._h, hdr.encode(), budget))
         so = build_emu.build_rblk(hdr, os.path.join(d, 'lib%s_q%d_%d.so' % (name, budget, len(_cache))), **kw)

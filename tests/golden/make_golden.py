@@ -32,7 +32,15 @@ CASES = {
     'synth_fracnu': os.path.join(HERE, 'synth_fracnu.inp'),     # fractional nu, > 3 molecules per side
     # synth_mech.generate(72, 260, 6, 10, 4, 200, 2, seed=20240915): mostly irreversible, two lane groups per workgroup
     'synth_irrev72': os.path.join(HERE, 'synth_irrev72.inp'),
+    # front-end corners (make_frontend_mechs.py): units keywords on the REACTIONS line, a separate thermo database
+    'fe_kcal': os.path.join(HERE, 'fe_kcal.inp'),
+    'fe_kelvins': os.path.join(HERE, 'fe_kelvins.inp'),
+    'fe_kjoules': os.path.join(HERE, 'fe_kjoules.inp'),
+    'fe_joules': os.path.join(HERE, 'fe_joules.inp'),
+    'fe_evolts': os.path.join(HERE, 'fe_evolts.inp'),
+    'fe_septherm': os.path.join(HERE, 'fe_septherm.inp'),
 }
+THERM = {'fe_septherm': os.path.join(HERE, 'fe_septherm.dat')}
 
 
 def states_for(name, nsp):
@@ -51,7 +59,7 @@ def states_for(name, nsp):
         return P, np.ascontiguousarray(ysoa.T)
     else:
         rng = np.random.default_rng(7)
-        n = 120
+        n = 24 if name.startswith('fe_') else 120
         T = rng.uniform(400, 2800, n)
         P = 101325 * 10 ** rng.uniform(-1.5, 1.5, n)
         Y = rng.uniform(0, 1, (n, nsp)) ** 2 + 1e-6
@@ -65,7 +73,7 @@ def main():
     for name, mech in CASES.items():
         if only and name not in only:
             continue
-        build_ref(mech, name)
+        build_ref(mech, name, therm_path=THERM.get(name))
         r = Reference(name)
         P, y = states_for(name, r.nsp)
         outs = {k: [] for k in ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')}

@@ -1,0 +1,71 @@
+"""GPU: pyjac_amd/dist.py through RCCL (backend "nccl") on the one GPU a test box has -- world size 1.
+
+The 8-GPU scaling run is the driver's; this makes sure its collectives are not executed for the first time there:
+`all_gather_into_tensor` on the `view(-1)` buffers, the chunk loop with its ragged last chunk and the checksum gather
+run through RCCL on device tensors that hold a real Jacobian shard (512 GRI-shaped states from the HIP path), and what
+comes back is the local shard bit for bit (BASELINE config 4 = config 3 per rank + this)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import MECHS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def rccl_world1():
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    torch.cuda.set_device(0)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,n', [('gri30_shaped', 512), ('h2o2_n2', 1000)])
+def test_dist_collectives_through_rccl_on_a_real_shard(name, n, rccl_world1):
+    import torch
+    import pyjac_amd
+    from pyjac_amd import synth
+    from pyjac_amd.dist import gather_shards, global_entry, iter_gathered, shard_checksums, shard_range
+    dist = rccl_world1
+    assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+    ev = pyjac_amd.Evaluator(MECHS[name])
+    pres, y = synth.dist_b(n, ev.nsp, seed=5, Tlo=900, Thi=2400)
+    lo, hi = shard_range(n, 0, 1)
+    assert (lo, hi) == (0, n)
+    local = ev.jacobian(torch.from_numpy(pres).cuda(), torch.from_numpy(np.ascontiguousarray(y)).cuda())
+    torch.cuda.synchronize()
+    assert local.is_cuda and local.shape == (ev.nsp * ev.nsp, n) and bool(torch.isfinite(local).all())
+    # one all_gather_into_tensor of the whole shard (rank-major [world][rows][n])
+    g = gather_shards(local)
+    assert g.shape == (1,) + tuple(local.shape) and torch.equal(g[0], local)
+    for st in (0, n // 2, n - 1):
+        assert torch.equal(global_entry(g, st, n, 1), local[:, st])
+    # the chunked form bench.py validates with: 77 states at a time through one receive buffer, ragged last chunk
+    seen, chunks = 0, 0
+    for c0, part in iter_gathered(local, 77):
+        cols = part.shape[2]
+        assert part.shape[:2] == (1, local.shape[0]) and cols == min(77, n - c0)
+        assert torch.equal(part[0], local[:, c0:c0 + cols])
+        seen += cols
+        chunks += 1
+    assert seen == n and chunks == -(-n // 77) and n % 77 != 0
+    # checksum of checksums
+    cs = shard_checksums(local)
+    assert cs.shape == (1, 2)
+    assert torch.equal(cs[0], torch.stack([local.sum(), (local * local).sum()]).to(torch.float64))
+    # a barrier + MAX all-reduce as bench.py brackets its timed region
+    t = torch.tensor([1.25], device='cuda', dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t) == 1.25

@@ -5,7 +5,7 @@ relative error (functional_tester/test.py:1446-1463)."""
 import numpy as np
 import pytest
 
-from conftest import MECHS, jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err, truth_report
+from conftest import FRONT_END, MECHS, THERMS, jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err, truth_report
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +52,7 @@ def torch_cuda():
 
 def _ev(name):
     import pyjac_amd
-    return pyjac_amd.Evaluator(MECHS[name])
+    return pyjac_amd.Evaluator(MECHS[name], THERMS.get(name))
 
 
 def _batch_api(ev, pres, y_soa):
@@ -71,7 +71,7 @@ def _batch_api(ev, pres, y_soa):
     return {k: v.reshape(-1, n).T for k, v in out.items()}
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'synth_srichb', 'synth_fracnu'])
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'synth_srichb', 'synth_fracnu'] + list(FRONT_END))
 def test_batch_api_matches_reference_golden(name, golden, tables, torch_cuda):
     g = golden(name)
     ev = _ev(name)
@@ -461,23 +461,26 @@ def test_jacobian_vector_product(name, fused, layout, tables, torch_cuda):
     assert (np.abs(w - ref) / scale).max() < 1e-9, (name, fused, layout)
 
 
-def test_finite_difference_arm(tables, torch_cuda):
-    """N3: the reference's FD Jacobian (fd_jacob.c) on the GPU dydt.  A forward difference
-    amplifies the ~1e-16 differences between GPU and CPU dydt by 1/r ~ 1e8 / |y_j|, so the
-    comparison is relative to each column's scale; it also has to agree with the analytical
-    Jacobian to truncation error."""
+@pytest.mark.parametrize('name,n,tol', [('h2o2_n2', 300, 1e-5), ('gri30_shaped', 48, 1e-4), ('usc2_shaped', 16, 1e-4)])
+def test_finite_difference_arm(name, n, tol, tables, torch_cuda):
+    """N3: the reference's FD Jacobian (fd_jacob.c / fd_jacob.cu:23-96) on the GPU dydt -- k_lane<2> for the H2
+    mechanism, the one-visit k_rate kernels for the 53- / 111-species ones (NSP + 1 rate passes per batch).  A
+    forward difference amplifies the ~1e-16 differences between GPU and CPU dydt by 1/r ~ 1e8 / |y_j|, so the
+    comparison is relative to each column's scale; it also has to agree with the analytical Jacobian to
+    truncation error."""
     from oracle.oracle import Oracle
     from pyjac_amd import synth
     torch = torch_cuda
-    ev = _ev('h2o2_n2')
-    n = 300
+    ev = _ev(name)
     pres, y = synth.dist_b(n, ev.nsp, seed=5, Tlo=900, Thi=2200)
     d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
     fd = ev.fd_jacobian(d_p, d_y).cpu().numpy().T.reshape(n, ev.nsp, ev.nsp)          # [s][col][row]
-    o = Oracle(tables('h2o2_n2'))
+    o = Oracle(tables(name))
     ref = np.array([o.fd_jacob(float(pres[s]), y[:, s].copy()) for s in range(n)]).reshape(n, ev.nsp, ev.nsp)
     colscale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
-    assert (np.abs(fd - ref) / colscale).max() < 1e-5
+    err = (np.abs(fd - ref) / colscale).max()
+    print('%s FD arm vs oracle FD (column-scaled): %.3g' % (name, err))
+    assert np.isfinite(fd).all() and err < tol
     ana = ev.jacobian(d_p, d_y).cpu().numpy().T.reshape(n, ev.nsp, ev.nsp)
     # first-order differences carry truncation error (large where a tiny Y_j gets the r0/ewt
     # increment); the bulk of the entries must still agree with the analytical Jacobian
@@ -807,3 +810,15 @@ def test_per_state_cache_serves_the_testers_call_sequence(golden, torch_cuda):
         fwd2, rev2 = np.zeros(ev.n_fwd), np.zeros(ev.n_rev)
         pyjacob.py_eval_rxn_rates(y[0], 2.0 * P, conc2, fwd2, rev2)
         assert pyjacob.cache_hits == h1 and not np.allclose(fwd2, cached['fwd'])
+        # a setting that changes results (the J_nplusone quirk switch) invalidates the cached state
+        pyjacob.py_eval_jacobian(0.0, P, y, np.zeros(nsp * nsp))        # refill the cache with (P, y)
+        h2 = pyjacob.cache_hits
+        ev.set_sum_last_species(True)
+        jac3 = np.zeros(nsp * nsp)
+        pyjacob.py_eval_jacobian(0.0, P, y, jac3)
+        assert pyjacob.cache_hits == h2, 'served a state cached under other evaluator settings'
+        ev.set_sum_last_species(False)
+        jac4 = np.zeros(nsp * nsp)
+        pyjacob.py_eval_jacobian(0.0, P, y, jac4)
+        assert pyjacob.cache_hits == h2 and np.array_equal(jac4, cached['jac'])
+        assert not np.array_equal(jac3, jac4)          # synth_alltypes has a reacting last species: jac[0] differs

@@ -101,3 +101,34 @@ def test_speedtest_protocol(tmp_path, capsys):
     line = capsys.readouterr().out.strip().splitlines()[0]
     assert line.split(',')[0] == str(n) and float(line.split(',')[1]) > 0     # "N,ms" (tester.c.in:31)
     assert r['kernel_ms'] > 0 and r['end_to_end_ms'] >= r['kernel_ms'] * 0.5
+
+
+def test_sweep_step_list_matches_reference_driver():
+    """performance_tester.py:341-347: powers of two below the number of conditions, then the number itself."""
+    assert pt.step_list(1) == [1]
+    assert pt.step_list(8) == [1, 2, 4, 8]
+    assert pt.step_list(10) == [1, 2, 4, 8, 10]
+    assert pt.step_list(1020) == [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1020]
+    assert pt.output_name(False) == 'cuda_nco_nosmem_ajac_-1_output.txt'
+    assert pt.output_name(True) == 'cuda_nco_nosmem_fd_-1_output.txt'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fd', [False, True])
+def test_sweep_writes_the_reference_drivers_lines(fd, tmp_path, capsys):
+    """The N = 1, 2, 4, ... sweep of the reference's GPU arm (performance_tester.py:341-347, 497-508): `repeats`
+    "N,ms" lines per batch size in the reference's output file."""
+    import pyjac_amd
+    a = np.load(os.path.join(ROOT, 'pyjac_amd', 'data', 'h2_pasr_output.npy'))
+    f = tmp_path / 'data.bin'
+    n = pt.write_data_bin(str(f), [a])
+    ev = pyjac_amd.Evaluator(MECHS['h2o2_n2'])
+    pres, y = pt.read_initial_conditions(str(f), n, ev.nsp, ev.mechanism.fwd_spec_map)
+    res = pt.sweep(ev, pres, y, repeats=2, fd=fd, out_dir=str(tmp_path))
+    steps = pt.step_list(n)
+    assert [r[0] for r in res] == steps and all(len(r[1]) == 2 and min(r[1]) > 0 for r in res)
+    lines = open(tmp_path / pt.output_name(fd)).read().strip().splitlines()
+    assert len(lines) == 2 * len(steps)
+    assert [int(l.split(',')[0]) for l in lines] == [s for s in steps for _ in range(2)]
+    assert all(float(l.split(',')[1]) > 0 for l in lines)
+    assert capsys.readouterr().out.strip().splitlines() == lines

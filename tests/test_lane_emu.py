@@ -13,7 +13,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'emu'))
-from conftest import MECHS, jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err  # noqa: E402
+from conftest import MECHS, THERMS, jac_scaled_err, mixed_err, rate_scales, thresholded_rel_err  # noqa: E402
 import build_emu  # noqa: E402
 import pyjac_amd  # noqa: E402
 from pyjac_amd import _lib, synth  # noqa: E402
@@ -22,8 +22,8 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _p = lambda a: a.ctypes.data_as(_dp)
 
 
-def _lane_emu(mech, tmp, tag):
-    ev = pyjac_amd.Evaluator(mech, specialize='off')
+def _lane_emu(mech, tmp, tag, therm=None):
+    ev = pyjac_amd.Evaluator(mech, therm, specialize='off')
     hdr = os.path.join(tmp, tag + '.h')
     _lib.check(_lib.lib().pj_mech_emit_spec(ev._h, hdr.encode()))
     so = os.path.join(tmp, 'liblane_%s.so' % tag)
@@ -74,10 +74,11 @@ def _check_all_modes(ev, L, orc, tab, n=40, seed=5):
     assert mixed_err(bufs['dy'].T, g['dydt'], sdy) <= 1.0
 
 
-@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes'])
+# (fe_septherm: species with three different T_mid -- several pre-summed K_c groups per reaction)
+@pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'fe_septherm'])
 def test_lane_kernel_modes_vs_oracle(name, tmp_path, tables):
     from oracle.oracle import Oracle
-    ev, L = _lane_emu(MECHS[name], str(tmp_path), name)
+    ev, L = _lane_emu(MECHS[name], str(tmp_path), name, THERMS.get(name))
     _check_all_modes(ev, L, Oracle(tables(name)), tables(name))
 
 

@@ -11,7 +11,9 @@ KEYS = ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')
 
 
 @pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24',
-                                  'synth_srichb', 'synth_fracnu', 'synth_irrev72'])
+                                  'synth_srichb', 'synth_fracnu', 'synth_irrev72',
+                                  # front-end corners: units keywords, separate thermo database (conftest.FRONT_END)
+                                  'fe_kcal', 'fe_kelvins', 'fe_kjoules', 'fe_joules', 'fe_evolts', 'fe_septherm'])
 def test_oracle_matches_reference_golden(name, golden, tables):
     g = golden(name)
     tab = tables(name)

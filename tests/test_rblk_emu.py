@@ -82,6 +82,8 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     # third-body and falloff reactions and with the last species as a reactant
     ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6)),
     ('synth_fracnu', 200, dict(blocks_per_part=1, rates_per_part=1000, c_lds=1)),
+    # species with three different T_mid (separate thermo database): several pre-summed K_c groups per reaction
+    ('fe_septherm', 16, dict(blocks_per_part=2, rates_per_part=9)),
 ])
 def test_rblk_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     """Row blocks that rebuild their rates (Arrhenius, K_c, third body, theta per visit), the falloff /
@@ -91,7 +93,8 @@ def test_rblk_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     ev, L = _rblk_emu_lib(name, budget, str(tmp_path), **kw)
     orc = Oracle(tables(name))
     n = 300                               # crosses a 256-state hand-over tile
-    pres, y = synth.dist_b(n, ev.nsp)
+    # (T from 300 K: every range of every species' NASA polynomials and K_c group is visited)
+    pres, y = synth.dist_b(n, ev.nsp) if name != 'fe_septherm' else synth.dist_b(n, ev.nsp, seed=3, Tlo=300, Thi=2600)
     ref = orc.batch_jacob(pres, np.ascontiguousarray(y.T))
     for aos in (False, True):
         jac = _run(L, ev.nsp, pres, y, aos=aos)
