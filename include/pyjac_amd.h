@@ -99,15 +99,22 @@ int pj_mech_emit_spec(const pj_mech* m, const char* header_path);
 int pj_mech_emit_rows_spec(const pj_mech* m, const char* header_path, int acc_budget);
 /* ... plus the kernel plan of a pj_rblk.hip library (NKER / KER_B / KER_BM: row blocks [B0, B1) of each row kernel
  * and where its two lane groups meet; NRATE / RATE_R: reactions of each rate kernel).  fuse: row blocks per
- * kernel and lane group at most; block, halves: states per workgroup and lane groups (1 | 2) of the row
- * kernels; rate_block, rate_c_lds: states per workgroup of the rate kernels and whether they keep the
+ * kernel and lane group at most; block, halves: states per workgroup and lane groups (1 | 2 | 4, on the same states)
+ * of the row kernels, KER_GB: first row block of each lane group; single != 0: ONE row kernel takes every row block
+ * (the state is read once, no hand-over of the energy-row sums between kernels); rate_block, rate_c_lds: states per workgroup of the rate kernels and whether they keep the
  * concentrations in LDS; rate_groups: K_c groups per rate kernel at most (0: what fits the LDS); cost_visit /
  * cost_entry (<= 0: defaults): balance of the two lane groups.  counts (may be null): [0] row kernels,
  * [1] rate kernels, [2] reactions evaluated by the pre-pass, [3] row blocks, [4] reaction visits.
  * (pyJac's counterpart: the generation step, python -m pyjac; libgen/libgen.py:330-420 compiles its output) */
 int pj_mech_emit_rblk_spec(const pj_mech* m, const char* header_path, int acc_budget, int fuse, int block, int halves,
-                           int rate_block, int rate_c_lds, int rate_groups, double cost_visit, double cost_entry,
-                           int* counts);
+                           int single, int rate_block, int rate_c_lds, int rate_groups, double cost_visit,
+                           double cost_entry, int* counts);
+/* Equilibrium constants from per-species factors for the pj_rblk.hip row kernels (PJQ_KCF): rows = [nsp][15] doubles
+ * (T_mid, lo[7], hi[7]) of the shifted ln X_k in pyJac's K_c polynomial form (rate_subs.py:540-558, 660-809), with
+ * 1 / K_c,i = (p_atm / R_u)^(-sum nu) prod_k X_k^(-nu_ki) -- one exp per species and state instead of one per
+ * reaction visit; computed by the host front end from the stoichiometry (pyjac_amd/kcfactors.py).  n = 15 * nsp, or
+ * 0 / rows = NULL to go back to the per-reaction polynomial form.  Only shapes the headers the emit functions write. */
+int pj_mech_set_kc_factors(pj_mech* m, const double* rows, long n);
 /* dlopen a library built from pj_lane.hip / pj_rblk.hip for this mechanism (hash-checked) and
  * route pj_eval_jacobian_dev / pj_run / pj_eval_jacob through it */
 int pj_mech_attach_spec(pj_mech* m, const char* library_path);

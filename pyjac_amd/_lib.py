@@ -40,8 +40,9 @@ SIGNATURES = {
     'pj_mech_spec_hash': (ctypes.c_ulonglong, [_vp]),
     'pj_mech_emit_spec': (ctypes.c_int, [_vp, ctypes.c_char_p]),
     'pj_mech_emit_rows_spec': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
-    'pj_mech_emit_rblk_spec': (ctypes.c_int, [_vp, ctypes.c_char_p] + [ctypes.c_int] * 7 + [ctypes.c_double] * 2 +
+    'pj_mech_emit_rblk_spec': (ctypes.c_int, [_vp, ctypes.c_char_p] + [ctypes.c_int] * 8 + [ctypes.c_double] * 2 +
                                [ctypes.POINTER(ctypes.c_int)]),
+    'pj_mech_set_kc_factors': (ctypes.c_int, [_vp, _dp, ctypes.c_long]),
     'pj_mech_attach_spec': (ctypes.c_int, [_vp, ctypes.c_char_p]),
     'pj_mech_has_spec': (ctypes.c_int, [_vp]),
     'pj_mech_use_spec': (ctypes.c_int, [_vp, ctypes.c_int]),

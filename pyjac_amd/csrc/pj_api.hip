@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -714,14 +715,27 @@ int pj_mech_emit_rows_spec(const pj_mech* m, const char* header_path, int acc_bu
     return ok ? PJ_OK : fail(PJ_EIO, "short write");
 }
 
+int pj_mech_set_kc_factors(pj_mech* m, const double* rows, long n)
+{
+    if (!m || n < 0 || (n > 0 && (!rows || n != (long)m->P.nsp * KCW))) return fail(PJ_EINVAL, "kc factor rows: [nsp][15] doubles");
+    try {
+        m->P.kcf.assign(rows, rows + n);
+    } catch (const std::exception& ex) {
+        return fail(PJ_ENOMEM, ex.what());
+    }
+    for (double v : m->P.kcf)
+        if (!(v == v) || v > 1e300 || v < -1e300) { m->P.kcf.clear(); return fail(PJ_EINVAL, "kc factor rows: not finite"); }
+    return PJ_OK;
+}
+
 int pj_mech_emit_rblk_spec(const pj_mech* m, const char* header_path, int acc_budget, int fuse, int block, int halves,
-                           int rate_block, int rate_c_lds, int rate_groups, double cost_visit, double cost_entry,
-                           int* counts)
+                           int single, int rate_block, int rate_c_lds, int rate_groups, double cost_visit,
+                           double cost_entry, int* counts)
 {
     if (acc_budget < 8) return fail(PJ_EINVAL, "accumulator budget too small");
-    if (block < 1 || rate_block < 1 || fuse < 1 || (halves != 1 && halves != 2)) return fail(PJ_EINVAL, "kernel plan options");
+    if (block < 1 || rate_block < 1 || fuse < 1 || (halves != 1 && halves != 2 && halves != 4)) return fail(PJ_EINVAL, "kernel plan options");
     RblkPlanOpts O;
-    O.fuse = fuse; O.block = block; O.halves = halves; O.rate_block = rate_block; O.rate_c_lds = rate_c_lds;
+    O.fuse = fuse; O.block = block; O.halves = halves; O.single = single != 0; O.rate_block = rate_block; O.rate_c_lds = rate_c_lds;
     O.rate_groups = rate_groups;
     if (cost_visit > 0.0) O.cost_visit = cost_visit;
     if (cost_entry > 0.0) O.cost_entry = cost_entry;
@@ -965,13 +979,12 @@ int pj_debug_phase_cycles(pj_mech* m, long n, const double* d_pres, const double
 // ---- batched LU / Newton solves on per-state blocks (pj_lu.h) ----
 static int lu_cus()
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    return cus;
+    static int cus[64] = {};        // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev] &&
+        (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] <= 0)) cus[dev] = 256;
+    return cus[dev];
 }
 static int lu_call(int nsp, long n, const double* a, int a_layout, double gamma, double* lu, int* perm, const double* b, double* x,
                    int vec_layout, int mode, void* stream)
@@ -1007,6 +1020,19 @@ int pj_newton_solve_dev(int nsp, long n, const double* d_a, int a_layout, double
 {
     if (n > 0 && (!d_a || !d_b || !d_x)) return fail(PJ_EINVAL, "null device pointer");
     if ((d_lu == nullptr) != (d_perm == nullptr)) return fail(PJ_EINVAL, "d_lu and d_perm: both or neither");
+    // the same restriction as pj_lu_factor_dev: stored factors are per state, and a wavefront's factor stores would
+    // overwrite batch-layout entries of states that other wavefronts have not loaded yet
+    if (d_lu == d_a && a_layout != PJ_LAYOUT_AOS) return fail(PJ_EINVAL, "in-place factorisation needs the per-state layout");
+    // the solution must not overlap the blocks or the factors (blocks of other states are still being read)
+    {
+        const char *x0 = (const char*)d_x, *x1 = x0 + sizeof(double) * (size_t)nsp * (size_t)n;
+        const char *a0 = (const char*)d_a, *a1 = a0 + sizeof(double) * (size_t)nsp * (size_t)nsp * (size_t)n;
+        if (nsp > 0 && n > 0 && x0 < a1 && a0 < x1) return fail(PJ_EINVAL, "d_x overlaps d_a");
+        if (d_lu && nsp > 0 && n > 0) {
+            const char *l0 = (const char*)d_lu, *l1 = l0 + sizeof(double) * (size_t)nsp * (size_t)nsp * (size_t)n;
+            if (x0 < l1 && l0 < x1) return fail(PJ_EINVAL, "d_x overlaps d_lu");
+        }
+    }
     return lu_call(nsp, n, d_a, a_layout, gamma, d_lu, d_perm, d_b, d_x, vec_layout, pj::LU_FACTOR | pj::LU_SOLVE, stream);
 }
 

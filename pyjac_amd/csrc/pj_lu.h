@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
         if (!pre) {
             // pivot of column c0 among rows c0 .. nsp-1, by the lower half of wavefront 0 (lane tr: rows c0 + tr + 32 q --
             // for c0 = k + 1 exactly the entries those lanes have just updated): maximum magnitude, ties to the lowest
-            // lane.  Left in red_i[0] for the next step: no barrier, no pivot-column read for the other wavefronts.
+            // row.  Left in red_i[0] for the next step: no barrier, no pivot-column read for the other wavefronts.
             auto search = [&](const int c0) {
                 double best = -1.0; int brow = c0;
 #pragma unroll
@@ -340,9 +340,20 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
                     }
                 }
                 const double mx = lu_wave_max(best);
-                const unsigned long long hit = __builtin_amdgcn_ballot_w64(best == mx && best >= 0.0);
+                // among the lanes that hold the maximum the LOWEST ROW wins (a lane scans rows c0 + tr + 32 q, so the
+                // lowest lane need not hold the lowest row): the first row of maximum magnitude, as k_lu and dgetf2
+                const bool mine = best == mx && best >= 0.0;
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(mine);
                 if (hit == 0) { if (tid == 0) red_i[0] = c0; }             // a column of NaNs
-                else if (lane == (int)__builtin_ctzll(hit)) red_i[0] = brow;
+                else {
+                    int lowest = mine ? brow : 0x7fffffff;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const int o = __shfl_xor(lowest, off, 64);
+                        lowest = o < lowest ? o : lowest;
+                    }
+                    if (lane == 0) red_i[0] = lowest;
+                }
             };
             if (wave == 0) search(0);
             __syncthreads();
@@ -644,10 +655,13 @@ inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, do
     if (nsp > 64) {
         const int ld = nsp | 1;
         const size_t lds = sizeof(double) * ((size_t)ld * nsp + nsp + 4) + sizeof(int) * (4 + (size_t)nsp);
-        static bool attr_set = false;
-        if (!attr_set) {
+        // (per device: a function attribute belongs to the device that was current when it was set)
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -2;
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             if (hipFuncSetAttribute((const void*)k_lu_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
-            attr_set = true;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         const long slots = (n + 127) / 128 * 128;
         long blocks = slots < (long)cus * 4 ? slots : (long)cus * 4;

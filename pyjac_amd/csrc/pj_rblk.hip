@@ -83,8 +83,20 @@ using namespace pj;
 #define PJQ_STREAMS 1       // internal streams the chunks of a batch are dealt to
 #endif
 #ifndef PJQ_HALVES
-#define PJQ_HALVES 1        // 2: a workgroup is two groups of PJQ_BLOCK lanes that share the PJQ_BLOCK states'
-                            // concentration columns and run different row blocks ([B0,BM) and [BM,B1))
+#define PJQ_HALVES 1        // 2 / 4: a workgroup is that many groups of PJQ_BLOCK lanes that share the PJQ_BLOCK states'
+                            // concentration columns and run different row blocks (k_rblk)
+#endif
+#ifndef PJQ_KCF
+#define PJQ_KCF 0           // 1: equilibrium constants as products of per-species factors X_k that the prologue puts
+                            // into LDS columns next to the concentrations (one exp per species and state) instead of a
+                            // 7-term polynomial and an exp per reversible visit (k_rblk; pyjac_amd/kcfactors.py)
+#endif
+#ifndef PJQ_SINGLE
+#define PJQ_SINGLE 0        // 1: the library has ONE row kernel (nothing is handed from row kernel to row kernel)
+#endif
+#ifndef PJQ_SUMSETS
+#define PJQ_SUMSETS (PJQ_SINGLE ? 0 : 2 * PJQ_HALVES)   // slot sets of the energy-row sums between row kernels: a pair
+                            // per lane group of the ROW kernels (every translation unit of a library gets the same value)
 #endif
 #ifndef PJQ_CONC_AHEAD
 #define PJQ_CONC_AHEAD 1    // 1: a visit's concentration reads are issued during the previous visit (-1 %)
@@ -103,8 +115,6 @@ using namespace pj;
 #endif
 #define PJQ_TILE 256        // states per scratch tile
 #if defined(PJR_HOST_EMU)
-#define PJQ_E_ADD(ptr, val) (*(ptr) += (val))
-#define PJQ_E_READ(ptr) (*(ptr))
 #define PJQ_STORE(ptr, val) (*(ptr) = (val))
 #define PJQ_LOAD_NT(ptr) (*(ptr))
 #define PJQ_SCHED_BARRIER()
@@ -126,9 +136,6 @@ using namespace pj;
 #endif
 #define PJQ_LOAD_NT(ptr) __builtin_nontemporal_load(ptr)
 #define PJQ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-// energy-row sums: no-return fp64 atomic add performed in the L2 (global_atomic_add_f64), read back past the L1
-#define PJQ_E_ADD(ptr, val) ((void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)(ptr), (val)))
-#define PJQ_E_READ(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 // debug builds (-DPJQ_TIMING): shader cycles per phase and wavefront, summed over a kernel
@@ -176,21 +183,11 @@ constexpr int NSUM = 5 + (pjs::NSP - 1);   // H, SCP, SJT, HP, HQ, E_j
 #ifdef PJQ_ID
 constexpr int SUM_IN = pjs::NSCQ + (PJQ_ID % 2) * NSUM, SUM_OUT = pjs::NSCQ + ((PJQ_ID + 1) % 2) * NSUM;
 #endif
-// PJQ_E_ATOMIC = 1 (experiment, measured and switched off): the LAST partial sums E_j of the energy row are not
-// carried in registers (52 / 110 doubles per lane: the AGPRs of the 53-species kernels, spills in the 111-species
-// ones, five instructions per update) -- every update is one no-return fp64 atomic add (global_atomic_add_f64,
-// performed in the L2) into a per-state array behind the slot sets: [lane group][real | trash][wavefront of the
-// tile][j][64 lanes].  One lane owns a state's sums within a kernel and kernels of a batch run in stream order, so
-// the sums are deterministic; lanes that evaluate a state a second time (shifted last workgroup) add to the trash
-// copy, lanes past the end to the slots of the state index they would have had.  The first row kernel zeroes the
-// sums, the last one reads them back.  Results agree with the register form to rounding, 8 % fewer instructions
-// and half the AGPRs -- and 7.0 -> 11.1 ms (GRI-shaped), 6.5 -> 8.8 ms (USC-shaped): 1.8 k / 5.7 k atomic adds per
-// state are more than the L2 takes next to the Jacobian stores (profiles/r03_rblk_energy_row_atomics.txt).
-#ifndef PJQ_E_ATOMIC
-#define PJQ_E_ATOMIC 0
-#endif
-constexpr int E_BASE = pjs::NSCQ + 2 * PJQ_HALVES * NSUM;     // with two halves: a pair of sets per half
-constexpr int NSLOTS = E_BASE + (PJQ_E_ATOMIC ? PJQ_HALVES * 2 * (pjs::NSP - 1) : 0);
+// (Tried and removed: the LAST partial sums E_j as no-return fp64 atomic adds into a per-state array instead of
+// registers -- 8 % fewer instructions, half the AGPRs, and 7.0 -> 11.1 ms (GRI-shaped), 6.5 -> 8.8 ms (USC-shaped):
+// 1.8 k / 5.7 k atomic adds per state are more than the L2 takes next to the Jacobian stores;
+// profiles/r03_rblk_energy_row_atomics.txt.)
+constexpr int NSLOTS = pjs::NSCQ + PJQ_SUMSETS * NSUM;
 
 // reactions evaluated once per state by k_pre and handed over
 constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG | F_CHEB)) != 0; }
@@ -210,6 +207,17 @@ template <int I0, int I1, class F>
 __device__ __forceinline__ void static_range(F&& f)
 {
     if constexpr (I1 > I0) static_for_seq<I0>(f, std::make_integer_sequence<int, I1 - I0>{});
+}
+// f(integral_constant<g>) for the one g == grp of [G0, G1): an if / else-if chain on a wavefront-uniform value
+template <int G0, int G1, class F>
+__device__ __forceinline__ void group_dispatch(const int grp, F&& f)
+{
+    if constexpr (G0 + 1 >= G1) {
+        f(std::integral_constant<int, G0>{});
+    } else {
+        if (grp == G0) f(std::integral_constant<int, G0>{});
+        else group_dispatch<G0 + 1, G1>(grp, f);
+    }
 }
 
 #include "pj_math.h"
@@ -495,16 +503,21 @@ struct Reg { Reg() { pjq_register(0, 1, launch_pre); } } reg_;
 #ifndef PJQ_B0      // from the kernel plan
 #define PJQ_B0 pjs::KER_B[PJQ_ID][0]
 #define PJQ_B1 pjs::KER_B[PJQ_ID + 1][0]
-#define PJQ_BM pjs::KER_BM[PJQ_ID][0]
+#define PJQ_PLAN 1
 #define PJQ_FIRST (PJQ_ID == 0)
 #define PJQ_LAST (PJQ_ID == pjs::NKER - 1)
+#else
+#define PJQ_PLAN 0
 #endif
 constexpr int B0_ = PJQ_B0, B1_ = PJQ_B1;
 constexpr bool FIRST_ = PJQ_FIRST != 0, LASTK_ = PJQ_LAST != 0;
+static_assert(!PJQ_KCF || pjs::KCF_OK, "PJQ_KCF needs the per-species factor rows (pj_mech_set_kc_factors)");
+static_assert(!PJQ_SINGLE || (FIRST_ && LASTK_), "PJQ_SINGLE: one row kernel");
 constexpr KcMap make_kcmap()
 {
     KcMap m{};
     for (int g = 0; g < NKC_ALL; ++g) m.loc[g] = -1;
+    if (PJQ_KCF) return m;          // no per-reaction polynomial rows at all
     for (int b = B0_; b < B1_; ++b)
         for (int v = pjs::BLK_RX_PTR[b][0]; v < pjs::BLK_RX_PTR[b + 1][0]; ++v) kcmap_add(m, pjs::BLK_RX[v][0]);
     return m;
@@ -523,6 +536,14 @@ constexpr int max_kc_cnt()
     return m;
 }
 constexpr int MAXKC = max_kc_cnt();
+constexpr int max_net_cnt()
+{
+    int m = 1;
+    for (int i = 0; i < NRXN; ++i)
+        if ((pjs::RI[i][RI_FLAGS] & F_REV) && pjs::RI[i][RI_NET_CNT] > m) m = pjs::RI[i][RI_NET_CNT];
+    return m;
+}
+constexpr int MAXNET = max_net_cnt();
 
 template <int i>
 constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
@@ -539,33 +560,144 @@ constexpr int n_pre_visits()
 __device__ long long g_tim[5][1024][4];
 #endif
 
-// PJQ_HALVES == 2 (mechanisms whose concentration columns leave room for 128 lanes only): the workgroup
-// is 256 threads, two groups ("halves") of PJQ_BLOCK lanes.  Both hold the same PJQ_BLOCK states -- lane l
-// of either half is state l -- and share one set of concentration columns and K_c rows in LDS; half 0
-// runs the row blocks [B0, BM), half 1 the blocks [BM, B1).  All four SIMDs of a CU work instead of two,
-// for the same LDS.  Each half carries its own energy-row sums from kernel to kernel (own slot sets);
-// in the last kernel half 1 hands its sums to half 0 through the (then free) concentration columns.
-constexpr int NTHR = PJQ_BLOCK * PJQ_HALVES;
-#ifndef PJQ_BM
-#define PJQ_BM PJQ_B1
+// Lane groups (PJQ_HALVES = G: 1, 2 or 4).  The workgroup is G groups of PJQ_BLOCK lanes ON THE SAME PJQ_BLOCK
+// STATES -- lane l of every group is state l -- that share one set of concentration columns (and factor columns /
+// K_c rows) in LDS and run different row blocks: group g takes the blocks [GB(g), GB(g + 1)) of the kernel.  All four
+// SIMDs of a CU work for the LDS of PJQ_BLOCK states: 128 states and two groups where 111 species leave room for
+// no more; 64 states and four groups where the per-species factor columns of PJQ_KCF take the room (then ONE kernel
+// covers every row block: the state is read once, nothing is handed from kernel to kernel).  Each group carries its
+// own energy-row sums (own slot sets between kernels); in the last kernel the groups exchange them through the
+// then free columns and share the columns of the energy row.
+constexpr int G_ = PJQ_HALVES;
+constexpr int NTHR = PJQ_BLOCK * G_;
+static_assert(G_ == 1 || G_ == 2 || G_ == 4, "PJQ_HALVES: 1, 2 or 4 lane groups");
+constexpr int group_first_block(int g)
+{
+#if PJQ_PLAN
+    if (pjs::KER_NG == G_) return pjs::KER_GB[PJQ_ID][g];
 #endif
-constexpr int BM_ = PJQ_HALVES == 2 ? PJQ_BM : PJQ_B1;
-static_assert(PJQ_HALVES == 1 || PJQ_HALVES == 2, "PJQ_HALVES: 1 or 2");
-static_assert(PJQ_HALVES == 1 || (BM_ > PJQ_B0 && BM_ < PJQ_B1), "PJQ_BM must split [B0, B1)");
+#ifdef PJQ_BM
+    if (G_ == 2) return g == 0 ? B0_ : g == 1 ? (int)(PJQ_BM) : B1_;
+#endif
+    return B0_ + (int)((long)(B1_ - B0_) * g / G_);        // (tests: explicit block ranges, even split)
+}
+// species (prologue of the PJQ_KCF kernels) and energy-row columns (epilogue) of group g: contiguous, even
+constexpr int group_first_species(int g) { return (int)((long)NSP * g / G_); }
+constexpr int group_first_col(int g) { return (int)((long)LAST * g / G_); }
+constexpr int col_owner(int j)
+{
+    for (int g = 0; g < G_; ++g) if (j < group_first_col(g + 1)) return g;
+    return G_ - 1;
+}
+// is species k a net reactant / product of some reversible reaction (its factor column is read)?
+constexpr bool kcf_used(int k)
+{
+    for (int i = 0; i < NRXN; ++i)
+        if (pjs::RI[i][RI_FLAGS] & F_REV)
+            for (int q = 0; q < pjs::RI[i][RI_NET_CNT]; ++q)
+                if (pjs::NET_SP[pjs::RI[i][RI_NET_PTR] + q][0] == k) return true;
+    return false;
+}
+
+// LDS of a workgroup, one raw array (doubles):
+//   main phase   CL[NSP][BLOCK] concentrations | PJQ_KCF: XT[NSP][BLOCK] {X_k, t_k}, IXT[NSP][BLOCK] {1/X_k, t_k}
+//                (t_k = h_k/RT - 1 rides along: one 16-byte read per net species and visit; tried: three 8-byte
+//                columns X, 1/X, t -- the 27 KB of the second copy of t_k hold 14 more energy-row sums per lane
+//                group, see below -- and the kernels spill MORE: 8.3 .. 11 ms against 5.9) | else LTK[NKC][16] the
+//                kernel's K_c polynomial rows | PRED23[2][G][BLOCK] partial c_p sums of the cooperative prologue (read
+//                by the epilogue) | EL[G][NEL][BLOCK] energy-row sums (below); the prologue's first partial sums
+//                PRED01[2][G][BLOCK] use the same room before EL is cleared
+//   epilogue     (last kernel, G > 1, after a barrier) EX[LAST - NEL][G-1][BLOCK] register-resident energy-row sums on
+//                their way to the group that owns the column | RED[6][G][BLOCK] the scalar sums
+// Energy-row sums in LDS.  A lane group carries LAST partial sums E_j through the kernel (104 registers of the 512
+// a lane has); with the factor columns next to them the kernels spill, and a spill reload sits behind every Jacobian
+// store issued before it (vmcnt is in order): 9.2 ms per 1e6 GRI-shaped states against 5.7 ms for the same kernel
+// without the sums.  So as many of them as the LDS has room for (the columns with the most structural non-zeros first)
+// live in LDS, one slot per lane group, column and lane -- a single writer each, so the order of the additions is
+// fixed -- and an update is ONE ds_add_f64 instead of five instructions on an AGPR pair.
+constexpr int SM_CL = 0;
+constexpr int SM_XT = SM_CL + NSP * PJQ_BLOCK;
+constexpr int SM_IXT = SM_XT + (PJQ_KCF ? 2 * NSP * PJQ_BLOCK : 0);
+constexpr int SM_LTK = SM_IXT + (PJQ_KCF ? 2 * NSP * PJQ_BLOCK : 0);
+constexpr int SM_PRED23 = SM_LTK + (NKC > 0 ? NKC * 16 : 0);
+constexpr int SM_EL = SM_PRED23 + (PJQ_KCF && G_ > 1 ? 2 * G_ * PJQ_BLOCK : 0);
+#ifndef PJQ_NEL
+#define PJQ_NEL (-1)        // energy-row sums per lane group that live in LDS; -1: as many as fit
+#endif
+constexpr int nel_fit()
+{
+    const long room = (160L * 1024 / 8 - SM_EL) / ((long)G_ * PJQ_BLOCK);
+    const long need01 = (PJQ_KCF && G_ > 1) ? 2 : 0;        // PRED01 borrows the room of two columns' worth per group
+    long n = room < LAST ? room : LAST;
+    if (n < need01 && room >= need01) n = n;                // (PRED01 only needs the ROOM, see SM_MAIN)
+    return (int)(n < 0 ? 0 : n);
+}
+constexpr int NEL_ = PJQ_NEL >= 0 ? (PJQ_NEL < LAST ? PJQ_NEL : LAST) : nel_fit();
+constexpr int SM_EL_DOUBLES = G_ * PJQ_BLOCK * (NEL_ > 2 ? NEL_ : (PJQ_KCF && G_ > 1 ? 2 : NEL_));
+constexpr int SM_MAIN = SM_EL + SM_EL_DOUBLES;
+constexpr int SM_EX = 0;
+constexpr int SM_RED = SM_EX + (LAST - NEL_) * (G_ - 1) * PJQ_BLOCK;
+constexpr int SM_EPI = (G_ > 1 && LASTK_) ? SM_RED + 6 * G_ * PJQ_BLOCK : 0;
+constexpr int SM_DOUBLES = SM_MAIN > SM_EPI ? SM_MAIN : SM_EPI;
+static_assert(SM_DOUBLES * 8 <= 160 * 1024, "LDS: columns of PJQ_BLOCK states do not fit");
+static_assert(!(G_ > 1 && LASTK_) || SM_EPI <= SM_PRED23 || NEL_ == 0, "LDS: the epilogue's exchange area must not reach the sums kept in LDS");
+// which columns' sums live in LDS: those with the most structural non-zeros (the most updates)
+constexpr int col_nnz(int j)
+{
+    int c = 0;
+    for (int k = 0; k < NSP; ++k) c += pjs::SLOC[k][j] >= 0 ? 1 : 0;
+    return c;
+}
+struct ElMap { int slot[LAST > 0 ? LAST : 1]; };
+constexpr ElMap make_elmap()
+{
+    ElMap m{};
+    int cnt[LAST > 0 ? LAST : 1] = {};
+    for (int j = 0; j < LAST; ++j) cnt[j] = col_nnz(j);
+    for (int j = 0; j < LAST; ++j) {
+        int rank = 0;
+        for (int q = 0; q < LAST; ++q) rank += (cnt[q] > cnt[j] || (cnt[q] == cnt[j] && q < j)) ? 1 : 0;
+        m.slot[j] = rank < NEL_ ? rank : -1;
+    }
+    return m;
+}
+constexpr ElMap ELM = make_elmap();
+// index of a register-resident column among the register-resident ones (the exchange area of the epilogue)
+constexpr int ex_index(int j)
+{
+    int c = 0;
+    for (int q = 0; q < j; ++q) c += ELM.slot[q] < 0 ? 1 : 0;
+    return c;
+}
+#ifdef PJR_HOST_EMU
+#define PJQ_LDS_ADD(ptr, val) (*(ptr) += (val))
+#else
+#define PJQ_LDS_ADD(ptr, val) ((void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ptr), (val)))
+#endif
+
 __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 {
+    __shared__ __attribute__((aligned(16))) double SM[SM_DOUBLES];
     // Concentrations live in LDS, one column per lane (bank-conflict free)
-    __shared__ double CL[NSP][PJQ_BLOCK];
+    double (*const CL)[PJQ_BLOCK] = (double (*)[PJQ_BLOCK])(SM + SM_CL);
     // NASA row pairs of every K_c group (the low / high range select is per lane)
-    // (the last kernel of a two-half build also passes four sums per state from half 1 to half 0 through it)
-    constexpr int LTK_X = (PJQ_HALVES == 2 && LASTK_) ? 4 * PJQ_BLOCK : 1;
-    __shared__ __attribute__((aligned(16))) double LTK[(NKC * 16 > LTK_X ? NKC * 16 : LTK_X)];
+    double* const LTK = SM + SM_LTK;
+#if PJQ_KCF
+    d2 (*const XT)[PJQ_BLOCK] = (d2 (*)[PJQ_BLOCK])(SM + SM_XT);
+    d2 (*const IXT)[PJQ_BLOCK] = (d2 (*)[PJQ_BLOCK])(SM + SM_IXT);
+#endif
 #ifdef PJQ_TIMING
     long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64();
 #endif
-    // half: wavefront-uniform; tid: the lane's index within its half = its state's index in the workgroup
-    const int half = PJQ_HALVES == 2 ? (int)(threadIdx.x >= PJQ_BLOCK) : 0;
-    const int tid = (int)threadIdx.x - half * PJQ_BLOCK;
+    // grp: wavefront-uniform -- and the compiler has to know (readfirstlane: a scalar), or the group branches below
+    // become divergent regions that every wavefront walks through under an execution mask, with the registers of
+    // all of them allocated together; tid: the lane's index within its group = its state's index in the workgroup
+#ifdef PJR_HOST_EMU
+    const int grp = G_ > 1 ? (int)threadIdx.x / PJQ_BLOCK : 0;
+#else
+    const int grp = G_ > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / PJQ_BLOCK) : 0;
+#endif
+    const int tid = (int)threadIdx.x - grp * PJQ_BLOCK;
     // lanes past the end repeat the last state (same values to the same addresses): no divergence
 #if PJQ_PAIR
     // pair stores need whole lane pairs: the last workgroup is shifted back over states its neighbour
@@ -574,21 +706,100 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     if (s0_wg + PJQ_BLOCK > A.n) s0_wg = A.n - PJQ_BLOCK;
     // lanes 0..31 of a wavefront: its even states, lanes 32..63: the odd ones (swap_halves)
     const long s = s0_wg + (tid & ~63) + 2 * (tid & 31) + ((tid >> 5) & 1);
-    // a state of the shifted workgroup that its neighbour evaluates too: its energy-row sums go to the trash copy
-    const long e_state = s;
-    const bool e_dup = s < (long)blockIdx.x * PJQ_BLOCK;
 #else
     long s = (long)blockIdx.x * PJQ_BLOCK + tid;
-    // lanes past the end accumulate their energy-row sums in the (unused) slots of the state index they would have
-    const long e_state = s;
-    const bool e_dup = false;
     if (s >= A.n) s = A.n - 1;
 #endif
 #ifdef PJQ_NO_STORE
     double pjq_sink = 0.0;
 #endif
     double T, rho, invrho, Wbar, mconc;
+    double cpa = 0.0, dcpa = 0.0;       // sum_k C_k cp_k / R and its d/dT: PJQ_KCF prologue, else the last kernel's epilogue
     PJQ_CONST_BASES()
+#if PJQ_KCF
+    {
+        // Cooperative prologue: group g loads the mass fractions of ITS species, the groups exchange partial sums,
+        // and each turns its species into concentration, factor and enthalpy columns for all of them:
+        // X_k = exp(ln X_k), 1 / X_k and t_k = h_k/RT - 1 -- NSP / G exponential pairs per lane instead of one per
+        // reversible visit.
+        double (*const PRED)[G_ > 1 ? G_ : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ : 1][PJQ_BLOCK])(SM + SM_EL);        // PRED01
+        double (*const PRED23)[G_ > 1 ? G_ : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ : 1][PJQ_BLOCK])(SM + SM_PRED23);
+        const double* const y = A.y + s * A.y_ss;
+        T = y[0];
+        const double p = A.pres[s];
+        constexpr int KMAXG = (NSP + G_ - 1) / G_ + 1;
+        double Y[KMAXG];
+        double sumY = 0.0, sumYW = 0.0;
+        static_for<G_>([&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            constexpr int k0 = group_first_species(g), k1 = group_first_species(g + 1);
+            if (G_ == 1 || grp == g) {
+                static_range<k0, k1>([&](auto kc) PJR_INL {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < LAST) Y[k - k0] = y[(k + 1) * A.y_si];
+                });
+                PJQ_SCHED_BARRIER();
+                static_range<k0, k1>([&](auto kc) PJR_INL {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < LAST) { sumY += Y[k - k0]; sumYW += Y[k - k0] * pjs::SP[k][0]; }
+                });
+            }
+        });
+        if constexpr (G_ > 1) {
+            PRED[0][grp][tid] = sumY; PRED[1][grp][tid] = sumYW;
+            __syncthreads();
+            sumY = 0.0; sumYW = 0.0;
+            static_for<G_>([&](auto gc) PJR_INL { sumY += PRED[0][decltype(gc)::value][tid]; sumYW += PRED[1][decltype(gc)::value][tid]; });
+        }
+        const double yN = 1.0 - sumY;
+        sumYW += yN * pjs::SP[LAST][0];
+        Wbar = 1.0 / sumYW;
+        rho = p * Wbar / (RU_ * T);
+        invrho = 1.0 / rho;
+        mconc = p / (RU_ * T);
+        const double logT_ = log(T), invT_ = 1.0 / T;
+        static_for<G_>([&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            constexpr int k0 = group_first_species(g), k1 = group_first_species(g + 1);
+            if (G_ == 1 || grp == g) {
+                static_range<k0, k1>([&](auto kc) PJR_INL {
+                    constexpr int k = decltype(kc)::value;
+                    const double Ck = rho * (k < LAST ? Y[k < LAST ? k - k0 : 0] : yN) * pjs::SP[k][0];
+                    CL[k][tid] = Ck;
+                    const bool lo = T <= pjs::SP[k][2];
+                    double a[6];
+                    static_for<6>([&](auto cc) PJR_INL {
+                        constexpr int c = decltype(cc)::value;
+                        a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+                    });
+                    cpa += Ck * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
+                    dcpa += Ck * (a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T)));
+                    // t_k = h_k/RT - 1 = T dlnX_k/dT (rate_subs.py:660-809: the d/dT of the K_c polynomial)
+                    const double tq = (a[0] - 1.0) + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) + T * (a[3] * (1.0 / 4.0) +
+                                      a[4] * (1.0 / 5.0) * T))) + a[5] * invT_;
+                    double X = 1.0, IX = 1.0;
+                    if constexpr (kcf_used(k)) {
+                        const bool lx = T <= pjs::KCF_ROW[k][0];
+                        double b[7];
+                        static_for<7>([&](auto cc) PJR_INL {
+                            constexpr int c = decltype(cc)::value;
+                            b[c] = lx ? pjs::KCF_ROW[k][1 + c] : pjs::KCF_ROW[k][8 + c];
+                        });
+                        const double lnX = b[0] + b[1] * logT_ + T * (b[2] + T * (b[3] + T * (b[4] + b[5] * T))) - b[6] * invT_;
+                        exp_pair(lnX, -lnX, X, IX);
+                    }
+                    d2 v; v.x = X; v.y = tq;
+                    XT[k][tid] = v;
+                    v.x = IX;
+                    IXT[k][tid] = v;
+                });
+            }
+        });
+        // (with several groups the partial c_p sums stay in LDS until the epilogue adds them up: four registers less)
+        if constexpr (G_ > 1) { PRED23[0][grp][tid] = cpa; PRED23[1][grp][tid] = dcpa; }
+        __syncthreads();
+    }
+#else
     {
         // one round trip for everything the prologue reads: the state and this thread's share of the
         // K_c table are requested before anything waits (a load behind other workgroups' Jacobian
@@ -597,14 +808,15 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         d2 lt[NQ > 0 ? NQ : 1];
         kc_issue<NQ, NTHR>(KCL.v, NKC, lt);
         State L;
-        load_state(A, s, L);        // all loads, scheduling barrier, sums (both halves: each needs T, rho, ...)
+        load_state(A, s, L);        // all loads, scheduling barrier, sums (every group: each needs T, rho, ...)
         kc_land<NQ, NTHR>(LTK, NKC, lt);
         to_conc(L);
         T = L.T; rho = L.rho; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
-        if (PJQ_HALVES == 1 || half == 0)
+        if (G_ == 1 || grp == 0)
             static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
     }
     __syncthreads();
+#endif
 #if defined(PJQ_STAGGER) && !defined(PJR_HOST_EMU)
     // experiment: shift the compute / store phases of neighbouring workgroups against each other
     {
@@ -638,6 +850,29 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         if constexpr (sp == ONE) return 1.0;
         else return ((const double*)((const char*)clb[sp / CGRP] + vzo))[(sp % CGRP) * PJQ_BLOCK];
     };
+#if PJQ_KCF
+    // factor columns: one base address each (16 bytes per species and lane: 64 KB hold 64 species of 64 states)
+    constexpr int XGRP = 65536 / (16 * PJQ_BLOCK) > 0 ? 65536 / (16 * PJQ_BLOCK) : 1;
+    constexpr int NXG = (NSP + XGRP - 1) / XGRP;
+    const d2* xtb[NXG];
+    const d2* ixtb[NXG];
+    static_for<NXG>([&](auto gc) PJR_INL {
+        constexpr int g = decltype(gc)::value;
+        unsigned z0 = 0, z1 = 0;
+#ifndef PJR_HOST_EMU
+        asm volatile("" : "+v"(z0), "+v"(z1));
+#endif
+        xtb[g] = (const d2*)((const char*)&XT[g * XGRP][tid] + z0);
+        ixtb[g] = (const d2*)((const char*)&IXT[g * XGRP][tid] + z1);
+    });
+    // {X_k or 1 / X_k, t_k} of net species q of reaction i: a product (nu > 0) divides K_c's inverse
+    auto factor = [&](auto ic, auto qc) PJR_INL {
+        constexpr int i = decltype(ic)::value, q = pjs::RI[i][RI_NET_PTR] + decltype(qc)::value;
+        constexpr int k = pjs::NET_SP[q][0];
+        if constexpr (pjs::NET_NU[q][0] > 0.0) return ixtb[k / XGRP][(k % XGRP) * PJQ_BLOCK];
+        else return xtb[k / XGRP][(k % XGRP) * PJQ_BLOCK];
+    };
+#endif
 #if PJQ_JV
     // the vector this state's Jacobian is applied to (read once per kernel; AGPRs)
     double V[NSP];
@@ -647,31 +882,35 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     }
     double* const wp = A.w + s * A.w_ss;
 #endif
-#define PJQ_E_AT (PJQ_E_ATOMIC && !PJQ_JV)
-#if !PJQ_E_AT
     // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
     double E[LAST > 0 ? LAST : 1];
-#endif
     double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
     const double* const scr = scr_of(A, s);
-    const long hset = (long)half * (2 * NSUM) * PJQ_TILE;      // this half's pair of slot sets
+    const long hset = (long)grp * (2 * NSUM) * PJQ_TILE;      // this group's pair of slot sets
+    // (sums that live in LDS: this lane's slot of column j is el[ELM.slot[j] * PJQ_BLOCK])
+    double* const el = SM + SM_EL + (long)grp * NEL_ * PJQ_BLOCK + tid;
+    auto e_add = [&](auto jc, const double v) PJR_INL {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (ELM.slot[j] >= 0) PJQ_LDS_ADD(el + ELM.slot[j] * PJQ_BLOCK, v);
+        else E[j] += v;
+    };
     if constexpr (FIRST_) {
-#if !PJQ_E_AT
-        static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] = 0.0; });
-#endif
+        static_for<LAST>([&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (ELM.slot[j] >= 0) el[ELM.slot[j] * PJQ_BLOCK] = 0.0; else E[j] = 0.0;
+        });
     } else {
         // partial sums of the previous row kernel: fetched here, next to the state loads, so that no
         // kernel ever waits for a load behind its own Jacobian stores
-#if !PJQ_E_AT
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
-            E[j] = scr[hset + (long)(SUM_IN + 5 + j) * PJQ_TILE];
+            const double e_in = scr[hset + (long)(SUM_IN + 5 + j) * PJQ_TILE];
 #else
-            E[j] = 0.0;
+            const double e_in = 0.0;
 #endif
+            if constexpr (ELM.slot[j] >= 0) el[ELM.slot[j] * PJQ_BLOCK] = e_in; else E[j] = e_in;
         });
-#endif
         H = scr[hset + (long)SUM_IN * PJQ_TILE];
         SCP = scr[hset + (long)(SUM_IN + 1) * PJQ_TILE];
         SJT = scr[hset + (long)(SUM_IN + 2) * PJQ_TILE];
@@ -690,19 +929,6 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     double* const Jw = A.jac + s_wave * A.j_ss;
     const unsigned jvo = (unsigned)((s - s_wave) * A.j_ss) * 8u;
 #define J_(e) (*(double*)((char*)(Jw + (long)(e) * A.j_si) + jvo))
-#if PJQ_E_AT
-    // energy-row sum j of this lane's state: wavefront-uniform base of the tile's array + j * 64 doubles + a 32-bit
-    // per-lane byte offset (tile relative to the wavefront's, lane group, real | trash copy, wavefront and lane of
-    // the state within its tile): sums of consecutive j are 512 bytes apart, eight per immediate-offset range
-    const long e_tile_w = s_wave / PJQ_TILE;
-    double* const Eb = A.scr + e_tile_w * ((long)NSLOTS * PJQ_TILE) + (long)E_BASE * PJQ_TILE;
-    const long e_t = e_state % PJQ_TILE;
-    const unsigned evo = (unsigned)(((e_state / PJQ_TILE - e_tile_w) * ((long)NSLOTS * PJQ_TILE) +
-                                     ((long)half * 2 + (e_dup ? 1 : 0)) * ((long)LAST * PJQ_TILE) +
-                                     (e_t / 64) * ((long)LAST * 64) + (e_t % 64)) * 8);
-#define E_(j) ((double*)((char*)(Eb + (long)(j) * 64) + evo))
-    if constexpr (FIRST_) static_for<LAST>([&](auto jc) PJR_INL { *E_(decltype(jc)::value) = 0.0; });
-#endif
 #if PJQ_PAIR
     // pair stores (SoA only, host-checked: j_ss == 1, 8 * NSP * j_si < 2^32): a lane of the lower half
     // addresses its own (even) state in column c, its partner in the upper half that state in column c + 1
@@ -739,7 +965,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         // evaluates them at the first visit and keeps them for every later block of the kernel -- in
         // AGPRs while they last, then in scratch memory, whose loads queue behind the Jacobian
         // stores.  Opaque copies of T's functions every few blocks bound that cache.
-        if constexpr ((b - LO_) % PJQ_LAUNDER_EVERY == 0 && b != LO_)
+        // (with several lane groups also at a group's first block: k_f of a reaction that two groups visit is
+        // otherwise computed once, in front of the group branches, and kept)
+        if constexpr ((b - LO_) % PJQ_LAUNDER_EVERY == 0 && (b != LO_ || G_ > 1))
             asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT), "+v"(T2), "+v"(T3), "+v"(T4), "+v"(T2d), "+v"(T3d), "+v"(T4d));
 #endif
         double om[nrows], P[nrows], Q[nrows], JT[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
@@ -755,9 +983,19 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         if constexpr (b == LO_) PJQ_TICK(0)
 
 #if PJQ_KC_AHEAD
-        // The K_c polynomial rows of visit v + 1 are read from LDS while visit v is computed (software
-        // pipelining by hand: a visit's first consumer of LDS data are those rows, and at one wavefront
-        // per SIMD nothing else covers the ~120-cycle LDS round trip at the top of every visit)
+        // The K_c data of visit v + 1 -- polynomial rows, or the net species' factor pairs (PJQ_KCF) -- are read
+        // from LDS while visit v is computed (software pipelining by hand: a visit's first consumer of LDS data
+        // are those values, and at one wavefront per SIMD nothing else covers the ~120-cycle LDS round trip at
+        // the top of every visit)
+#if PJQ_KCF
+        d2 xab[2][MAXNET];
+        auto fetch_ka = [&](auto vc) PJR_INL {
+            constexpr int v = decltype(vc)::value;
+            constexpr int i = pjs::BLK_RX[v0 + v][0];
+            constexpr int NN = (pjs::RI[i][RI_FLAGS] & F_REV) ? pjs::RI[i][RI_NET_CNT] : 0;
+            static_for<NN>([&](auto qc) PJR_INL { xab[v & 1][decltype(qc)::value] = factor(std::integral_constant<int, i>{}, qc); });
+        };
+#else
         double kab[2][MAXKC][7];
         auto fetch_ka = [&](auto vc) PJR_INL {
             constexpr int v = decltype(vc)::value;
@@ -769,6 +1007,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 static_for<7>([&](auto ec) PJR_INL { kab[v & 1][c][decltype(ec)::value] = a[decltype(ec)::value]; });
             });
         };
+#endif
         if constexpr (nv > 0) fetch_ka(std::integral_constant<int, 0>{});
 #endif
 #if PJQ_CONC_AHEAD
@@ -809,8 +1048,18 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                          cp2 = conc(std::integral_constant<int, pjs::RI[i][RI_P2]>{});
 #endif
             // ---- phase A: everything that has to travel (LDS reads of the concentration columns and
-            //      of the K_c polynomial rows) next to arithmetic that needs none of it (k_f) ----
+            //      of the K_c polynomial rows / factor pairs) next to arithmetic that needs none of it (k_f) ----
             constexpr int KCNT = (fl & F_REV) ? pjs::RI[i][RI_KC_CNT] : 0;
+#if PJQ_KCF
+            constexpr int NNET = (fl & F_REV) ? pjs::RI[i][RI_NET_CNT] : 0;
+            d2 xf[NNET > 0 ? NNET : 1];
+#if PJQ_KC_AHEAD
+            static_for<NNET>([&](auto qc) PJR_INL { xf[decltype(qc)::value] = xab[v & 1][decltype(qc)::value]; });
+            if constexpr (v + 1 < nv) fetch_ka(std::integral_constant<int, v + 1>{});
+#else
+            static_for<NNET>([&](auto qc) PJR_INL { xf[decltype(qc)::value] = factor(std::integral_constant<int, i>{}, qc); });
+#endif
+#else
             double ka[KCNT > 0 ? KCNT : 1][7];
 #if PJQ_KC_AHEAD
             static_for<KCNT>([&](auto cc) PJR_INL {
@@ -824,6 +1073,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
                 static_for<7>([&](auto ec) PJR_INL { ka[c][decltype(ec)::value] = a[decltype(ec)::value]; });
             });
+#endif
 #endif
 #if PJQ_SPLIT
             PJQ_SCHED_BARRIER();
@@ -841,12 +1091,28 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 gpw[f] = gen_pow<GP + f>(gcf[f]);
                 if constexpr (f < GNR) pr_ *= gpw[f]; else pp_ *= gpw[f];
             });
-            // Arrhenius (rate_subs.py:113-147); exp(-ln K_c) and T dlnK_c/dT from the pre-summed NASA
-            // polynomials of the reaction's groups (rate_subs.py:660-809); the two exponentials of a
-            // reversible reaction are evaluated side by side
+            // Arrhenius (rate_subs.py:113-147); exp(-ln K_c) and T dlnK_c/dT: from the pre-summed NASA
+            // polynomials of the reaction's groups (rate_subs.py:660-809; the two exponentials of a
+            // reversible reaction are evaluated side by side), or -- PJQ_KCF -- as the product of the net
+            // species' factors and the sum of their t_k: no polynomial, no second exponential
             double kf = 0.0, ekc = 0.0, td = 0.0, lnk = 0.0, lnKc = 0.0;
             if constexpr (!is_pre(i))
                 lnk = RDC(i, RD_LNA) + RDC(i, RD_B) * logT - RDC(i, RD_TA) * invT;
+#if PJQ_KCF
+            if constexpr ((fl & F_REV) != 0) {
+                ekc = pjs::KCF_PREFINV[i][0];
+                static_for<NNET>([&](auto qc) PJR_INL {
+                    constexpr int q = decltype(qc)::value;
+                    constexpr double nu = pjs::NET_NU[pjs::RI[i][RI_NET_PTR] + q][0];
+                    constexpr int m = (int)(nu < 0.0 ? -nu : nu);
+                    static_assert((double)m == (nu < 0.0 ? -nu : nu), "PJQ_KCF: whole net coefficients");
+                    static_for<m>([&](auto) PJR_INL { ekc *= xf[q].x; });
+                    if constexpr (!is_pre(i)) td += nu * xf[q].y;
+                });
+            }
+            if constexpr (!is_pre(i)) kf = exp_one(lnk);
+            (void)lnKc;
+#else
             if constexpr ((fl & F_REV) != 0) {
                 lnKc = RDC(i, RD_LNPREF);
                 static_for<KCNT>([&](auto cc) PJR_INL {
@@ -860,7 +1126,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             if constexpr (!is_pre(i) && (fl & F_REV) != 0) exp_pair(lnk, -lnKc, kf, ekc);
             else if constexpr (!is_pre(i)) kf = exp_one(lnk);
             else if constexpr ((fl & F_REV) != 0) ekc = exp_one(-lnKc);
+#endif
             if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
+
             double ckf, ckr = 0.0, theta = 0.0, rp, bM = 0.0, bcol = 0.0;
             double kf_slot = 0.0;       // Chebyshev: the k_f eval_jacob uses in its dR/dY_j terms (pj_rate_pre.inc)
             if constexpr (is_pre(i)) {
@@ -1003,8 +1271,13 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 constexpr int c = decltype(cc)::value;
                 a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
             });
+#if PJQ_KCF
+            // h_k W_k = R T (t_k + 1): t_k sits in the factor columns
+            hW[r] = (RU_ * T) * (xtb[k / XGRP][(k % XGRP) * PJQ_BLOCK].y + 1.0);
+#else
             hW[r] = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
                            T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+#endif
             const double cpk = (RU_ * pjs::SP[k][0]) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
             H += hW[r] * om[r];
             SCP += om[r] * pjs::SP[k][1] * cpk;
@@ -1026,11 +1299,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 constexpr int si = pjs::SLOC[k][j];
                 if constexpr (si >= 0) {
 #ifndef PJQ_NO_E      // experiment: what the energy-row partial sums cost (results wrong)
-#if PJQ_E_AT
-                    PJQ_E_ADD(E_(j), hW[r] * S[si]);
-#else
-                    E[j] += hW[r] * S[si];
-#endif
+                    e_add(std::integral_constant<int, j>{}, hW[r] * S[si]);
 #endif
                     return INVW(j) * (WP[r] + pjs::SP[k][1] * S[si]) - WQN[r];
                 } else {
@@ -1076,34 +1345,33 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         PJQ_TICK(3)
     });
     };      // run_blocks
-    if constexpr (PJQ_HALVES == 2) {
-        if (half == 0) run_blocks(std::integral_constant<int, B0_>{}, std::integral_constant<int, BM_>{});
-        else run_blocks(std::integral_constant<int, BM_>{}, std::integral_constant<int, B1_>{});
-    } else {
-        run_blocks(std::integral_constant<int, B0_>{}, std::integral_constant<int, B1_>{});
-    }
+    // one of G_ mutually exclusive branches (an if / else-if chain: ONE join behind them -- as G_ independent ifs every
+    // sum that a group carries would be merged G_ times)
+    group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+        constexpr int g = decltype(gc)::value;
+        run_blocks(std::integral_constant<int, group_first_block(g)>{}, std::integral_constant<int, group_first_block(g + 1)>{});
+    });
 
     // ---- energy row: partial sums travel from kernel to kernel through hand-over slots (stored here,
     //      loaded in the next kernel's prologue); the last kernel turns them into d(dT/dt)/d. ----
-    double* const sw = scr_of(A, s) + hset;
     if constexpr (!LASTK_) {
+        double* const sw = scr_of(A, s) + hset;
         sw[(long)SUM_OUT * PJQ_TILE] = H;
         sw[(long)(SUM_OUT + 1) * PJQ_TILE] = SCP;
         sw[(long)(SUM_OUT + 2) * PJQ_TILE] = SJT;
         sw[(long)(SUM_OUT + 3) * PJQ_TILE] = HP;
         sw[(long)(SUM_OUT + 4) * PJQ_TILE] = HQ;
-#if !PJQ_E_AT
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
-            sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = E[j];
+            if constexpr (ELM.slot[j] >= 0) sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = el[ELM.slot[j] * PJQ_BLOCK];
+            else sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = E[j];
 #endif
         });
-#endif
     } else {
         // rate_subs.py:2171-2335 / create_jacobian.py:2940-3120: mass-fraction weighted c_p sums
         // from the concentrations, Y_k c_p,k = C_k R (a0 + ...) / rho
-        double cpa = 0.0, dcpa = 0.0, cpN = 0.0;
+        double cpN = 0.0;
         auto cp_of = [&](auto kc, double& cpm, double& dcpm) PJR_INL {
             constexpr int k = decltype(kc)::value;
             const bool lo = T <= pjs::SP[k][2];
@@ -1115,6 +1383,19 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             cpm = a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T)));
             dcpm = a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T));
         };
+#if PJQ_KCF
+        {
+            double cpm, dcpm;
+            cp_of(std::integral_constant<int, LAST>{}, cpm, dcpm);
+            cpN = (RU_ * pjs::SP[LAST][0]) * cpm;
+            if constexpr (G_ > 1) {
+                // the prologue's partial sums (still in LDS; the prologue's barrier is long past)
+                double (*const PRED23)[G_][PJQ_BLOCK] = (double (*)[G_][PJQ_BLOCK])(SM + SM_PRED23);
+                cpa = 0.0; dcpa = 0.0;
+                static_for<G_>([&](auto gc) PJR_INL { cpa += PRED23[0][decltype(gc)::value][tid]; dcpa += PRED23[1][decltype(gc)::value][tid]; });
+            }
+        }
+#else
         static_for<NSP>([&](auto kc) PJR_INL {
             constexpr int k = decltype(kc)::value;
             double cpm, dcpm;
@@ -1124,69 +1405,88 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             dcpa += Ck * dcpm;
             if constexpr (k == LAST) cpN = (RU_ * pjs::SP[k][0]) * cpm;
         });
+#endif
         const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
         const double icp = 1.0 / cpavg;
-        if constexpr (PJQ_HALVES == 2) {
-            // half 1 hands its sums to half 0 through the concentration columns (nobody reads them any more)
-            static_assert(!(PJQ_HALVES == 2 && LASTK_) || sizeof(LTK) >= sizeof(double) * 4 * PJQ_BLOCK, "exchange buffer");
-#if PJQ_E_AT
-            __threadfence();        // the other lane group's atomic adds have been performed before its sums are read
-#endif
+        if constexpr (G_ > 1) {
+            // Every group hands the sums of the columns it does not own to their owners through the columns (nobody
+            // reads them any more) and the scalar sums to everybody; then each finishes its share of the energy row.
+            double (*const EX)[G_ > 1 ? G_ - 1 : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ - 1 : 1][PJQ_BLOCK])(SM + SM_EX);
+            double (*const RED)[G_][PJQ_BLOCK] = (double (*)[G_][PJQ_BLOCK])(SM + SM_RED);
             __syncthreads();
-            if (half == 1) {
-#if !PJQ_E_AT
-                static_for<LAST>([&](auto jc) PJR_INL { CL[decltype(jc)::value][tid] = E[decltype(jc)::value]; });
-#endif
-                CL[LAST][tid] = H;
-                LTK[0 * PJQ_BLOCK + tid] = SCP; LTK[1 * PJQ_BLOCK + tid] = SJT;
-                LTK[2 * PJQ_BLOCK + tid] = HP; LTK[3 * PJQ_BLOCK + tid] = HQ;
-            }
+            static_for<G_>([&](auto gc) PJR_INL {
+                constexpr int g = decltype(gc)::value;
+                if (grp == g)
+                    static_for<LAST>([&](auto jc) PJR_INL {
+                        constexpr int j = decltype(jc)::value, o = col_owner(j);
+                        if constexpr (o != g && ELM.slot[j] < 0) EX[ex_index(j)][g < o ? g : g - 1][tid] = E[j];
+                    });
+            });
+            RED[0][grp][tid] = H; RED[1][grp][tid] = SCP; RED[2][grp][tid] = SJT; RED[3][grp][tid] = HP; RED[4][grp][tid] = HQ;
             __syncthreads();
-            if (half == 0) {
-#if !PJQ_E_AT
-                static_for<LAST>([&](auto jc) PJR_INL { E[decltype(jc)::value] += CL[decltype(jc)::value][tid]; });
-#endif
-                H += CL[LAST][tid];
-                SCP += LTK[0 * PJQ_BLOCK + tid]; SJT += LTK[1 * PJQ_BLOCK + tid];
-                HP += LTK[2 * PJQ_BLOCK + tid]; HQ += LTK[3 * PJQ_BLOCK + tid];
-            }
+            H = 0.0; SCP = 0.0; SJT = 0.0; HP = 0.0; HQ = 0.0;
+            static_for<G_>([&](auto gc) PJR_INL {
+                constexpr int g = decltype(gc)::value;
+                H += RED[0][g][tid]; SCP += RED[1][g][tid]; SJT += RED[2][g][tid]; HP += RED[3][g][tid]; HQ += RED[4][g][tid];
+            });
+            static_for<G_>([&](auto gc) PJR_INL {
+                constexpr int g = decltype(gc)::value;
+                if (grp == g)
+                    static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (ELM.slot[j] >= 0) {
+                            // the groups' slots of this column, in group order
+                            E[j] = 0.0;
+                            static_for<G_>([&](auto qc) PJR_INL {
+                                E[j] += SM[SM_EL + ((long)decltype(qc)::value * NEL_ + ELM.slot[j]) * PJQ_BLOCK + tid];
+                            });
+                        } else {
+                            static_for<G_ - 1>([&](auto qc) PJR_INL { E[j] += EX[ex_index(j)][decltype(qc)::value][tid]; });
+                        }
+                    });
+            });
         }
-        if (PJQ_HALVES == 1 || half == 0) {
-#if PJQ_E_AT
-        // the finished sums (this lane group's own atomic adds precede these loads in program order; the other
-        // group's were fenced before the barrier above); half 0's lanes never have half != 0 in evo
-        double E[LAST > 0 ? LAST : 1];
-        static_for<LAST>([&](auto jc) PJR_INL {
+        if constexpr (G_ == 1)
+            static_for<LAST>([&](auto jc) PJR_INL {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (ELM.slot[j] >= 0) E[j] = el[ELM.slot[j] * PJQ_BLOCK];
+            });
+        // column j + 1 of the energy row (create_jacobian.py:2940-3120)
+        auto erow = [&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
-#ifndef PJQ_NO_E
-            E[j] = PJQ_E_READ(E_(j));
-            if constexpr (PJQ_HALVES == 2) E[j] += PJQ_E_READ(E_(j) + 2L * LAST * PJQ_TILE);
-#else
-            E[j] = 0.0;
-#endif
-        });
-#endif
+            double cpm, dcpm;
+            cp_of(jc, cpm, dcpm);
+            const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
+            return -((HP + E[j]) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
+        };
+        // (rho is not carried through the kernel: one division here; rounding of 1 / (1 / rho) is below the sums')
+        const double rho_e = 1.0 / invrho;
+        const double e0 = -(SCP - (dcpavg * icp) * H + rho_e * SJT) / (rho_e * cpavg);
 #if PJQ_JV
-        double w0 = (-(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg)) * V[0];
-        static_for<LAST>([&](auto jc) PJR_INL {
-            constexpr int j = decltype(jc)::value;
-            double cpm, dcpm;
-            cp_of(jc, cpm, dcpm);
-            const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
-            w0 += (-((HP + E[j]) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp) * V[j + 1];
+        double w0 = 0.0;
+        static_for<G_>([&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            if (G_ == 1 || grp == g)
+                static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL { w0 += erow(jc) * V[decltype(jc)::value + 1]; });
         });
-        wp[0] = w0;
+        if constexpr (G_ > 1) {
+            double (*const RED)[G_][PJQ_BLOCK] = (double (*)[G_][PJQ_BLOCK])(SM + SM_RED);
+            RED[5][grp][tid] = w0;
+            __syncthreads();
+            w0 = 0.0;
+            static_for<G_>([&](auto gc) PJR_INL { w0 += RED[5][decltype(gc)::value][tid]; });
+        }
+        if (G_ == 1 || grp == 0) wp[0] = w0 + e0 * V[0];
 #else
-        PJQ_STORE(&J_(0), -(SCP - (dcpavg * icp) * H + rho * SJT) / (rho * cpavg));
-        static_for<LAST>([&](auto jc) PJR_INL {
-            constexpr int j = decltype(jc)::value;
-            double cpm, dcpm;
-            cp_of(jc, cpm, dcpm);
-            const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
-            PJQ_STORE(&J_(NSP * (j + 1)), -((HP + E[j]) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp);
+        if (G_ == 1 || grp == 0) PJQ_STORE(&J_(0), e0);
+        static_for<G_>([&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            if (G_ == 1 || grp == g)
+                static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
+                    PJQ_STORE(&J_(NSP * (decltype(jc)::value + 1)), erow(jc));
+                });
         });
 #endif
-        }
     }
 #ifdef PJQ_NO_STORE
     if (pjq_sink == 1.2345e-300) J_(0) = pjq_sink;
@@ -1194,7 +1494,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #ifdef PJQ_TIMING
     PJQ_TICK(4)
     if ((tid & 63) == 0 && blockIdx.x < 1024)
-        for (int ph = 0; ph < 5; ++ph) g_tim[ph][blockIdx.x][tid >> 6] = tacc[ph];
+        for (int ph = 0; ph < 5; ++ph) g_tim[ph][blockIdx.x][(tid >> 6) + grp * (PJQ_BLOCK / 64)] = tacc[ph];
 #endif
 #undef J_
 }
@@ -1637,7 +1937,7 @@ static int run_batch(Ctx& C, long n, const double* pres, const double* y, long y
     // explicit streams / chunk settings take precedence.
     if (C.cfg_streams <= 0 && chunk_cfg < 256 && PJQ_STREAMS == 1 && PJQ_SPLIT_TAIL && C.cfg_split) {
         if (!C.cus && hipDeviceGetAttribute(&C.cus, hipDeviceAttributeMultiprocessorCount, C.device) != hipSuccess) C.cus = 256;
-        const long lds_wg = (long)NSP * PJQ_BLOCK * 8 + 4096;
+        const long lds_wg = (long)NSP * PJQ_BLOCK * 8 * (PJQ_KCF ? 5 : 1) + 4096;   // (+ the factor columns)
         long per_cu = 256 / (PJQ_BLOCK * PJQ_HALVES);           // one wavefront per SIMD (512 registers)
         if (per_cu > (160L << 10) / lds_wg) per_cu = (160L << 10) / lds_wg;
         if (per_cu < 1) per_cu = 1;
@@ -1751,8 +2051,8 @@ int pj_spec_jacobian_ctx(void* ctx, long n, const double* pres, const double* y,
     constexpr long NE = (long)NSP * NSP;
     if (n >= PJQ_BLOCK && j_si == 1 && j_ss == NE && g_rows[0] && !C.cfg_aos_direct) {
         std::lock_guard<std::mutex> lock(C.aos_mutex);
-        // chunks that fill the device once (one workgroup per CU): 256 workgroups
-        long chunk = 256L * PJQ_BLOCK;
+        // chunks that fill the device (one workgroup per CU, 256 CUs) a whole number of times: 65536 states
+        long chunk = 256L * PJQ_BLOCK < 65536 ? 65536 : 256L * PJQ_BLOCK;
         if (chunk > n) chunk = n;
         if (const int rc = grow(C.aos_tmp, C.aos_tmp_states, chunk, (size_t)NE)) return rc;
         for (long s0 = 0; s0 < n; s0 += chunk) {

@@ -850,10 +850,30 @@ std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* 
     arr_i("SCQ", scq, 6);
     arr_i("ARM_BLK_PTR", arm_ptr, 1);
     arr_i("ARM_BLKS", arm_list, 1);
+    {
+        // equilibrium constants from per-species factors (PJQ_KCF kernels): shifted rows of ln X_k and the
+        // per-reaction constant (p_atm / R_u)^(-sum nu) = exp(-RD_LNPREF)
+        const bool kcf = p.kcf.size() == (size_t)nsp * KCW;
+        char buf[64];
+        o += std::string("constexpr int KCF_OK = ") + (kcf ? "1" : "0") + ";\n";
+        o += "constexpr double KCF_ROW[" + std::to_string(nsp) + "][" + std::to_string(KCW) + "] = {";
+        for (int k = 0; k < nsp; ++k) {
+            o += "{";
+            for (int c = 0; c < KCW; ++c) { snprintf(buf, sizeof buf, "%a", kcf ? p.kcf[(size_t)k * KCW + c] : 0.0); o += buf; o += ","; }
+            o += "},\n";
+        }
+        o += "};\nconstexpr double KCF_PREFINV[" + std::to_string(nrxn ? nrxn : 1) + "][1] = {";
+        if (!nrxn) o += "{}";
+        for (int i = 0; i < nrxn; ++i) {
+            snprintf(buf, sizeof buf, "%a", std::exp(-p.rd[(size_t)i * RDW + RD_LNPREF]));
+            o += std::string("{") + buf + "},";
+        }
+        o += "};\n";
+    }
     if (plan_opts) {
         // ---- kernel plan of a pj_rblk.hip library (which row blocks / reactions each kernel takes) ----
         const RblkPlanOpts& O = *plan_opts;
-        const int halves = O.halves == 2 ? 2 : 1, fuse = O.fuse > 0 ? O.fuse : 13;
+        const int halves = (O.halves == 2 || O.halves == 4) ? O.halves : 1, fuse = O.fuse > 0 ? O.fuse : 13;
         // K_c groups a row block / a reaction needs (a kernel stages their polynomial rows in LDS, 128 bytes each)
         auto groups_of_rxn = [&](int i, std::vector<char>& g) {
             const int32_t* ri = &p.ri[(size_t)i * RIW];
@@ -863,20 +883,23 @@ std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* 
         const int ngrp = (int)(p.kcg.size() / KCW);
         auto count = [](const std::vector<char>& g) { int c = 0; for (char x : g) c += x; return c; };
         std::vector<int32_t> kb{0}, km;
-        if (halves == 1) {
+        if (O.single) {
+            // one row kernel: state read once, no hand-over of the energy-row sums, one prologue
+            kb.push_back(nblk);
+        } else if (halves == 1) {
             // row kernels of (nearly) equal block counts, at most `fuse` blocks each
             const int nker = (nblk + fuse - 1) / fuse;
             kb.clear();
             for (int i = 0; i <= nker; ++i) kb.push_back((int32_t)((long)nblk * i / nker));
         } else {
-            // two lane groups per workgroup: a kernel spans up to 2 * fuse blocks, and the K_c rows of all of
+            // several lane groups per workgroup: a kernel spans up to halves * fuse blocks, and the K_c rows of all of
             // them sit next to the concentration columns -- kernels are cut where one more block's rows would not fit
             const long limit = (160L * 1024 - (long)nsp * O.block * 8) / 128 - 2;
             std::vector<char> cur(ngrp + 1, 0);
             for (int b = 0; b < nblk; ++b) {
                 std::vector<char> both = cur;
                 for (int v = brx_ptr[b]; v < brx_ptr[b + 1]; ++v) groups_of_rxn(brx[v], both);
-                if (b > kb.back() && (count(both) > limit || b - kb.back() >= 2 * fuse)) {
+                if (b > kb.back() && (count(both) > limit || b - kb.back() >= halves * fuse)) {
                     kb.push_back(b);
                     std::fill(cur.begin(), cur.end(), 0);
                     for (int v = brx_ptr[b]; v < brx_ptr[b + 1]; ++v) groups_of_rxn(brx[v], cur);
@@ -884,35 +907,38 @@ std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* 
                     cur = both;
                 }
             }
-            if (nblk - kb.back() < 2 && kb.size() > 1) kb.pop_back();      // a kernel needs a block per half
+            if (nblk - kb.back() < halves && kb.size() > 1) kb.pop_back();      // a kernel needs a block per lane group
             kb.push_back(nblk);
         }
         const int nker = (int)kb.size() - 1;
-        // two halves: the blocks of a kernel are cut where the halves' estimated times meet
-        // (a visit ~ cost_visit, a Jacobian entry of the output phase ~ cost_entry)
+        // lane groups: the blocks of a kernel are cut where the groups' estimated times meet
+        // (a visit ~ cost_visit, a Jacobian entry of the output phase ~ cost_entry).  KER_BM: the one boundary of a
+        // two-group kernel (kept for those builds); KER_GB: [kernel][group] first block, halves + 1 entries per kernel
+        std::vector<int32_t> kgb;
         for (int i = 0; i < nker; ++i) {
             const int b0 = kb[i], b1 = kb[i + 1];
-            int bm = b1;
-            if (halves == 2) {
-                std::vector<double> cost;
-                double tot = 0.0;
-                for (int b = b0; b < b1; ++b) {
-                    cost.push_back(O.cost_visit * (brx_ptr[b + 1] - brx_ptr[b]) + O.cost_entry * nsp * (brow_ptr[b + 1] - brow_ptr[b]));
-                    tot += cost.back();
-                }
-                double acc = 0.0;
-                bm = b0 + 1;
-                for (int b = b0; b < b1 - 1; ++b) {
-                    acc += cost[b - b0];
-                    bm = b + 1;
-                    if (acc >= 0.5 * tot) {
-                        if (acc - 0.5 * tot > 0.5 * cost[b - b0] && b > b0) bm = b;
-                        break;
-                    }
-                }
-                bm = std::min(std::max(bm, b0 + 1), b1 - 1);
+            std::vector<double> cost;
+            double tot = 0.0;
+            for (int b = b0; b < b1; ++b) {
+                cost.push_back(O.cost_visit * (brx_ptr[b + 1] - brx_ptr[b]) + O.cost_entry * nsp * (brow_ptr[b + 1] - brow_ptr[b]));
+                tot += cost.back();
             }
-            km.push_back(bm);
+            std::vector<int> cut{b0};
+            double acc = 0.0;
+            int b = b0;
+            for (int g = 1; g < halves; ++g) {
+                const double want = tot * g / halves;
+                // first block of group g: where the running cost passes g / halves of the total (the closer side)
+                while (b < b1 && acc + cost[b - b0] <= want) acc += cost[b++ - b0];
+                if (b < b1 && want - acc > 0.5 * cost[b - b0]) acc += cost[b++ - b0];
+                int c = std::max(b, cut.back() + (b1 - b0 >= halves ? 1 : 0));
+                c = std::min(c, b1 - (b1 - b0 >= halves ? (halves - g) : 0));
+                while (b < c) acc += cost[b++ - b0];
+                cut.push_back(c);
+            }
+            cut.push_back(b1);
+            for (int c : cut) kgb.push_back(c);
+            km.push_back(halves == 2 ? cut[1] : b1);
         }
         // rate kernels: reaction ranges whose K_c rows fit the LDS (next to the concentration columns, if those
         // are in LDS), at most rate_groups groups each
@@ -937,6 +963,8 @@ std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* 
         o += "constexpr int NKER = " + std::to_string(nker) + ", NRATE = " + std::to_string(rb.size() - 1) + ";\n";
         arr_i("KER_B", kb, 1);
         arr_i("KER_BM", km, 1);
+        o += "constexpr int KER_NG = " + std::to_string(halves) + ";\n";
+        arr_i("KER_GB", kgb, halves + 1);
         arr_i("RATE_R", rb, 1);
         if (plan_out) { plan_out->n_row_kernels = nker; plan_out->n_rate_kernels = (int)rb.size() - 1; plan_out->n_pre = npre; plan_out->n_blocks = nblk; plan_out->n_visits = (int)brx.size(); }
     }

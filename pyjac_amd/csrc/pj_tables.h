@@ -137,6 +137,11 @@ struct Programs {
     std::vector<int32_t> ecol_ptr;
     std::vector<uint32_t> ecol;
     int nnz = 0;
+    // Equilibrium constants from per-species factors (pj_rblk.hip, PJQ_KCF): [nsp][KCW] rows (T_mid, lo[7], hi[7]) of
+    // the SHIFTED ln X_k in the K_c polynomial form, 1 / K_c,i = (p_atm / R_u)^(-sum nu) prod_k X_k^(-nu_ki); computed by
+    // the host front end from the stoichiometry (pyjac_amd/kcfactors.py, set through pj_mech_set_kc_factors); empty:
+    // the mechanism keeps the per-reaction polynomial form.  Not part of programs_hash (derived data).
+    std::vector<double> kcf;
     int nrp = 0;                   // nrxn padded to a multiple of 64
     std::vector<int32_t> rti;      // [(RIW + EFF_INL) * nrp]
     std::vector<double> rtd;       // [(RDW + KCW + EFF_INL) * nrp]
@@ -157,7 +162,8 @@ std::string emit_spec_header(const Programs& p);
 struct RblkPlanOpts {
     int fuse = 13;              // row blocks per kernel and lane group at most
     int block = 256;            // states per workgroup of the row kernels
-    int halves = 1;             // lane groups per workgroup (2: on the same states, different row blocks)
+    int halves = 1;             // lane groups per workgroup (2 / 4: on the same states, different row blocks)
+    int single = 0;             // 1: ONE row kernel takes every row block (its lane groups split them)
     int rate_block = 256;       // states per workgroup of the rate kernels
     int rate_c_lds = 0;         // rate kernels keep the concentrations in LDS columns
     int rate_groups = 0;        // K_c groups per rate kernel at most (0: whatever fits the LDS)

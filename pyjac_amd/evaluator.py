@@ -94,7 +94,8 @@ class Evaluator:
             if kinds[0] == 'lane':
                 specbuild.build_lane(L, self._h, so)
             else:
-                specbuild.build_rblk(L, self._h, self.nsp, so, **opts)
+                from .kcfactors import kc_factor_rows
+                specbuild.build_rblk(L, self._h, self.nsp, so, kcf_rows=kc_factor_rows(self.tables), **opts)
         check(L.pj_mech_attach_spec(self._h, so.encode()))
         self.settings_generation += 1
         self.attached_spec = so

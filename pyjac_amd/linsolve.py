@@ -28,6 +28,10 @@ def _blocks(a, name='a', layout=None):
     nsp = int(round(ne ** 0.5))
     if nsp * nsp != ne:
         raise ValueError('%s: the block dimension is not a square' % name)
+    # the launch goes to torch's current stream of the CURRENT device: the tensors have to live there
+    if a.device.index != torch.cuda.current_device():
+        raise ValueError('%s lives on %s but the current device is cuda:%d (use torch.cuda.device(%s.device))'
+                         % (name, a.device, torch.cuda.current_device(), name))
     return n, nsp
 
 

@@ -22,7 +22,8 @@ STEM = {'lane': 'libpj_spec_%016x', 'rblk': 'libpj_rblk_%016x'}
 SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rblk': ('pj_rblk.hip', 'pj_math.h', 'pj_rate_pre.inc')}
 # environment overrides that shape a binary (experiments): part of the digest
 ENV = ('PJ_LANE_FLAGS', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE', 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES',
-       'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST', 'PJ_RBLK_RATE_GROUPS', 'PJ_RBLK_RATE_DEFINES')
+       'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST', 'PJ_RBLK_RATE_GROUPS', 'PJ_RBLK_RATE_DEFINES',
+       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV')
 
 # reciprocal instead of IEEE division sequences, contraction, no -0 special-casing; NO reassociation (it keeps
 # every product of an accumulation chain live: +40 AGPRs, -5 %); measured on MI355X against -ffast-math and
@@ -32,6 +33,9 @@ LANE_FLAGS = ('-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal
 RBLK_FLAGS = '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math -mllvm -amdgpu-schedule-relaxed-occupancy=1'
 
 RBLK_BUDGET = 56          # accumulator doubles per row block of pj_rblk.hip (4 dense + non-zero S per row)
+RBLK_BUDGET_KCF = 48      # ... of the one-kernel builds with per-species factor columns: at 56 they keep a few long-lived
+                          # values in scratch memory, and a scratch reload sits behind every Jacobian store issued before
+                          # it (GRI-shaped: 8.5 ms at 56, 5.9 ms at 48 with no scratch; profiles/r04_rblk_gri_variants.txt)
 RBLK_BUDGET_HALVES = 40   # ... of the two-lane-group builds (57..120 species: 110 energy-row sums per lane leave less
                           # room; USC-shaped 6.46 ms at 56, 6.35 at 48, 6.28 at 40: profiles/r03_rblk_energy_row_atomics.txt)
 RBLK_FUSE = 13            # row blocks per kernel and lane group (at most)
@@ -47,6 +51,9 @@ def source_digest(kind: str):
         try:
             for f in SOURCES[kind] + ('pj_tables.h', 'pj_tables.cpp'):
                 with open(os.path.join(CSRC, f), 'rb') as fh:
+                    d.update(fh.read())
+            if kind == 'rblk':      # the per-species equilibrium-constant factors shape the header
+                with open(os.path.join(HERE, 'kcfactors.py'), 'rb') as fh:
                     d.update(fh.read())
             with open(os.path.abspath(__file__).replace('.pyc', '.py'), 'rb') as fh:
                 d.update(fh.read())
@@ -75,6 +82,34 @@ def _hipcc():
     return os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 
+def kernel_resources(so: str):
+    """[(kernel name, vgpr spills, scratch bytes per lane, LDS bytes)] of the gfx950 code objects embedded in a built
+    library (llvm-objcopy + llvm-readelf of the ROCm toolchain; [] when they are not installed)."""
+    import re
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), 'lib', 'llvm', 'bin')
+    if not os.path.exists(os.path.join(llvm, 'llvm-readelf')):
+        return []
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, 'fatbin')
+        if subprocess.call([os.path.join(llvm, 'llvm-objcopy'), '--dump-section', '.hip_fatbin=' + fat, so],
+                           stderr=subprocess.DEVNULL) or not os.path.exists(fat):
+            return []
+        data = open(fat, 'rb').read()
+        idx = [m.start() for m in re.finditer(b'\x7fELF', data)]
+        for n, i in enumerate(idx):
+            elf = os.path.join(d, 'co%d.elf' % n)
+            with open(elf, 'wb') as f:
+                f.write(data[i:idx[n + 1] if n + 1 < len(idx) else len(data)])
+            notes = subprocess.run([os.path.join(llvm, 'llvm-readelf'), '--notes', elf], capture_output=True, text=True).stdout
+            for blk in notes.split('- .agpr_count:')[1:]:
+                g = lambda k: (re.findall(re.escape(k) + r':\s+(\S+)', blk) or ['0'])[0]
+                out.append((g('.name'), int(g('.vgpr_spill_count')), int(g('.private_segment_fixed_size')),
+                            int(g('.group_segment_fixed_size'))))
+    return out
+
+
 def _finish(tmp_so, tmp_hdr, work, so):
     """Publish a finished build: header first, library last, both by rename (other ranks / processes never see
     a half-written file; every process builds in its own work directory)."""
@@ -97,11 +132,40 @@ def build_lane(L, handle, so: str):
     _finish(tmp, hdr, None, so)
 
 
-def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=()):
+def rblk_geometry(nsp: int, kcf_ok: bool):
+    """(block, halves, kcf, single) of the row kernels of a mechanism.
+    * Per-species equilibrium-constant factors available and the columns of 64 states fit the LDS five times over
+      (concentration + two 16-byte factor columns: 40 NSP bytes per state, NSP <= 62): 64 states per workgroup, four
+      lane groups on them, ONE row kernel (PJQ_KCF, PJQ_SINGLE).
+    * Otherwise the concentration columns (8 NSP bytes per lane) + the K_c rows of the kernel's reactions must fit:
+      256 states, or 128 states and two lane groups (57..120 species), several row kernels."""
+    env = os.environ.get
+    kcf = int(env('PJ_RBLK_KCF', 1 if (kcf_ok and 40 * nsp * 64 + 8192 <= 160 * 1024) else 0))
+    if kcf and not kcf_ok:
+        raise ValueError('PJ_RBLK_KCF=1: the mechanism has no per-species factor rows (pyjac_amd/kcfactors.py)')
+    if kcf:
+        block = int(env('PJ_RBLK_BLOCK', 64))
+        halves = int(env('PJ_RBLK_HALVES', 4))
+        single = int(env('PJ_RBLK_SINGLE', 1))
+    else:
+        block = 256 if nsp * 256 * 8 <= 112 * 1024 else 128 if nsp * 128 * 8 <= 120 * 1024 else 64
+        block = int(env('PJ_RBLK_BLOCK', block))
+        # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on the
+        # same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
+        halves = int(env('PJ_RBLK_HALVES', 2 if block == 128 else 1))
+        single = int(env('PJ_RBLK_SINGLE', 0))
+    return block, halves, kcf, single
+
+
+def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=(),
+               kcf_rows=None):
     """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the falloff / PLOG
     reactions) and the one-pass rate-output kernels (k_rate: pj_spec_rates).  One translation unit per kernel,
     compiled in parallel; which row blocks / reactions a kernel takes is planned by the C side
-    (pj_mech_emit_rblk_spec) and travels in the header.  rates_per_part: K_c groups per rate kernel at most."""
+    (pj_mech_emit_rblk_spec) and travels in the header.  rates_per_part: K_c groups per rate kernel at most.
+    kcf_rows: per-species equilibrium-constant factor rows (kcfactors.kc_factor_rows) or None."""
+    import ctypes as ct
+    import numpy as np
     from ._lib import check
     os.makedirs(os.path.dirname(so), exist_ok=True)
     pid = os.getpid()
@@ -109,49 +173,55 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     work = so[:-3] + '.%d.obj' % pid
     os.makedirs(work, exist_ok=True)
     fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', RBLK_FUSE))
-    # states per workgroup of the row kernels: the concentration columns (8 NSP bytes per lane) + the K_c rows of
-    # the kernel's reactions must fit the LDS
-    block = 256 if nsp * 256 * 8 <= 112 * 1024 else 128 if nsp * 128 * 8 <= 120 * 1024 else 64
-    block = int(os.environ.get('PJ_RBLK_BLOCK', block))
-    # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on the
-    # same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
-    halves = int(os.environ.get('PJ_RBLK_HALVES', 2 if block == 128 else 1))
-    budget = int(budget or os.environ.get('PJ_RBLK_BUDGET', RBLK_BUDGET_HALVES if halves == 2 else RBLK_BUDGET))
+    block, halves, kcf, single = rblk_geometry(nsp, kcf_rows is not None)
+    if kcf_rows is not None:
+        rows = np.ascontiguousarray(kcf_rows, dtype=np.float64)
+        check(L.pj_mech_set_kc_factors(handle, rows.ctypes.data_as(ct.POINTER(ct.c_double)), rows.size))
+    else:
+        check(L.pj_mech_set_kc_factors(handle, None, 0))
+    budget = int(budget or os.environ.get('PJ_RBLK_BUDGET', RBLK_BUDGET_KCF if kcf else RBLK_BUDGET_HALVES if halves == 2 else RBLK_BUDGET))
     c_lds = int(nsp > 64)
     # rate kernels: concentrations in registers up to 64 species (256 states per workgroup), in LDS columns beyond
     # (128 states, two lane groups)
     r_clds = int(nsp > 64)
     r_block, r_halves = (128, 2) if r_clds else (256, 1)
+    # the pre-pass (falloff / PLOG / Chebyshev reactions once per state): its own geometry, 256 states or -- with the
+    # concentrations in LDS -- 128 states and two lane groups
+    p_block, p_halves = (128, 2) if c_lds else (256, 1)
     cv, ce = (float(x) for x in os.environ.get('PJ_RBLK_HALF_COST', '0,0').split(','))
     counts = (ctypes.c_int * 5)()
-    check(L.pj_mech_emit_rblk_spec(handle, hdr.encode(), budget, fuse, block, halves, r_block, r_clds,
+    check(L.pj_mech_emit_rblk_spec(handle, hdr.encode(), budget, fuse, block, halves, single, r_block, r_clds,
                                    int(rates_per_part or os.environ.get('PJ_RBLK_RATE_GROUPS', 0)), cv, ce, counts))
     nker, nrate, npre = counts[0], counts[1], counts[2]
-    common = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr, '-I', CSRC]
+    common = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr, '-I', CSRC,
+              '-DPJQ_SUMSETS=%d' % (0 if nker == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1)]
     flags = os.environ.get('PJ_RBLK_FLAGS', RBLK_FLAGS).split()
     src = os.path.join(CSRC, 'pj_rblk.hip')
     # (the 111-species kernels are short of registers: without the one-visit look-ahead of the K_c rows and
     # concentrations they spill half as much, and spill reloads queue behind the Jacobian stores: -3 %)
-    rblk = common + flags + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves] + \
-        (['-DPJQ_CONC_AHEAD=0', '-DPJQ_KC_AHEAD=0'] if halves == 2 else []) + \
+    rblk = common + flags + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf] + \
+        (['-DPJQ_CONC_AHEAD=0', '-DPJQ_KC_AHEAD=0'] if (halves == 2 and not kcf) else []) + \
+        list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [src]
+    pre = common + flags + ['-DPJQ_BLOCK=%d' % p_block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % p_halves] + \
         list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [src]
     rate = common + flags + ['-DPJQ_BLOCK=%d' % r_block, '-DPJQ_C_LDS=%d' % r_clds, '-DPJQ_HALVES=%d' % r_halves] + \
         list(defines) + os.environ.get('PJ_RBLK_RATE_DEFINES', '').split() + [src]
     jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
     if npre:
-        jobs.append((rblk + ['-DPJQ_PART=1'], 'pre.o'))
+        jobs.append((pre + ['-DPJQ_PART=1'], 'pre.o'))
     # each row kernel three times: with pair stores (SoA output, whole workgroups: the fast path), general,
     # and as w = J v (the Jacobian consumed in registers)
     pair_modes = [int(x) for x in os.environ.get('PJ_RBLK_PAIR_MODES', '1,0').split(',')]
     for i in range(nker):
         for pair in pair_modes:
             jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=%d' % pair], 'rblk%d_%d.o' % (i, pair)))
-        jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % i))
+        if not os.environ.get('PJ_RBLK_NO_JV'):     # (experiments: skip the w = J v build)
+            jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % i))
     for i in range(nrate):
         for full in (0, 1):
             jobs.append((rate + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % i, '-DPJQ_FULL=%d' % full], 'rate%d_%d.o' % (i, full)))
     # longest first so the pool drains evenly
-    jobs.sort(key=lambda j: 0 if j[1].startswith('rate') else 1 if j[1].startswith('rblk') else 2)
+    jobs.sort(key=lambda j: 0 if (j[1].startswith('rblk') and nker == 1) else 1 if j[1].startswith('rate') else 2 if j[1].startswith('rblk') else 3)
 
     def run(job):
         subprocess.check_call(job[0] + ['-o', os.path.join(work, job[1])])
@@ -160,4 +230,12 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     tmp = so + '.tmp.%d' % pid
     subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] +
                           [os.path.join(work, j[1]) for j in jobs])
+    # A row kernel that keeps values in scratch memory reloads them behind its own Jacobian stores (one in-order vmcnt
+    # queue on gfx9): the one-kernel builds lose a third of their speed to a handful of spilled registers.  Say so.
+    for name, spills, scratch, lds in kernel_resources(tmp):
+        if 'k_rblk' in name and scratch > 0 and kcf:
+            import sys
+            sys.stderr.write('pyjac_amd.specbuild: %s: a k_rblk kernel of this library uses %d bytes of scratch memory per '
+                             'lane (%d spilled registers); a smaller accumulator budget (PJ_RBLK_BUDGET, now %d) or '
+                             '-DPJQ_DEPTH=2 (PJ_RBLK_DEFINES) avoids it\n' % (os.path.basename(so), scratch, spills, budget))
     _finish(tmp, hdr, work, so)

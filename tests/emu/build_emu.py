@@ -12,23 +12,29 @@ CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
 
 
 def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int = 128, c_lds: int = 0,
-               opt: str = '-O1', defines=()) -> str:
+               opt: str = '-O1', defines=(), halves: int = 1, kcf: int = 0, single: int = 0) -> str:
     """csrc/pj_rblk.hip for the host: row blocks that rebuild their rates + falloff / PLOG pre-pass (k_pre,
     k_rblk, also as w = J v) and the rate-output kernels (k_rate, one per `rates_per_part` reactions, with and
-    without the per-reaction outputs), the way Evaluator._build_rblk links them."""
+    without the per-reaction outputs), the way specbuild.build_rblk links them.  halves: lane groups of the row kernels
+    (each one OS thread in the emulation); kcf: equilibrium constants from the per-species factor columns (the header
+    must carry the rows: pj_mech_set_kc_factors before it was emitted); single: one row kernel for every block."""
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
     t = open(hdr).read()
     nblk = int(re.search(r'NBLK = (\d+)', t).group(1))
     nrxn = int(re.search(r'NRXN = (\d+)', t).group(1))
     npre = int(re.search(r'NPRE = (\d+)', t).group(1))
-    common = ['g++', opt, '-std=c++17', '-fPIC', '-c', '-x', 'c++', '-DPJR_HOST_EMU', '-DPJS_HEADER="%s"' % hdr] + \
+    common = ['g++', opt, '-std=c++17', '-fPIC', '-pthread', '-c', '-x', 'c++', '-DPJR_HOST_EMU', '-DPJS_HEADER="%s"' % hdr] + \
         list(defines) + ['-I', HERE, '-I', CSRC]
-    rblk = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % c_lds, os.path.join(CSRC, 'pj_rblk.hip')]
+    if single:
+        blocks_per_part = nblk
+    starts = list(range(0, nblk, blocks_per_part))
+    common += ['-DPJQ_SUMSETS=%d' % (0 if len(starts) == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(len(starts) == 1)]
+    base = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % c_lds, os.path.join(CSRC, 'pj_rblk.hip')]
+    rblk = base + ['-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf]
     jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
     if npre:
-        jobs.append((rblk + ['-DPJQ_PART=1'], 'pre.o'))
-    starts = list(range(0, nblk, blocks_per_part))
+        jobs.append((base + ['-DPJQ_PART=1'], 'pre.o'))
     for n, b0 in enumerate(starts):
         jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % n, '-DPJQ_B0=%d' % b0,
                              '-DPJQ_B1=%d' % min(nblk, b0 + blocks_per_part), '-DPJQ_FIRST=%d' % (n == 0),
@@ -39,7 +45,7 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     rstarts = list(range(0, nrxn, rates_per_part))
     for n, r0 in enumerate(rstarts):
         for full in (0, 1):
-            jobs.append((rblk + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % n, '-DPJQ_R0=%d' % r0, '-DPJQ_R1=%d' % min(nrxn, r0 + rates_per_part),
+            jobs.append((base + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % n, '-DPJQ_R0=%d' % r0, '-DPJQ_R1=%d' % min(nrxn, r0 + rates_per_part),
                                  '-DPJQ_FIRST=%d' % (n == 0), '-DPJQ_LAST=%d' % (n == len(rstarts) - 1),
                                  '-DPJQ_FULL=%d' % full], 'rate%d_%d.o' % (n, full)))
 
@@ -47,5 +53,5 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
         subprocess.check_call(j[0] + ['-o', os.path.join(work, j[1])])
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(run, jobs))
-    subprocess.check_call(['g++', '-shared', '-o', out] + [os.path.join(work, j[1]) for j in jobs])
+    subprocess.check_call(['g++', '-shared', '-pthread', '-o', out] + [os.path.join(work, j[1]) for j in jobs])
     return out

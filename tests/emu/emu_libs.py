@@ -21,7 +21,13 @@ def rblk_emu_lib(name, budget, tmp, **kw):
     if key not in _cache:
         d = str(tmp.mktemp('emu')) if hasattr(tmp, 'mktemp') else str(tmp)
         ev = pyjac_amd.Evaluator(MECHS[name], THERMS.get(name), specialize='off')
-        hdr = os.path.join(d, '%s_q%d.h' % (name, budget))
+        hdr = os.path.join(d, '%s_q%d_%d.h' % (name, budget, len(_cache)))
+        if kw.get('kcf'):
+            # equilibrium constants from per-species factor columns: the header carries the rows
+            from pyjac_amd.kcfactors import kc_factor_rows
+            rows = kc_factor_rows(ev.tables)
+            assert rows is not None, 'no factor rows for ' + name
+            _lib.check(_lib.lib().pj_mech_set_kc_factors(ev._h, rows.ctypes.data_as(_dp), rows.size))
         _lib.check(_lib.lib().pj_mech_emit_rows_spec(ev._h, hdr.encode(), budget))
         so = build_emu.build_rblk(hdr, os.path.join(d, 'lib%s_q%d_%d.so' % (name, budget, len(_cache))), **kw)
         L = ctypes.CDLL(so)

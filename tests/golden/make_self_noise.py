@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""How far is pyJac's generated C from ITSELF?  ("weak" #1.)
+
+Runs only in the container that has /root/reference: oracle/build_ref.py compiles the C that pyJac's generator emits
+for a mechanism three times -- the reference's own flags (-O3 -mtune=native, pyjac/libgen/libgen.py:43-46), -O0
+-ffp-contract=off, and -O3 -mfma -ffp-contract=fast -- and this script evaluates the builds on the committed golden
+states + seeded random states and records, under the reference tester's metric
+(pyjac/functional_tester/test.py:1446-1463), the largest entry-wise difference between two builds of the SAME source.
+tests/golden/self_noise.json is the fixture the GPU tests take their kernel-vs-reference bound from (MX_BIG = 10 x
+the self-noise); tests/test_conditioning.py repeats the measurement live and ties it to the kernels entry by entry.
+The fixture is data (numbers); no reference source is stored."""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from conftest import MECHS, rel_err_entries  # noqa: E402
+from oracle.build_ref import VARIANTS, build_ref  # noqa: E402
+from oracle.oracle import Reference  # noqa: E402
+from pyjac_amd import synth  # noqa: E402
+
+CASES = {'gri30_shaped': 300, 'usc2_shaped': 160, 'synth_irrev72': 200, 'h2o2_n2': 300}
+
+
+def states(name, n_random):
+    g = np.load(os.path.join(HERE, name + '_golden.npz'))
+    nsp = int(g['nsp'])
+    pres, y = synth.dist_b(n_random, nsp, seed=11, Tlo=800, Thi=2500)
+    return np.concatenate([g['pres'], pres]), np.ascontiguousarray(np.concatenate([g['y'], y.T], axis=0))
+
+
+def main():
+    out = {}
+    for name, nr in CASES.items():
+        build_ref(MECHS[name], name, variants=('', '_fma') if name in ('synth_irrev72',) else ('', '_O0', '_fma'))
+        pres, ya = states(name, nr)
+        J = {v: Reference(name + v).batch_jacob(pres, ya) for v in VARIANTS if Reference.available(name + v)}
+        rec = dict(states=int(pres.size), flags={v or 'default': ' '.join(VARIANTS[v]) for v in J})
+        for a, b in (('', '_O0'), ('', '_fma')):
+            if b in J:
+                r = rel_err_entries(J[b], J[a])
+                rec['max_rel' + b] = float(r.max())
+                rec['entries_over_1e-6_per_state' + b] = float((r > 1e-6).sum()) / pres.size
+        rec['self_noise'] = max(rec.get('max_rel_O0', 0.0), rec.get('max_rel_fma', 0.0))
+        out[name] = rec
+        print(name, rec)
+    with open(os.path.join(HERE, 'self_noise.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write('\n')
+
+
+if __name__ == '__main__':
+    main()

@@ -89,3 +89,60 @@ def test_truth_agrees_with_binary64_oracle_where_well_conditioned(tables, golden
         for k in ('conc', 'fwd', 'rev', 'pres_mod'):
             assert np.allclose(a[k], b[k], rtol=1e-13, atol=0), k
         assert rel_err_entries(b['jac'], a['jac']).max() < 1e-9
+
+
+def self_noise_report(test, ref, ref_other, label=''):
+    """Evidence that needs no trust in the binary128 restatement: `ref` and `ref_other` are two builds of the SAME
+    C that pyJac's generator emitted (reference flags vs -mfma -ffp-contract=fast, oracle/build_ref.py VARIANTS).
+    d = kernel vs pyJac, s = pyJac vs pyJac, entry by entry under the reference tester's metric."""
+    d, s = rel_err_entries(test, ref), rel_err_entries(ref_other, ref)
+    bad = d > 1e-6
+    repro = s < 1e-11           # entries pyJac reproduces under a change of compiler flags
+    rep = dict(kernel_vs_ref=float(d.max()), self_noise=float(s.max()), n_bad=int(bad.sum()),
+               self_over_1e6=int((s > 1e-6).sum()), repro_frac=float(repro.mean()),
+               kernel_vs_ref_on_repro=float(d[repro].max()))
+    if bad.any():
+        rep.update(bad_with_self_over_1e9=float((s[bad] > 1e-9).mean()),
+                   bad_self_over_d_median=float(np.median(s[bad] / d[bad])))
+    print('%s kernel vs pyJac %.3g; pyJac vs pyJac (other flags) %.3g; on the %.1f %% of entries pyJac reproduces to '
+          '1e-11: kernel vs pyJac %.3g; entries kernel-vs-pyJac > 1e-6: %d%s'
+          % (label, rep['kernel_vs_ref'], rep['self_noise'], 100 * rep['repro_frac'], rep['kernel_vs_ref_on_repro'],
+             rep['n_bad'], '' if not bad.any() else ' (%.1f %% of them differ between the two pyJac builds by > 1e-9, '
+             'median self / kernel difference %.2f)' % (100 * rep['bad_with_self_over_1e9'], rep['bad_self_over_d_median'])))
+    return rep
+
+
+@pytest.mark.parametrize('name,n_random', [('gri30_shaped', 300), ('usc2_shaped', 48)])
+def test_reference_disagrees_with_itself_where_the_kernels_disagree_with_it(name, n_random, tables, golden, tmp_path_factory):
+    """pyJac's generated C compiled with -O3 -mfma -ffp-contract=fast differs from the same C compiled with the
+    reference's flags by 7e-7 (GRI-shaped) / 9e-4 (USC-shaped) -- on the same entries, and by the same order, as
+    the kernels differ from it.  -O0 against -O3 is bit-identical (x86-64 without -mfma never contracts)."""
+    import json
+    from oracle.oracle import Reference
+    if not (Reference.available(name) and Reference.available(name + '_fma')):
+        pytest.skip('oracle/_ref variants not built (no /root/reference here)')
+    tab = tables(name)
+    nsp = tab.nsp
+    L = rblk_emu_lib(name, 56, tmp_path_factory, blocks_per_part=13, c_lds=0)[1] if nsp <= 64 else None
+    g = golden(name)
+    pres, y = synth.dist_b(n_random, nsp, seed=11, Tlo=800, Thi=2500)
+    pres = np.concatenate([g['pres'], pres])
+    y = np.concatenate([g['y'].T, y], axis=1)
+    y_aos = np.ascontiguousarray(y.T)
+    ref, ref_fma = Reference(name).batch_jacob(pres, y_aos), Reference(name + '_fma').batch_jacob(pres, y_aos)
+    if Reference.available(name + '_O0'):
+        assert np.array_equal(Reference(name + '_O0').batch_jacob(pres, y_aos), ref)
+    emu = run_jacobian(L, nsp, pres, y) if L is not None else _ktab_emulated(tab, pres, y)
+    rep = self_noise_report(emu, ref, ref_fma, label='%s (%d states):' % (name, pres.size))
+    # 1. where pyJac is reproducible, the kernels meet the north star's entry-wise rtol 1e-6 against pyJac itself
+    assert rep['repro_frac'] > 0.9 and rep['kernel_vs_ref_on_repro'] < 1e-6
+    # 2. the kernels are not further from pyJac than 10x pyJac is from itself (MX_BIG of the GPU tests)
+    assert rep['kernel_vs_ref'] < 10 * rep['self_noise']
+    # 3. (almost) every entry on which kernel and pyJac differ by more than 1e-6 is one pyJac does not reproduce
+    if rep['n_bad']:
+        assert rep['bad_with_self_over_1e9'] > 0.95
+    if name == 'usc2_shaped':
+        assert rep['self_noise'] > 1e-6 and rep['self_over_1e6'] > 0       # pyJac misses rtol 1e-6 against itself
+    # the committed fixture the GPU tests read (tests/golden/make_self_noise.py) was measured the same way
+    fix = json.load(open(os.path.join(HERE, 'golden', 'self_noise.json')))[name]
+    assert 0.1 * fix['self_noise'] < rep['self_noise'] < 10 * fix['self_noise']

@@ -200,3 +200,58 @@ def test_newton_step_on_jacobians(name, n, torch_cuda):
     # and as one call on the evaluator
     xe = ev.newton_solve(d_p, torch.from_numpy(y).cuda(), torch.from_numpy(np.ascontiguousarray(b.T)).cuda(), gamma)
     assert np.array_equal(xe.cpu().numpy().T, xs)
+
+
+@pytest.mark.parametrize('nsp', [10, 24, 53, 64, 100, 111])
+def test_pivot_ties_go_to_the_first_row_like_dgetf2(nsp, torch_cuda):
+    """Exact ties of the column maximum (structured Newton matrices have them): the FIRST row of maximum magnitude is
+    the pivot, as LAPACK's dgetf2 -- in every kernel (a lane per row; 16 / 32-lane groups; the LDS-resident kernel,
+    where a lane scans rows 32 apart and the lowest lane does not hold the lowest row)."""
+    import scipy.linalg
+    from pyjac_amd import linsolve
+    torch = torch_cuda
+    rng = np.random.default_rng(7 + nsp)
+    n = 64
+    # small integers: every elimination step is exact, so ties stay ties in the Schur complements
+    a = rng.integers(-2, 3, (n, nsp, nsp)).astype(np.float64)
+    a[:, :, 0] = rng.choice([-3.0, 3.0], (n, nsp))          # column 0: every row ties
+    if nsp > 40:
+        a[:, 1, 0] = 1.0
+        a[:, 0, 0] = 2.0                                     # the first maximum is row 2, its twins sit 32 rows further down
+    lu, perm = linsolve.lu_factor(torch.from_numpy(_to_aos(a)).cuda())
+    lu, perm = _from_aos(lu.cpu().numpy(), nsp), perm.cpu().numpy()
+    checked = 0
+    for s in range(n):
+        with np.errstate(all='ignore'):
+            ref_lu, piv = scipy.linalg.lu_factor(a[s], check_finite=False)
+        if not np.isfinite(ref_lu).all() or np.abs(np.diag(ref_lu)).min() == 0.0:
+            continue                                         # singular draw
+        assert np.array_equal(_scipy_perm(piv), perm[s]), (nsp, s)
+        assert np.abs(lu[s] - ref_lu).max() <= 1e-9 * max(1.0, np.abs(ref_lu).max())
+        checked += 1
+    assert checked > n // 2
+
+
+def test_newton_solve_rejects_aliased_buffers(torch_cuda):
+    """pj_newton_solve_dev: storing the factors over batch-layout blocks, or the solution over the blocks, is refused
+    (PJ_EINVAL) instead of corrupting other states' blocks."""
+    import ctypes
+    from pyjac_amd import _lib
+    torch = torch_cuda
+    nsp, n = 10, 256
+    a = torch.randn((nsp * nsp, n), dtype=torch.float64, device='cuda')
+    b = torch.randn((nsp, n), dtype=torch.float64, device='cuda')
+    perm = torch.empty((n, nsp), dtype=torch.int32, device='cuda')
+    L = _lib.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.pj_newton_solve_dev(nsp, n, a.data_ptr(), _lib.LAYOUT_SOA, 0.0, b.data_ptr(), b.data_ptr(), _lib.LAYOUT_SOA,
+                               a.data_ptr(), perm.data_ptr(), st)
+    assert rc != 0                                           # d_lu == d_a in the batch layout
+    rc = L.pj_newton_solve_dev(nsp, n, a.data_ptr(), _lib.LAYOUT_SOA, 0.0, b.data_ptr(), a.data_ptr(), _lib.LAYOUT_SOA,
+                               None, None, st)
+    assert rc != 0                                           # d_x inside d_a
+    x = torch.empty_like(b)
+    rc = L.pj_newton_solve_dev(nsp, n, a.data_ptr(), _lib.LAYOUT_SOA, 0.0, b.data_ptr(), x.data_ptr(), _lib.LAYOUT_SOA,
+                               None, None, st)
+    assert rc == 0
+    torch.cuda.synchronize()

@@ -10,13 +10,20 @@ from conftest import FRONT_END, MECHS, THERMS, jac_scaled_err, mixed_err, rate_s
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-6
-# 53- / 111-species mechanisms: the entry-wise tolerance is checked against the TRUTH -- the reference's formulas
-# evaluated in binary128 (oracle/pyjac_oracle_quad.c, `_truth` below): every entry of the kernels' Jacobians is
-# within RTOL of it (measured <= 3e-9).  pyJac's own binary64 evaluation order is not (entries 1e-13 of their
-# row / column scale carry its rounding error: 4e-6 GRI-shaped, 2e-3 USC-shaped; tests/test_conditioning.py), so
-# kernel-vs-reference under the reference tester's metric is bounded by 3x those measured values, and every
-# entry where the two differ by more than RTOL must be explained by the reference's distance from the truth.
-MX_BIG = {'gri30_shaped': 1.2e-5, 'usc2_shaped': 7e-3, 'synth_irrev72': 5e-3}
+# 53- / 111-species mechanisms: a few entries per state (~1e-13 of their row / column scale) differ from pyJac's
+# generated C by more than RTOL.  Two independent pieces of evidence say whose rounding error that is:
+#  (a) pyJac's generated C does not reproduce ITSELF there: the same emitted C compiled with -O3 -mfma
+#      -ffp-contract=fast differs from the reference-flags build by 7.2e-7 (GRI-shaped) / 8.6e-4 (USC-shaped) / 9.6e-4
+#      (72 species) -- tests/golden/self_noise.json, measured by tests/golden/make_self_noise.py, live in
+#      tests/test_conditioning.py.  MX_BIG, the bound on kernel-vs-reference under the reference tester's metric, is
+#      10x that self-noise; and when the variant libraries travelled with the snapshot (oracle/_ref) the same states
+#      are checked entry by entry: where pyJac reproduces itself to 1e-11 the kernel is within RTOL of pyJac.
+#  (b) the TRUTH -- the reference's formulas evaluated in binary128 (oracle/pyjac_oracle_quad.c, `_truth` below):
+#      every entry of the kernels' Jacobians is within RTOL of it (measured <= 3e-9).
+import json as _json
+import os as _os
+_SELF = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'golden', 'self_noise.json')))
+MX_BIG = {k: 10.0 * _SELF[k]['self_noise'] for k in ('gri30_shaped', 'usc2_shaped', 'synth_irrev72')}
 _truth_cache = {}
 
 
@@ -26,6 +33,21 @@ def _truth(name, tables, pres, y_aos, key):
     if (name, key) not in _truth_cache:
         _truth_cache[(name, key)] = OracleQuad(tables(name)).batch_jacob(pres, np.ascontiguousarray(y_aos))
     return _truth_cache[(name, key)]
+
+
+def _check_vs_self_noise(label, name, jac, pres, y_aos):
+    """(a) above, entry by entry, against the reference libraries themselves (skipped when they did not travel)."""
+    from oracle.oracle import Reference
+    from test_conditioning import self_noise_report
+    if not (Reference.available(name) and Reference.available(name + '_fma')):
+        return None
+    y_aos = np.ascontiguousarray(y_aos)
+    ref, ref_fma = Reference(name).batch_jacob(pres, y_aos), Reference(name + '_fma').batch_jacob(pres, y_aos)
+    rep = self_noise_report(jac, ref, ref_fma, label=label)
+    assert rep['repro_frac'] > 0.9 and rep['kernel_vs_ref_on_repro'] < RTOL, rep
+    if rep['n_bad']:
+        assert rep['bad_with_self_over_1e9'] > 0.95, rep
+    return rep
 
 
 def _check_vs_truth(label, name, jac, ref, truth, nsp, table_driven=False):
@@ -248,6 +270,7 @@ def test_large_mechanisms_vs_oracle(name, n, layout, kernel, tables, torch_cuda)
     assert sc <= 1.0 and fro < 1e-9 and mx < MX_BIG[name], (name, layout, sc, mx, fro)
     _check_vs_truth('%s %s %s n=%d' % (name, layout, kernel, n), name, jac, ref,
                     _truth(name, tables, pres, y.T, ('dist_b21', n)), ev.nsp, table_driven=(kernel == 'k_eval'))
+    _check_vs_self_noise('%s %s %s n=%d' % (name, layout, kernel, n), name, jac, pres, y.T)
     if kernel == 'k_tab':
         # the same states through the cooperative kernel: the two no-compile paths agree
         ev.set_generic_kernel('k_eval')
@@ -509,6 +532,7 @@ def test_large_mechanisms_vs_reference_golden(name, golden, tables, torch_cuda):
         assert mx < MX_BIG[name]
         _check_vs_truth('%s golden use_spec=%d' % (name, use), name, jac, g['jac'],
                         _truth(name, tables, g['pres'], g['y'], 'golden'), ev.nsp, table_driven=not use)
+        _check_vs_self_noise('%s golden use_spec=%d' % (name, use), name, jac, g['pres'], g['y'])
     # every rate output of both paths (state-per-lane rate kernels, table-driven kernel) against the
     # reference's vectors: net rates are judged against the gross rate they are the difference of
     gross, sdy = rate_scales(tables(name), g['pres'], g['y'], g['conc'], g['fwd'], g['rev'], g['pres_mod'])
@@ -526,7 +550,11 @@ def test_large_mechanisms_vs_reference_golden(name, golden, tables, torch_cuda):
 
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
 @pytest.mark.parametrize('n', [4099, 256, 100])
-def test_rblk_kernels_all_reaction_types(layout, n, tables, torch_cuda):
+# build geometry (pyjac_amd/specbuild.py rblk_geometry): the default -- per-species factor columns, 64 states and four
+# lane groups per workgroup, ONE row kernel -- and the per-reaction polynomial form with one lane group on 256 states and
+# several row kernels (energy-row sums handed from kernel to kernel through the scratch slots)
+@pytest.mark.parametrize('geometry', [{}, {'PJ_RBLK_KCF': '0'}], ids=['factors-4groups-1kernel', 'polynomials-1group'])
+def test_rblk_kernels_all_reaction_types(layout, n, geometry, tables, torch_cuda, monkeypatch):
     """csrc/pj_rblk.hip (row blocks that rebuild their rates, falloff / PLOG pre-pass, energy-row
     partials handed from kernel to kernel) on the mechanism that holds every supported reaction type,
     built with a deliberately fine partition (several row kernels, multi-row blocks): against the
@@ -538,6 +566,8 @@ def test_rblk_kernels_all_reaction_types(layout, n, tables, torch_cuda):
     from pyjac_amd import synth
     torch = torch_cuda
     name = 'synth_alltypes'
+    for k, v in geometry.items():
+        monkeypatch.setenv(k, v)
     ev = pyjac_amd.Evaluator(MECHS[name], specialize='off')
     assert ev.specialize(build=True, kind='rblk', budget=16, fuse=3, rates_per_part=7)
     assert ev.spec_kernel == 'pj_rblk'
@@ -569,6 +599,34 @@ def test_rblk_kernels_all_reaction_types(layout, n, tables, torch_cuda):
         assert mx < RTOL and fro < 1e-9, (layout, n, sum_last, mx, fro)
         mx, fro = thresholded_rel_err(spec, gen)
         assert mx < RTOL and fro < 1e-9, ('rblk vs table-driven', sum_last, mx, fro)
+
+
+@pytest.mark.parametrize('geometry', [{}, {'PJ_RBLK_SINGLE': '0', 'PJ_RBLK_HALVES': '2'}], ids=['default', 'factors-2groups-kernels'])
+@pytest.mark.parametrize('name,n', [('synth_mid24', 1000 + 37), ('fe_septherm', 300)])
+def test_rblk_geometries_vs_oracle(name, n, geometry, tables, torch_cuda, monkeypatch):
+    """The row-block kernels of two small mechanisms in the geometries of pyjac_amd/specbuild.py: per-species factor
+    columns with four lane groups in one kernel (default) and with two lane groups over several row kernels (sums
+    handed from kernel to kernel, lane groups exchanging them in the last one); fe_septherm: species with three
+    different T_mid (range select per species).  Against the oracle, SoA, ragged tail."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    if name == 'fe_septherm' and geometry:
+        pytest.skip('built in the default geometry only')
+    for k, v in geometry.items():
+        monkeypatch.setenv(k, v)
+    ev = pyjac_amd.Evaluator(MECHS[name], THERMS.get(name), specialize='off')
+    opts = dict(budget=16, fuse=3, rates_per_part=7) if name == 'fe_septherm' else {}
+    assert ev.specialize(build=True, kind='rblk', **opts)
+    pres, y = synth.dist_b(n, ev.nsp, seed=17, Tlo=300, Thi=2700)
+    jac = ev.jacobian(torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()).cpu().numpy().T
+    ref = Oracle(tables(name)).batch_jacob(pres, np.ascontiguousarray(y.T))
+    assert np.isfinite(jac).all()
+    mx, fro = thresholded_rel_err(jac, ref)
+    sc = jac_scaled_err(jac, ref, ev.nsp)
+    print('%s %s: scaled %.3g, thresholded max rel %.3g, fro %.3g' % (name, geometry or 'default', sc, mx, fro))
+    assert sc <= 1.0 and fro < 1e-9
 
 
 @pytest.mark.parametrize('name,n', [('gri30_shaped', 700), ('usc2_shaped', 200), ('synth_irrev72', 300)])
@@ -626,6 +684,7 @@ def test_full_size_large_mechanism_properties(name, n, tables, torch_cuda, monke
     print('%s full size: scaled %.3g, thresholded max rel %.3g, fro %.3g' % (name, sc, mx, fro))
     assert sc <= 1.0 and fro < 1e-9 and mx < MX_BIG[name]
     _check_vs_truth('%s full-size sample' % name, name, got, ref, _truth(name, tables, pres[ii], y[:, ii].T, 'full'), ev.nsp)
+    _check_vs_self_noise('%s full-size sample' % name, name, got, pres[ii], y[:, ii].T)
     assert jac_scaled_err(small.cpu().numpy().T, got, ev.nsp) <= 1e-3       # same arithmetic, other kernel variant
     # the end of the batch (a workgroup shifted back over its neighbour's states, the end of the second
     # part when the batch runs as two parts on two streams) against the same states as their own batch

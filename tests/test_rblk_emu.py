@@ -74,8 +74,20 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('h2o2_n2', 12, dict(blocks_per_part=100, rates_per_part=5)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_DEPTH=1',))),
-    # the build option that keeps the energy-row sums in a per-state array (atomic adds on the device) instead of registers
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_E_ATOMIC=1',))),
+    # several lane groups per workgroup on the same states (each an OS thread in the emulation, a real barrier behind
+    # __syncthreads): groups split the row blocks of a kernel, exchange the energy-row sums and share its columns
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
+    ('synth_mid24', 40, dict(blocks_per_part=6, rates_per_part=40, halves=4)),
+    # equilibrium constants from per-species factor columns (PJQ_KCF: cooperative prologue, products instead of a
+    # polynomial + exp per visit): one group and several kernels; four groups and ONE kernel (the 53-species shape)
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, kcf=1)),
+    ('synth_mid24', 40, dict(rates_per_part=40, kcf=1, halves=4, single=1)),
+    ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1)),
+    ('h2o2_n2', 12, dict(blocks_per_part=2, rates_per_part=5, kcf=1, halves=2)),
+    # ... with species of three different T_mid (range select per species instead of per K_c group)
+    ('fe_septherm', 16, dict(rates_per_part=9, kcf=1, halves=4, single=1)),
+    # ... with SRI / Chebyshev reactions (reversible hand-over visits take their 1 / K_c from the factors too)
+    ('synth_srichb', 16, dict(rates_per_part=5, kcf=1, halves=4, single=1)),
     # SRI falloff (3 / 5 parameters, LOW / HIGH, collider) and Chebyshev reactions: evaluated by the pre-pass
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
     # N1: fractional stoichiometric coefficients (pow), more than three molecules / species per side, also on

@@ -26,7 +26,8 @@ def main():
             so = os.path.join(VDIR, '%s_%s.so' % (stem, tag))
             t0 = time.time()
             from pyjac_amd import specbuild, _lib
-            specbuild.build_rblk(_lib.lib(), ev._h, ev.nsp, so, defines=defines, **opts)
+            from pyjac_amd.kcfactors import kc_factor_rows
+            specbuild.build_rblk(_lib.lib(), ev._h, ev.nsp, so, defines=defines, kcf_rows=kc_factor_rows(ev.tables), **opts)
             print('built %s in %.0f s' % (so, time.time() - t0), flush=True)
         return
     import numpy as np, torch
