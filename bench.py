@@ -150,7 +150,8 @@ def kernel_label(ev, inject=None):
         # PJ_BENCH_EVALUATOR: not the HIP path at all (tests/test_bench_gloo.py); the line must say so
         return 'INJECTED evaluator %s (PJ_BENCH_EVALUATOR): not a measurement of the HIP path' % inject
     return {'pj_lane': 'pj_lane (register-resident state-per-lane kernel)',
-            'pj_rblk': 'pj_rblk (state-per-lane row-block kernels that rebuild their rates + falloff/PLOG pre-pass)',
+            'pj_rblk': 'pj_rblk (state-per-lane row-block kernels that rebuild their rates + falloff/PLOG pre-pass; up to 62 '
+                       'species: one row kernel, four lane groups on 64 states, K_c from per-species factor columns in LDS)',
             }.get(
                 ev.spec_kernel if ev.has_spec else '', 'k_tab / k_eval (table-driven: NO mechanism-specific library attached)')
 

@@ -188,7 +188,9 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     # the pre-pass (falloff / PLOG / Chebyshev reactions once per state): its own geometry, 256 states or -- with the
     # concentrations in LDS -- 128 states and two lane groups
     p_block, p_halves = (128, 2) if c_lds else (256, 1)
-    cv, ce = (float(x) for x in os.environ.get('PJ_RBLK_HALF_COST', '0,0').split(','))
+    # balance of the lane groups: time of a visit / of a Jacobian entry of the output phase (0: the planner's defaults,
+    # measured on the 111-species kernels; one-kernel factor-column builds, GRI-shaped, -DPJQ_TIMING: 412 / 115 cycles)
+    cv, ce = (float(x) for x in os.environ.get('PJ_RBLK_HALF_COST', '0.206,0.0575' if kcf else '0,0').split(','))
     counts = (ctypes.c_int * 5)()
     check(L.pj_mech_emit_rblk_spec(handle, hdr.encode(), budget, fuse, block, halves, single, r_block, r_clds,
                                    int(rates_per_part or os.environ.get('PJ_RBLK_RATE_GROUPS', 0)), cv, ce, counts))
@@ -199,8 +201,12 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     src = os.path.join(CSRC, 'pj_rblk.hip')
     # (the 111-species kernels are short of registers: without the one-visit look-ahead of the K_c rows and
     # concentrations they spill half as much, and spill reloads queue behind the Jacobian stores: -3 %)
+    # (the one-kernel builds must not keep anything in scratch memory, see below: three hand-over visits in flight
+    # instead of four leave the register allocator the dozen registers it is short of at budget 48 -- GRI-shaped:
+    # 12 bytes of scratch per lane at four, none at three or two)
     rblk = common + flags + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf] + \
         (['-DPJQ_CONC_AHEAD=0', '-DPJQ_KC_AHEAD=0'] if (halves == 2 and not kcf) else []) + \
+        (['-DPJQ_DEPTH=3'] if kcf and not any('PJQ_DEPTH' in d for d in list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split()) else []) + \
         list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [src]
     pre = common + flags + ['-DPJQ_BLOCK=%d' % p_block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % p_halves] + \
         list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [src]
@@ -227,11 +233,24 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
         subprocess.check_call(job[0] + ['-o', os.path.join(work, job[1])])
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
+    # A row kernel that keeps values in scratch memory reloads them behind its own Jacobian stores (one in-order vmcnt
+    # queue on gfx9): the one-kernel builds lose a third of their speed to a handful of spilled registers
+    # (profiles/r04_rblk_gri_variants.txt).  A pair-store row kernel of such a build that came out with scratch is
+    # compiled once more with two hand-over visits in flight instead of three (twelve more registers).
+    if kcf:
+        redo = []
+        for j in jobs:
+            if j[1].startswith('rblk') and j[1].endswith('_1.o'):
+                res = [r for r in kernel_resources(os.path.join(work, j[1])) if 'k_rblk' in r[0]]
+                if res and res[0][2] > 0:
+                    redo.append((j[0] + ['-UPJQ_DEPTH', '-DPJQ_DEPTH=2'], j[1]))
+        if redo:
+            with ThreadPoolExecutor(max_workers=len(redo)) as ex:
+                list(ex.map(run, redo))
     tmp = so + '.tmp.%d' % pid
     subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] +
                           [os.path.join(work, j[1]) for j in jobs])
-    # A row kernel that keeps values in scratch memory reloads them behind its own Jacobian stores (one in-order vmcnt
-    # queue on gfx9): the one-kernel builds lose a third of their speed to a handful of spilled registers.  Say so.
+    # ... and if a row kernel still has scratch, say so
     for name, spills, scratch, lds in kernel_resources(tmp):
         if 'k_rblk' in name and scratch > 0 and kcf:
             import sys
