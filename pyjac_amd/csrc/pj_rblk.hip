@@ -20,9 +20,13 @@
 //                  PLOG, Chebyshev) are evaluated once per state and handed over: theta, c*k_f, rp, b_M, b_col --
 //                  4-5 doubles for ~10 % of the reactions.  Their loads for block b+1 are issued
 //                  BEFORE the stores of block b.
-//   energy row     partial sums in registers (AGPRs), carried between the kernels of one library
-//                  through hand-over slots that the next kernel loads with its state; the last kernel
-//                  finishes the row and jac[0].
+//   energy row     column j is finished by the block that holds ROW j (E_j = sum_i Hr_i G_ij over the reactions it
+//                  visits anyway; see BCOL below), long-lived sums only for what that block cannot see; scalar sums
+//                  and those few columns travel between the kernels of one library through hand-over slots
+//                  that the next kernel loads with its state; the last kernel finishes the row and jac[0].
+//   lane groups    PJQ_HALVES = 2 / 4: the wavefronts of a workgroup work on the SAME states and split the row blocks;
+//   PJQ_KCF        up to 62 species: equilibrium constants as products of per-species factors kept in LDS columns,
+//                  64 states per workgroup, four lane groups, ONE row kernel (see k_rblk).
 //
 //   PJQ_JV         the same row kernels with the Jacobian stores replaced by w_k += J(k, c) v_c: the
 //                  consumer of pyJac's sparse_multiplier (create_jacobian.py:3301-3404) fused in, NSP
@@ -187,7 +191,52 @@ constexpr int SUM_IN = pjs::NSCQ + (PJQ_ID % 2) * NSUM, SUM_OUT = pjs::NSCQ + ((
 // registers -- 8 % fewer instructions, half the AGPRs, and 7.0 -> 11.1 ms (GRI-shaped), 6.5 -> 8.8 ms (USC-shaped):
 // 1.8 k / 5.7 k atomic adds per state are more than the L2 takes next to the Jacobian stores;
 // profiles/r03_rblk_energy_row_atomics.txt.)
-constexpr int NSLOTS = pjs::NSCQ + PJQ_SUMSETS * NSUM;
+// Energy row by columns (round 4).  E_j = sum_k h_kW_k S_kj with S_kj = sum_i nu_ki G_ij (G_ij: what reaction i's
+// molecule slots, efficiencies and collider put into column j), i.e. E_j = sum_i Hr_i G_ij with the reaction enthalpy
+// Hr_i = sum_k nu_ki h_kW_k = R T (T dlnK_c/dT + sum nu) -- which a visit has anyway.  The block that owns ROW j visits
+// every reaction that has j as a net reactant / product, so it can finish COLUMN j of the energy row itself: one
+// running sum per row of the block instead of LAST sums carried through the whole kernel by every lane group (104 /
+// 220 registers -- what made the kernels spill, and a spill reload sits behind every Jacobian store).  What a block
+// cannot see -- slots of species that are not net species of the reaction: enhanced third-body colliders, a falloff
+// collider, a species on both sides -- goes into long-lived sums as before, but only the few columns that have such
+// contributions exist (constant zero otherwise), added at ONE visit of the reaction (its first block).
+constexpr bool in_net(int i, int sp)
+{
+    for (int q = 0; q < pjs::RI[i][RI_NET_CNT]; ++q)
+        if (pjs::NET_SP[pjs::RI[i][RI_NET_PTR] + q][0] == sp) return true;
+    return false;
+}
+constexpr double net_sum(int i)
+{
+    double s = 0.0;
+    for (int q = 0; q < pjs::RI[i][RI_NET_CNT]; ++q) s += pjs::NET_NU[pjs::RI[i][RI_NET_PTR] + q][0];
+    return s;
+}
+struct BCols { bool b[pjs::NSP + 1]; int n; };
+constexpr BCols make_bcols()
+{
+    BCols m{};
+    auto mark = [&](int i, int sp) { if (sp >= 0 && sp < pjs::NSP - 1 && !in_net(i, sp)) m.b[sp] = true; };
+    for (int i = 0; i < pjs::NRXN; ++i) {
+        const int fl = pjs::RI[i][RI_FLAGS];
+        for (int c = RI_R0; c <= RI_R2; ++c) mark(i, pjs::RI[i][c]);
+        if (fl & F_REV) for (int c = RI_P0; c <= RI_P2; ++c) mark(i, pjs::RI[i][c]);
+        if (fl & F_GEN) {
+            const int nf = pjs::RI[i][RI_GEN_NR] + ((fl & F_REV) ? pjs::RI[i][RI_GEN_NP] : 0);
+            for (int f = 0; f < nf; ++f) mark(i, pjs::GEN_SP[pjs::RI[i][RI_GEN_PTR] + f][0]);
+        }
+        if (fl & F_EFFTYPE) for (int e = 0; e < pjs::RI[i][RI_EFF_CNT]; ++e) mark(i, pjs::EFF_SP[pjs::RI[i][RI_EFF_PTR] + e][0]);
+        if ((fl & F_COLLIDER) && pjs::RI[i][RI_COLLIDER] >= 0) mark(i, pjs::RI[i][RI_COLLIDER]);
+    }
+    for (int j = 0; j < pjs::NSP - 1; ++j) m.n += m.b[j] ? 1 : 0;
+    return m;
+}
+constexpr BCols BCOL = make_bcols();
+// With several lane groups AND several row kernels a finished column sum travels to the last kernel through one
+// slot per column behind the slot sets (written once, by the kernel that holds the row)
+#define PJQ_ECOLS (PJQ_SUMSETS > 2)
+constexpr int E_COL0 = pjs::NSCQ + PJQ_SUMSETS * NSUM;
+constexpr int NSLOTS = E_COL0 + (PJQ_ECOLS ? pjs::NSP - 1 : 0);
 
 // reactions evaluated once per state by k_pre and handed over
 constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG | F_CHEB)) != 0; }
@@ -556,6 +605,17 @@ constexpr int n_pre_visits()
     for (int v = pjs::BLK_RX_PTR[b][0]; v < pjs::BLK_RX_PTR[b + 1][0]; ++v) c += is_pre(pjs::BLK_RX[v][0]) ? 1 : 0;
     return c;
 }
+// the first row block that visits a reaction: where its contributions to the long-lived energy-row sums are added
+struct OwnerMap { int b[NRXN > 0 ? NRXN : 1]; };
+constexpr OwnerMap make_owner()
+{
+    OwnerMap m{};
+    for (int i = 0; i < NRXN; ++i) m.b[i] = -1;
+    for (int b = pjs::NBLK - 1; b >= 0; --b)
+        for (int v = pjs::BLK_RX_PTR[b][0]; v < pjs::BLK_RX_PTR[b + 1][0]; ++v) m.b[pjs::BLK_RX[v][0]] = b;
+    return m;
+}
+constexpr OwnerMap OWNER = make_owner();
 #ifdef PJQ_TIMING
 __device__ long long g_tim[5][1024][4];
 #endif
@@ -571,6 +631,9 @@ __device__ long long g_tim[5][1024][4];
 constexpr int G_ = PJQ_HALVES;
 constexpr int NTHR = PJQ_BLOCK * G_;
 static_assert(G_ == 1 || G_ == 2 || G_ == 4, "PJQ_HALVES: 1, 2 or 4 lane groups");
+// a column of the energy row has a long-lived sum only if something outside its own row's block contributes (BCOL) --
+// or, with one lane group, always: the block's finished column sum is then kept there until the epilogue
+constexpr bool e_live_col(int j) { return G_ == 1 || BCOL.b[j]; }
 constexpr int group_first_block(int g)
 {
 #if PJQ_PLAN
@@ -609,20 +672,28 @@ constexpr bool kcf_used(int k)
 //                PRED01[2][G][BLOCK] use the same room before EL is cleared
 //   epilogue     (last kernel, G > 1, after a barrier) EX[LAST - NEL][G-1][BLOCK] register-resident energy-row sums on
 //                their way to the group that owns the column | RED[6][G][BLOCK] the scalar sums
-// Energy-row sums in LDS.  A lane group carries LAST partial sums E_j through the kernel (104 registers of the 512
-// a lane has); with the factor columns next to them the kernels spill, and a spill reload sits behind every Jacobian
-// store issued before it (vmcnt is in order): 9.2 ms per 1e6 GRI-shaped states against 5.7 ms for the same kernel
-// without the sums.  So as many of them as the LDS has room for (the columns with the most structural non-zeros first)
-// live in LDS, one slot per lane group, column and lane -- a single writer each, so the order of the additions is
-// fixed -- and an update is ONE ds_add_f64 instead of five instructions on an AGPR pair.
+// Long-lived energy-row sums in LDS (PJQ_NEL > 0; measured, no longer the default).  While every lane group carried
+// LAST partial sums E_j through the kernel (104 registers of the 512 a lane has) the one-kernel builds spilled, and a
+// spill reload sits behind every Jacobian store issued before it (vmcnt is in order): 9.2 ms per 1e6 GRI-shaped states
+// against 5.7 ms for the same kernel without the sums.  Keeping the sums of the columns with the most structural
+// non-zeros in LDS -- one slot per lane group, column and lane: a single writer each, so the order of the additions is
+// fixed; an update is ONE ds_add_f64 instead of five instructions on an AGPR pair -- brought that to 5.9 ms; since the
+// energy row is finished column by column (BCOL) far fewer long-lived sums exist and they fit the registers.
 constexpr int SM_CL = 0;
 constexpr int SM_XT = SM_CL + NSP * PJQ_BLOCK;
 constexpr int SM_IXT = SM_XT + (PJQ_KCF ? 2 * NSP * PJQ_BLOCK : 0);
 constexpr int SM_LTK = SM_IXT + (PJQ_KCF ? 2 * NSP * PJQ_BLOCK : 0);
-constexpr int SM_PRED23 = SM_LTK + (NKC > 0 ? NKC * 16 : 0);
-constexpr int SM_EL = SM_PRED23 + (PJQ_KCF && G_ > 1 ? 2 * G_ * PJQ_BLOCK : 0);
+// EJ[LAST][BLOCK]: the finished column sums of the energy row on their way from the lane group that holds the row to
+// the group that writes the column (one kernel, several groups); the prologue's partial sums PRED[4][G][BLOCK] use the
+// same room before the first block ends
+constexpr bool EJ_LDS = PJQ_SINGLE && G_ > 1;
+constexpr int SM_EJ = SM_LTK + (NKC > 0 ? NKC * 16 : 0);
+constexpr int SM_EJ_DOUBLES = (EJ_LDS ? LAST * PJQ_BLOCK : 0) > (PJQ_KCF && G_ > 1 ? 4 * G_ * PJQ_BLOCK : 0)
+                                  ? (EJ_LDS ? LAST * PJQ_BLOCK : 0) : (PJQ_KCF && G_ > 1 ? 4 * G_ * PJQ_BLOCK : 0);
+constexpr int SM_EL = SM_EJ + SM_EJ_DOUBLES;
 #ifndef PJQ_NEL
-#define PJQ_NEL (-1)        // energy-row sums per lane group that live in LDS; -1: as many as fit
+#define PJQ_NEL 0           // long-lived energy-row sums per lane group that live in LDS (ds_add_f64); -1: as many as fit
+                            // (since the energy row is finished column by column only a few such sums exist: registers)
 #endif
 constexpr int nel_fit()
 {
@@ -633,14 +704,15 @@ constexpr int nel_fit()
     return (int)(n < 0 ? 0 : n);
 }
 constexpr int NEL_ = PJQ_NEL >= 0 ? (PJQ_NEL < LAST ? PJQ_NEL : LAST) : nel_fit();
-constexpr int SM_EL_DOUBLES = G_ * PJQ_BLOCK * (NEL_ > 2 ? NEL_ : (PJQ_KCF && G_ > 1 ? 2 : NEL_));
+constexpr int SM_EL_DOUBLES = G_ * PJQ_BLOCK * NEL_;
 constexpr int SM_MAIN = SM_EL + SM_EL_DOUBLES;
-constexpr int SM_EX = 0;
+// (the epilogue's exchange area: over the then free columns if it fits below the sums that are still needed, else behind)
+constexpr int SM_EPI_SIZE = (G_ > 1 && LASTK_) ? (LAST - NEL_) * (G_ - 1) * PJQ_BLOCK + 6 * G_ * PJQ_BLOCK : 0;
+constexpr int SM_EX = SM_EPI_SIZE <= SM_EJ ? 0 : SM_MAIN;
 constexpr int SM_RED = SM_EX + (LAST - NEL_) * (G_ - 1) * PJQ_BLOCK;
-constexpr int SM_EPI = (G_ > 1 && LASTK_) ? SM_RED + 6 * G_ * PJQ_BLOCK : 0;
+constexpr int SM_EPI = SM_EPI_SIZE ? SM_EX + SM_EPI_SIZE : 0;
 constexpr int SM_DOUBLES = SM_MAIN > SM_EPI ? SM_MAIN : SM_EPI;
 static_assert(SM_DOUBLES * 8 <= 160 * 1024, "LDS: columns of PJQ_BLOCK states do not fit");
-static_assert(!(G_ > 1 && LASTK_) || SM_EPI <= SM_PRED23 || NEL_ == 0, "LDS: the epilogue's exchange area must not reach the sums kept in LDS");
 // which columns' sums live in LDS: those with the most structural non-zeros (the most updates)
 constexpr int col_nnz(int j)
 {
@@ -722,8 +794,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         // and each turns its species into concentration, factor and enthalpy columns for all of them:
         // X_k = exp(ln X_k), 1 / X_k and t_k = h_k/RT - 1 -- NSP / G exponential pairs per lane instead of one per
         // reversible visit.
-        double (*const PRED)[G_ > 1 ? G_ : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ : 1][PJQ_BLOCK])(SM + SM_EL);        // PRED01
-        double (*const PRED23)[G_ > 1 ? G_ : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ : 1][PJQ_BLOCK])(SM + SM_PRED23);
+        double (*const PRED)[G_ > 1 ? G_ : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ : 1][PJQ_BLOCK])(SM + SM_EJ);
         const double* const y = A.y + s * A.y_ss;
         T = y[0];
         const double p = A.pres[s];
@@ -795,9 +866,15 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 });
             }
         });
-        // (with several groups the partial c_p sums stay in LDS until the epilogue adds them up: four registers less)
-        if constexpr (G_ > 1) { PRED23[0][grp][tid] = cpa; PRED23[1][grp][tid] = dcpa; }
-        __syncthreads();
+        if constexpr (G_ > 1) {
+            PRED[2][grp][tid] = cpa; PRED[3][grp][tid] = dcpa;
+            __syncthreads();
+            cpa = 0.0; dcpa = 0.0;
+            static_for<G_>([&](auto gc) PJR_INL { cpa += PRED[2][decltype(gc)::value][tid]; dcpa += PRED[3][decltype(gc)::value][tid]; });
+            if constexpr (EJ_LDS) __syncthreads();      // (the room is EJ's from here on)
+        } else {
+            __syncthreads();
+        }
     }
 #else
     {
@@ -904,10 +981,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         // kernel ever waits for a load behind its own Jacobian stores
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
+            double e_in = 0.0;
 #ifndef PJQ_NO_E
-            const double e_in = scr[hset + (long)(SUM_IN + 5 + j) * PJQ_TILE];
-#else
-            const double e_in = 0.0;
+            if constexpr (e_live_col(j)) e_in = scr[hset + (long)(SUM_IN + 5 + j) * PJQ_TILE];
 #endif
             if constexpr (ELM.slot[j] >= 0) el[ELM.slot[j] * PJQ_BLOCK] = e_in; else E[j] = e_in;
         });
@@ -971,10 +1047,11 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT), "+v"(T2), "+v"(T3), "+v"(T4), "+v"(T2d), "+v"(T3d), "+v"(T4d));
 #endif
         double om[nrows], P[nrows], Q[nrows], JT[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
+        double EA[nrows];           // energy row, column of each row of the block: sum_i Hr_i G_ij over the block's visits
         double JTQ = 0.0;
         static_for<nrows>([&](auto rc) PJR_INL {
             constexpr int r = decltype(rc)::value;
-            om[r] = 0.0; P[r] = 0.0; Q[r] = 0.0; JT[r] = 0.0;
+            om[r] = 0.0; P[r] = 0.0; Q[r] = 0.0; JT[r] = 0.0; EA[r] = 0.0;
         });
         static_for<pjs::BLK_NNZ[b][0]>([&](auto ec) PJR_INL { S[decltype(ec)::value] = 0.0; });
         constexpr int npre = n_pre_visits<b>();
@@ -1187,6 +1264,47 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             double gN = 0.0;
             if constexpr (has_anm1<i>()) gN = bM * RDC(i, RD_ANM1);
             constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
+            // reaction enthalpy Hr_i = sum_k nu_ki h_kW_k = R T (sum_k nu_ki t_k + sum nu), t_k = h_k/RT - 1
+            // (dead code in the visits that add nothing to the energy row)
+            double hrt = 0.0;
+#if PJQ_KCF
+            if constexpr ((fl & F_REV) != 0) {
+                static_for<NNET>([&](auto qc) PJR_INL {
+                    hrt += pjs::NET_NU[np0 + decltype(qc)::value][0] * xf[decltype(qc)::value].y;
+                });
+            } else {
+                static_for<ncnt>([&](auto qc) PJR_INL {
+                    constexpr int k = pjs::NET_SP[np0 + decltype(qc)::value][0];
+                    hrt += pjs::NET_NU[np0 + decltype(qc)::value][0] * xtb[k / XGRP][(k % XGRP) * PJQ_BLOCK].y;
+                });
+            }
+            const double Hr = (RU_ * T) * (hrt + net_sum(i));
+#else
+            double Hr;
+            if constexpr ((fl & F_REV) != 0) {
+                static_for<KCNT>([&](auto cc) PJR_INL {
+                    const double* a = ka[decltype(cc)::value];
+                    hrt += a[1] + a[2] * T + a[3] * T2d + a[4] * T3d + a[5] * T4d + a[6] * invT;
+                });
+                Hr = (RU_ * T) * (hrt + net_sum(i));
+            } else {
+                // an irreversible reaction has no K_c polynomial: the species' enthalpies from their NASA coefficients
+                Hr = 0.0;
+                static_for<ncnt>([&](auto qc) PJR_INL {
+                    constexpr int k = pjs::NET_SP[np0 + decltype(qc)::value][0];
+                    const bool lo = T <= pjs::SP[k][2];
+                    double a[6];
+                    static_for<6>([&](auto cc) PJR_INL {
+                        constexpr int c = decltype(cc)::value;
+                        a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+                    });
+                    Hr += pjs::NET_NU[np0 + decltype(qc)::value][0] *
+                          (RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                                  T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T))))));
+                });
+            }
+            (void)hrt;
+#endif
             auto slot = [&](auto spc, const double gv) PJR_INL {
                 constexpr int sp = decltype(spc)::value;
                 if constexpr (sp == LAST) gN += gv;
@@ -1200,6 +1318,16 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                             S[si] += pjs::NET_NU[q][0] * gv;
                         }
                     });
+#ifndef PJQ_NO_E
+                    // energy row: column sp is finished by the block that holds row sp (it visits every reaction
+                    // with sp as a net species); what that block cannot see is added once, at the reaction's first visit
+                    if constexpr (in_net(i, sp)) {
+                        if constexpr (pjs::ROW_BLK[sp][0] == b) EA[pjs::ROWLOC[sp][0]] += Hr * gv;
+                    } else if constexpr (OWNER.b[i] == b) {
+                        static_assert(BCOL.b[sp], "energy row: column not marked");
+                        e_add(std::integral_constant<int, sp>{}, Hr * gv);
+                    }
+#endif
                 }
             };
             double gkf = ckf, gkr = ckr;
@@ -1298,9 +1426,6 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 constexpr int j = c - 1;
                 constexpr int si = pjs::SLOC[k][j];
                 if constexpr (si >= 0) {
-#ifndef PJQ_NO_E      // experiment: what the energy-row partial sums cost (results wrong)
-                    e_add(std::integral_constant<int, j>{}, hW[r] * S[si]);
-#endif
                     return INVW(j) * (WP[r] + pjs::SP[k][1] * S[si]) - WQN[r];
                 } else {
                     return INVW(j) * WP[r] - WQN[r];
@@ -1341,6 +1466,19 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 static_for<LAST>([&](auto jc) PJR_INL { (void)col_val(rc, std::integral_constant<int, decltype(jc)::value + 1>{}); });
             }
         });
+        // the block's finished columns of the energy row: to the long-lived sums (one lane group), to the LDS
+        // array the epilogue reads (one kernel), or to the column's slot of the hand-over array (several kernels)
+#ifndef PJQ_NO_E
+        static_for<nrows>([&](auto rc) PJR_INL {
+            constexpr int r = decltype(rc)::value;
+            constexpr int k = pjs::BLK_ROWS[r0 + r][0];
+            if constexpr (k < LAST) {
+                if constexpr (G_ == 1) e_add(std::integral_constant<int, k>{}, EA[r]);
+                else if constexpr (EJ_LDS) SM[SM_EJ + k * PJQ_BLOCK + tid] = EA[r];
+                else PJQ_STORE(&scr_of(A, s)[(long)(E_COL0 + k) * PJQ_TILE], EA[r]);
+            }
+        });
+#endif
         PJQ_SCHED_BARRIER();
         PJQ_TICK(3)
     });
@@ -1364,47 +1502,52 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
-            if constexpr (ELM.slot[j] >= 0) sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = el[ELM.slot[j] * PJQ_BLOCK];
-            else sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = E[j];
+            if constexpr (e_live_col(j)) {
+                if constexpr (ELM.slot[j] >= 0) sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = el[ELM.slot[j] * PJQ_BLOCK];
+                else sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = E[j];
+            }
 #endif
         });
     } else {
         // rate_subs.py:2171-2335 / create_jacobian.py:2940-3120: mass-fraction weighted c_p sums
         // from the concentrations, Y_k c_p,k = C_k R (a0 + ...) / rho
         double cpN = 0.0;
-        auto cp_of = [&](auto kc, double& cpm, double& dcpm) PJR_INL {
+        // (Tc: the temperature, or an opaque copy of it -- the range-selected coefficients of a species are wanted twice,
+        // in the c_p sums and in the species' column of the energy row; as common subexpressions they are kept from the
+        // first use to the second, 5 NSP doubles: 4.3 KB of scratch memory per lane in the 111-species kernel)
+        auto cp_of = [&](auto kc, const double Tc, double& cpm, double& dcpm) PJR_INL {
             constexpr int k = decltype(kc)::value;
-            const bool lo = T <= pjs::SP[k][2];
+            const bool lo = Tc <= pjs::SP[k][2];
             double a[5];
             static_for<5>([&](auto cc) PJR_INL {
                 constexpr int c = decltype(cc)::value;
                 a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
             });
-            cpm = a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T)));
-            dcpm = a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T));
+            cpm = a[0] + Tc * (a[1] + Tc * (a[2] + Tc * (a[3] + a[4] * Tc)));
+            dcpm = a[1] + Tc * (2.0 * a[2] + Tc * (3.0 * a[3] + 4.0 * a[4] * Tc));
         };
+        double Te = T;
 #if PJQ_KCF
         {
             double cpm, dcpm;
-            cp_of(std::integral_constant<int, LAST>{}, cpm, dcpm);
+            cp_of(std::integral_constant<int, LAST>{}, T, cpm, dcpm);
             cpN = (RU_ * pjs::SP[LAST][0]) * cpm;
-            if constexpr (G_ > 1) {
-                // the prologue's partial sums (still in LDS; the prologue's barrier is long past)
-                double (*const PRED23)[G_][PJQ_BLOCK] = (double (*)[G_][PJQ_BLOCK])(SM + SM_PRED23);
-                cpa = 0.0; dcpa = 0.0;
-                static_for<G_>([&](auto gc) PJR_INL { cpa += PRED23[0][decltype(gc)::value][tid]; dcpa += PRED23[1][decltype(gc)::value][tid]; });
-            }
         }
 #else
         static_for<NSP>([&](auto kc) PJR_INL {
             constexpr int k = decltype(kc)::value;
             double cpm, dcpm;
-            cp_of(kc, cpm, dcpm);
+            cp_of(kc, T, cpm, dcpm);
             const double Ck = conc(kc);
             cpa += Ck * cpm;
             dcpa += Ck * dcpm;
             if constexpr (k == LAST) cpN = (RU_ * pjs::SP[k][0]) * cpm;
         });
+#ifndef PJR_HOST_EMU
+        // (both sums finished HERE: left alone, the d/dT sum is evaluated behind the barriers below, from range-selected
+        // coefficients that are kept in scratch memory until then)
+        asm volatile("" : "+v"(cpa), "+v"(dcpa));
+#endif
 #endif
         const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
         const double icp = 1.0 / cpavg;
@@ -1413,13 +1556,14 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             // reads them any more) and the scalar sums to everybody; then each finishes its share of the energy row.
             double (*const EX)[G_ > 1 ? G_ - 1 : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ - 1 : 1][PJQ_BLOCK])(SM + SM_EX);
             double (*const RED)[G_][PJQ_BLOCK] = (double (*)[G_][PJQ_BLOCK])(SM + SM_RED);
+            if constexpr (!EJ_LDS) __threadfence();     // (column sums this kernel's other lane groups left in the hand-over array)
             __syncthreads();
             static_for<G_>([&](auto gc) PJR_INL {
                 constexpr int g = decltype(gc)::value;
                 if (grp == g)
                     static_for<LAST>([&](auto jc) PJR_INL {
                         constexpr int j = decltype(jc)::value, o = col_owner(j);
-                        if constexpr (o != g && ELM.slot[j] < 0) EX[ex_index(j)][g < o ? g : g - 1][tid] = E[j];
+                        if constexpr (o != g && ELM.slot[j] < 0 && e_live_col(j)) EX[ex_index(j)][g < o ? g : g - 1][tid] = E[j];
                     });
             });
             RED[0][grp][tid] = H; RED[1][grp][tid] = SCP; RED[2][grp][tid] = SJT; RED[3][grp][tid] = HP; RED[4][grp][tid] = HQ;
@@ -1429,36 +1573,42 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 constexpr int g = decltype(gc)::value;
                 H += RED[0][g][tid]; SCP += RED[1][g][tid]; SJT += RED[2][g][tid]; HP += RED[3][g][tid]; HQ += RED[4][g][tid];
             });
-            static_for<G_>([&](auto gc) PJR_INL {
-                constexpr int g = decltype(gc)::value;
-                if (grp == g)
-                    static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
-                        constexpr int j = decltype(jc)::value;
-                        if constexpr (ELM.slot[j] >= 0) {
-                            // the groups' slots of this column, in group order
-                            E[j] = 0.0;
-                            static_for<G_>([&](auto qc) PJR_INL {
-                                E[j] += SM[SM_EL + ((long)decltype(qc)::value * NEL_ + ELM.slot[j]) * PJQ_BLOCK + tid];
-                            });
-                        } else {
-                            static_for<G_ - 1>([&](auto qc) PJR_INL { E[j] += EX[ex_index(j)][decltype(qc)::value][tid]; });
-                        }
-                    });
-            });
         }
-        if constexpr (G_ == 1)
-            static_for<LAST>([&](auto jc) PJR_INL {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (ELM.slot[j] >= 0) E[j] = el[ELM.slot[j] * PJQ_BLOCK];
-            });
+        // the total of column j, for the lane group that owns it (called once per column, right where the value is
+        // used: gathered in front of the energy row, the sums of 55 columns spill)
+        auto ecol = [&](auto jc) PJR_INL {
+            constexpr int j = decltype(jc)::value;
+            double e = 0.0;
+            if constexpr (G_ == 1) {
+                if constexpr (ELM.slot[j] >= 0) e = el[ELM.slot[j] * PJQ_BLOCK]; else e = E[j];
+            } else {
+                double (*const EX)[G_ > 1 ? G_ - 1 : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ - 1 : 1][PJQ_BLOCK])(SM + SM_EX);
+                if constexpr (ELM.slot[j] >= 0) {
+                    // the groups' slots of this column, in group order
+                    static_for<G_>([&](auto qc) PJR_INL {
+                        e += SM[SM_EL + ((long)decltype(qc)::value * NEL_ + ELM.slot[j]) * PJQ_BLOCK + tid];
+                    });
+                } else if constexpr (e_live_col(j)) {
+                    e = E[j];
+                    static_for<G_ - 1>([&](auto qc) PJR_INL { e += EX[ex_index(j)][decltype(qc)::value][tid]; });
+                }
+                // + the column sum that the block of row j finished
+                if constexpr (EJ_LDS) e += SM[SM_EJ + j * PJQ_BLOCK + tid];
+                else e += scr[(long)(E_COL0 + j) * PJQ_TILE];
+            }
+            return e;
+        };
         // column j + 1 of the energy row (create_jacobian.py:2940-3120)
         auto erow = [&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
             double cpm, dcpm;
-            cp_of(jc, cpm, dcpm);
+            cp_of(jc, Te, cpm, dcpm);
             const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
-            return -((HP + E[j]) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
+            return -((HP + ecol(jc)) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
         };
+#ifndef PJR_HOST_EMU
+        asm volatile("" : "+v"(Te));        // (here: behind the barriers, or the columns' polynomials are evaluated in front of them and kept)
+#endif
         // (rho is not carried through the kernel: one division here; rounding of 1 / (1 / rho) is below the sums')
         const double rho_e = 1.0 / invrho;
         const double e0 = -(SCP - (dcpavg * icp) * H + rho_e * SJT) / (rho_e * cpavg);
@@ -1484,6 +1634,8 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             if (G_ == 1 || grp == g)
                 static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
                     PJQ_STORE(&J_(NSP * (decltype(jc)::value + 1)), erow(jc));
+                    // (the NASA selects of all the columns gathered in front of the stores would spill)
+                    if constexpr (decltype(jc)::value % 4 == 3) PJQ_SCHED_BARRIER();
                 });
         });
 #endif

@@ -42,6 +42,31 @@ def _ktab_emulated(tab, pres, y_soa):
     return jac.reshape(-1, n).T
 
 
+def test_factor_form_of_the_equilibrium_constants_against_the_truth(tables, golden, tmp_path_factory):
+    """The one-kernel geometry of the 53-species mechanism (csrc/pj_rblk.hip PJQ_KCF: 1 / K_c as a product of per-species
+    factors exp(ln X_k) that the prologue evaluates once per state, T dlnK_c/dT as a sum of t_k, the energy row finished
+    column by column from reaction enthalpies; four lane groups as four OS threads) against the binary128 truth: the
+    factors carry eps |ln X_k| each, a few times the rounding error of the pre-summed polynomial -- every entry stays
+    three orders of magnitude inside rtol 1e-6."""
+    from oracle.oracle import Oracle, OracleQuad
+    name = 'gri30_shaped'
+    tab = tables(name)
+    nsp = tab.nsp
+    L = rblk_emu_lib(name, 48, tmp_path_factory, kcf=1, halves=4, single=1, c_lds=0)[1]
+    g = golden(name)
+    pres, y = synth.dist_b(200, nsp, seed=11, Tlo=300, Thi=3000)
+    pres = np.concatenate([g['pres'], pres])
+    y = np.concatenate([g['y'].T, y], axis=1)
+    y_aos = np.ascontiguousarray(y.T)
+    truth = OracleQuad(tab).batch_jacob(pres, y_aos)
+    orc = Oracle(tab).batch_jacob(pres, y_aos)
+    emu = run_jacobian(L, nsp, pres, y)
+    rep = truth_report(emu, orc, truth, nsp, label='%s (emulated pj_rblk, factor columns / 4 groups / 1 kernel, %d states)' % (name, pres.size))
+    assert rep['test_vs_truth'] < 1e-7 and rep['test_over_1e6'] == 0
+    if rep['n_bad']:
+        assert rep['bad_explained'] and rep['bad_size_max'] < 1e-9
+
+
 @pytest.mark.parametrize('name,n_random', [('gri30_shaped', 300), ('usc2_shaped', 48)])
 def test_regrouped_formulation_is_closer_to_the_truth_than_the_reference(name, n_random, tables, golden, tmp_path_factory):
     from oracle.oracle import Oracle, OracleQuad
