@@ -688,8 +688,10 @@ constexpr int SM_LTK = SM_IXT + (PJQ_KCF ? 2 * NSP * PJQ_BLOCK : 0);
 // same room before the first block ends
 constexpr bool EJ_LDS = PJQ_SINGLE && G_ > 1;
 constexpr int SM_EJ = SM_LTK + (NKC > 0 ? NKC * 16 : 0);
-constexpr int SM_EJ_DOUBLES = (EJ_LDS ? LAST * PJQ_BLOCK : 0) > (PJQ_KCF && G_ > 1 ? 4 * G_ * PJQ_BLOCK : 0)
-                                  ? (EJ_LDS ? LAST * PJQ_BLOCK : 0) : (PJQ_KCF && G_ > 1 ? 4 * G_ * PJQ_BLOCK : 0);
+// (w = J v builds: the room holds the vector v instead -- NSP columns; a finished column sum is folded into w_0 at once)
+constexpr bool JV_LDS = PJQ_JV && EJ_LDS;
+constexpr int SM_EJ_DOUBLES = (EJ_LDS ? (JV_LDS ? NSP : LAST) * PJQ_BLOCK : 0) > (PJQ_KCF && G_ > 1 ? 4 * G_ * PJQ_BLOCK : 0)
+                                  ? (EJ_LDS ? (JV_LDS ? NSP : LAST) * PJQ_BLOCK : 0) : (PJQ_KCF && G_ > 1 ? 4 * G_ * PJQ_BLOCK : 0);
 constexpr int SM_EL = SM_EJ + SM_EJ_DOUBLES;
 #ifndef PJQ_NEL
 #define PJQ_NEL 0           // long-lived energy-row sums per lane group that live in LDS (ds_add_f64); -1: as many as fit
@@ -951,12 +953,31 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     };
 #endif
 #if PJQ_JV
-    // the vector this state's Jacobian is applied to (read once per kernel; AGPRs)
-    double V[NSP];
+    // the vector this state's Jacobian is applied to: read once per kernel, in registers (AGPRs) -- or, in the
+    // one-kernel builds with several lane groups, in an LDS column set that the groups fill together (53 doubles next
+    // to everything else spill, and every row block would reload them from scratch memory: 85 KB per state through
+    // the vector memory path, 9.8 ms per 1e6 products)
+    double V[JV_LDS ? 1 : NSP];
+    double WE = 0.0;        // JV_LDS: sum_j E^A_j v_{j+1} / W_j, the finished column sums' share of w_0
     {
         const double* vp = A.v + s * A.v_ss;
-        static_for<NSP>([&](auto cc) PJR_INL { V[decltype(cc)::value] = vp[decltype(cc)::value * A.v_si]; });
+        if constexpr (JV_LDS) {
+            static_for<G_>([&](auto gc) PJR_INL {
+                constexpr int g = decltype(gc)::value;
+                if (grp == g)
+                    static_range<group_first_species(g), group_first_species(g + 1)>([&](auto cc) PJR_INL {
+                        SM[SM_EJ + decltype(cc)::value * PJQ_BLOCK + tid] = vp[decltype(cc)::value * A.v_si];
+                    });
+            });
+            __syncthreads();
+        } else {
+            static_for<NSP>([&](auto cc) PJR_INL { V[decltype(cc)::value] = vp[decltype(cc)::value * A.v_si]; });
+        }
     }
+    auto vv = [&](auto cc) PJR_INL {
+        if constexpr (JV_LDS) return SM[SM_EJ + decltype(cc)::value * PJQ_BLOCK + tid];
+        else return V[decltype(cc)::value];
+    };
     double* const wp = A.w + s * A.w_ss;
 #endif
     // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
@@ -1438,7 +1459,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             if constexpr (k < LAST) {
 #if PJQ_JV
                 double wk = 0.0;
-                static_for<NSP>([&](auto cc) PJR_INL { wk += col_val(rc, cc) * V[decltype(cc)::value]; });
+                static_for<NSP>([&](auto cc) PJR_INL { wk += col_val(rc, cc) * vv(cc); });
                 wp[(k + 1) * A.w_si] = wk;
 #elif PJQ_PAIR
                 // two columns per store instruction: the halves of the wavefront exchange one value each,
@@ -1474,6 +1495,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             constexpr int k = pjs::BLK_ROWS[r0 + r][0];
             if constexpr (k < LAST) {
                 if constexpr (G_ == 1) e_add(std::integral_constant<int, k>{}, EA[r]);
+#if PJQ_JV
+                else if constexpr (JV_LDS) WE += EA[r] * pjs::SP[k][0] * vv(std::integral_constant<int, k + 1>{});
+#endif
                 else if constexpr (EJ_LDS) SM[SM_EJ + k * PJQ_BLOCK + tid] = EA[r];
                 else PJQ_STORE(&scr_of(A, s)[(long)(E_COL0 + k) * PJQ_TILE], EA[r]);
             }
@@ -1592,8 +1616,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     e = E[j];
                     static_for<G_ - 1>([&](auto qc) PJR_INL { e += EX[ex_index(j)][decltype(qc)::value][tid]; });
                 }
-                // + the column sum that the block of row j finished
-                if constexpr (EJ_LDS) e += SM[SM_EJ + j * PJQ_BLOCK + tid];
+                // + the column sum that the block of row j finished (w = J v with v in LDS: already in WE)
+                if constexpr (JV_LDS) {}
+                else if constexpr (EJ_LDS) e += SM[SM_EJ + j * PJQ_BLOCK + tid];
                 else e += scr[(long)(E_COL0 + j) * PJQ_TILE];
             }
             return e;
@@ -1617,8 +1642,11 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         static_for<G_>([&](auto gc) PJR_INL {
             constexpr int g = decltype(gc)::value;
             if (G_ == 1 || grp == g)
-                static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL { w0 += erow(jc) * V[decltype(jc)::value + 1]; });
+                static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
+                    w0 += erow(jc) * vv(std::integral_constant<int, decltype(jc)::value + 1>{});
+                });
         });
+        w0 -= icp * WE;         // (0 unless JV_LDS: erow's term -E_j / (W_j c_p) v_{j+1} of the finished column sums)
         if constexpr (G_ > 1) {
             double (*const RED)[G_][PJQ_BLOCK] = (double (*)[G_][PJQ_BLOCK])(SM + SM_RED);
             RED[5][grp][tid] = w0;
@@ -1626,7 +1654,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             w0 = 0.0;
             static_for<G_>([&](auto gc) PJR_INL { w0 += RED[5][decltype(gc)::value][tid]; });
         }
-        if (G_ == 1 || grp == 0) wp[0] = w0 + e0 * V[0];
+        if (G_ == 1 || grp == 0) wp[0] = w0 + e0 * vv(std::integral_constant<int, 0>{});
 #else
         if (G_ == 1 || grp == 0) PJQ_STORE(&J_(0), e0);
         static_for<G_>([&](auto gc) PJR_INL {

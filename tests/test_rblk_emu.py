@@ -159,6 +159,10 @@ def test_rblk_kernels_vs_reference_golden(tmp_path_factory, golden):
 @pytest.mark.parametrize('name,budget,kw', [
     ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
+    # one kernel, four lane groups, factor columns: v lives in an LDS column set, finished column sums fold into w_0
+    ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1)),
+    # two lane groups over several kernels: v in registers, column sums through the hand-over array
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
 ])
 def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
     """N2 for the row-block family: w = J v per state with the Jacobian consumed in registers
