@@ -1598,6 +1598,20 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 H += RED[0][g][tid]; SCP += RED[1][g][tid]; SJT += RED[2][g][tid]; HP += RED[3][g][tid]; HQ += RED[4][g][tid];
             });
         }
+        // Several kernels: the finished column sums of this group's columns come out of the hand-over array -- ALL requested
+        // here, in one batch (a load per column next to its use is a memory round trip per column, each behind the store
+        // of the column before: 170 k of the 500 k cycles of the 111-species mechanism's last kernel)
+        constexpr bool ECOL_MEM = G_ > 1 && !EJ_LDS;
+        double ECOL[ECOL_MEM ? (LAST + G_ - 1) / G_ + 1 : 1];       // (indexed within the group's column range)
+        if constexpr (ECOL_MEM) {
+            group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+                constexpr int g = decltype(gc)::value;
+                static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
+                    ECOL[decltype(jc)::value - group_first_col(g)] = PJQ_LOAD_NT(&scr[(long)(E_COL0 + decltype(jc)::value) * PJQ_TILE]);
+                });
+            });
+            PJQ_SCHED_BARRIER();
+        }
         // the total of column j, for the lane group that owns it (called once per column, right where the value is
         // used: gathered in front of the energy row, the sums of 55 columns spill)
         auto ecol = [&](auto jc) PJR_INL {
@@ -1619,7 +1633,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 // + the column sum that the block of row j finished (w = J v with v in LDS: already in WE)
                 if constexpr (JV_LDS) {}
                 else if constexpr (EJ_LDS) e += SM[SM_EJ + j * PJQ_BLOCK + tid];
-                else e += scr[(long)(E_COL0 + j) * PJQ_TILE];
+                else e += ECOL[j - group_first_col(col_owner(j))];
             }
             return e;
         };

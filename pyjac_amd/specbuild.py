@@ -33,9 +33,11 @@ LANE_FLAGS = ('-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal
 RBLK_FLAGS = '-ffp-contract=fast -fno-math-errno -fno-signed-zeros -freciprocal-math -mllvm -amdgpu-schedule-relaxed-occupancy=1'
 
 RBLK_BUDGET = 56          # accumulator doubles per row block of pj_rblk.hip (4 dense + non-zero S per row)
-RBLK_BUDGET_KCF = 48      # ... of the one-kernel builds with per-species factor columns: at 56 they keep a few long-lived
-                          # values in scratch memory, and a scratch reload sits behind every Jacobian store issued before
-                          # it (GRI-shaped: 8.5 ms at 56, 5.9 ms at 48 with no scratch; profiles/r04_rblk_gri_variants.txt)
+RBLK_BUDGET_KCF = 56      # ... of the one-kernel builds with per-species factor columns.  These must not keep ANYTHING in scratch
+                          # memory (a scratch reload sits behind every Jacobian store issued before it: GRI-shaped 8.5 ms with
+                          # 92 bytes of scratch per lane, 5.9 ms with none; profiles/r04_rblk_gri_variants.txt); since the
+                          # energy row is finished column by column they have none at 48 and at 56 (5.88 / 6.03 ms at 48
+                          # depending on unrelated edits of the source, 5.88 at 56: register allocation noise)
 RBLK_BUDGET_HALVES = 40   # ... of the two-lane-group builds (57..120 species: 110 energy-row sums per lane leave less
                           # room; USC-shaped 6.46 ms at 56, 6.35 at 48, 6.28 at 40: profiles/r03_rblk_energy_row_atomics.txt)
 RBLK_FUSE = 13            # row blocks per kernel and lane group (at most)
