@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpyjac_hip.so')
+# (PYJAC_AMD_LIB: another build of the same library, for experiments)
+LIB_PATH = os.environ.get('PYJAC_AMD_LIB') or os.path.join(_HERE, 'libpyjac_hip.so')
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int32)
