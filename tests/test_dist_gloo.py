@@ -54,17 +54,19 @@ def _worker(rank, world, port, n, rows, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gather_reassembles_global_batch():
+@pytest.mark.parametrize('world', [2, 8])
+def test_gather_reassembles_global_batch(world):
+    """world 2 and 8 (the driver's scaling run is 1 / 2 / 4 / 8 ranks)."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 1000, 9, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 1000, 9, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]

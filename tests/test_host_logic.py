@@ -260,3 +260,23 @@ def test_blob_validation_refuses_bad_flag_combinations_and_versions(tables):
     J[1] = 1
     with pytest.raises(_lib.PyjacError, match='version 1'):
         pyjac_amd.Evaluator(MechTables(J, tab.D.copy(), tab.nsp, tab.nrxn, tab.nrev, tab.npres, []), specialize='off')
+
+
+def test_one_kernel_library_keeps_nothing_in_scratch_memory():
+    """Performance guard (DESIGN.md section 5c'): the pair-store row kernel of the shipped one-kernel library of the
+    53-species mechanism must not use scratch memory -- a scratch reload sits behind every Jacobian store issued before
+    it, and the kernel loses a third of its speed to a handful of spilled registers.  Read from the code object's
+    metadata (no GPU needed); skipped where the library or the ROCm binutils are not there."""
+    import pyjac_amd
+    from pyjac_amd import specbuild
+    ev = pyjac_amd.Evaluator(MECHS['gri30_shaped'], specialize='off')
+    so = ev.spec_path('rblk')
+    if not so or not os.path.exists(so):
+        pytest.skip('no prebuilt row-block library of the 53-species mechanism')
+    res = [r for r in specbuild.kernel_resources(so) if 'k_rblk' in r[0]]
+    if not res:
+        pytest.skip('llvm-objcopy / llvm-readelf not available')
+    # code objects in link order: pair stores, general, w = J v (specbuild.build_rblk)
+    name, spills, scratch, lds = res[0]
+    assert scratch == 0, 'pair-store row kernel: %d bytes of scratch per lane (%d spilled registers)' % (scratch, spills)
+    assert lds <= 160 * 1024
