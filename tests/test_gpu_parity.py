@@ -888,3 +888,27 @@ def test_per_state_cache_serves_the_testers_call_sequence(golden, torch_cuda):
         assert pyjacob.cache_hits == h2 and np.array_equal(jac4, cached['jac'])
         pyjacob.py_eval_jacobian(0.0, P, y, jac4)        # ... and with unchanged settings the state is served again
         assert pyjacob.cache_hits == h2 + 1
+
+
+@pytest.mark.parametrize('name', ['gri30_shaped', 'synth_mid24'])
+def test_odd_batch_sizes_through_the_one_kernel_library(name, tables, torch_cuda):
+    """Batches below one workgroup of 64 states (general kernels, lanes past the end repeat the last state), exactly one,
+    one more (the pair-store kernels shift their last workgroup back over its neighbour's states) and across a chunk
+    of the AoS staging path: both layouts against the oracle (tools/small_n_check.py is the same loop as a tool)."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev(name)
+    assert ev.spec_kernel == 'pj_rblk'
+    orc = Oracle(tables(name))
+    for n in (1, 2, 63, 64, 65, 129, 1000, 65537):
+        pres, y = synth.dist_b(n, ev.nsp, seed=n)
+        ref = orc.batch_jacob(pres, np.ascontiguousarray(y.T))
+        jac = ev.jacobian(torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()).cpu().numpy().T
+        assert np.isfinite(jac).all() and jac_scaled_err(jac, ref, ev.nsp) <= 1.0, (name, n, 'soa')
+        ev.use_spec(2)
+        ja = ev.jacobian(torch.from_numpy(pres).cuda(), torch.from_numpy(np.ascontiguousarray(y.T)).cuda(),
+                         y_layout=pyjac_amd.LAYOUT_AOS, jac_layout=pyjac_amd.LAYOUT_AOS).cpu().numpy()
+        ev.use_spec(1)
+        assert np.isfinite(ja).all() and jac_scaled_err(ja, ref, ev.nsp) <= 1.0, (name, n, 'aos')
