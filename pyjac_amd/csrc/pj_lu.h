@@ -49,9 +49,21 @@ __device__ __forceinline__ double lu_bpermute(const double v, const int byte_add
 #ifndef PJ_LU_ABL
 #define PJ_LU_ABL 0          // timing experiments on k_lu_lds (results wrong): 1 no trailing update, 2 no row exchange, 4 no pivot search
 #endif
-#ifndef PJ_LU_BPERM
-#define PJ_LU_BPERM 2       // broadcasts of the pivot row: 0 all v_readlane, 1 all ds_bpermute, 2 every other column
+#ifndef PJ_LU_LOOKAHEAD
+#define PJ_LU_LOOKAHEAD 1    // k_lu: next column's pivot search in slices between this step's column updates (0: after them)
 #endif
+#ifndef PJ_LU_BPERM
+#define PJ_LU_BPERM 4       // broadcasts of the pivot row: 0 all v_readlane, 1 all ds_bpermute, 2 every other column, 4 every third, 5 two of five
+#endif
+#ifndef PJ_LU_WAVES
+#define PJ_LU_WAVES (NP <= 56 ? 3 : 2)   // k_lu: wavefronts per SIMD the register allocation aims at (168 / 256 registers)
+#endif
+// column k + d of elimination step k: pivot-row entry through the LDS crossbar (true) or v_readlane (false)
+constexpr bool lu_via_lds(const int d)
+{
+    return PJ_LU_BPERM == 1 || (PJ_LU_BPERM == 2 && (d & 1) == 0) || (PJ_LU_BPERM == 4 && d % 3 == 0) ||
+           (PJ_LU_BPERM == 5 && (d % 5 == 0 || d % 5 == 2)) || (PJ_LU_BPERM == 6 && d % 4 == 0);
+}
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double lu_dpp_max(const double v)
@@ -72,6 +84,17 @@ __device__ __forceinline__ double lu_dpp_max(const double v)
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));     // (fmax() would canonicalise both operands first)
     return r;
+}
+
+// the same step on unsigned keys: v_max_u32 takes the DPP operand itself (lanes without a source lane read 0, the
+// identity; rows outside ROWMASK keep their value)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned lu_dpp_umax(const unsigned v)
+{
+    unsigned o;
+    if constexpr (ROWMASK == 0xf) o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+    else o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false);
+    return v > o ? v : o;
 }
 
 // 1 / u correctly rounded in all but pathological cases (v_rcp_f64 + three Newton steps: 8 instructions instead of
@@ -116,7 +139,7 @@ struct LuLay { long a_si, a_ss, v_si, v_ss; };
 // if given), LU_PREFACTORED | LU_SOLVE (lu, perm, b -> x).  gamma != 0: the matrix is I - gamma A (the Newton
 // matrix of an implicit step).
 template <int NP>
-__global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const double* A, const LuLay Y, const double gamma,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PJ_LU_WAVES))) k_lu(const int nsp, const long n, const double* A, const LuLay Y, const double gamma,
                                             double* lu, int* __restrict__ perm, const double* __restrict__ b,
                                             double* __restrict__ x, const int mode)
 {
@@ -204,6 +227,98 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
             else bb = act ? b[lane * Y.v_si + s * Y.v_ss] : 0.0;
         }
         asm volatile("" : "+s"(nsp), "+v"(lane));
+#if PJ_LU_LOOKAHEAD
+        if (!(mode & LU_PREFACTORED)) {
+            // The pivot of column k + 1 depends on step k through that one column only: step k updates it first and
+            // the search for its pivot -- a chain of ~25 dependent instructions (magnitude key, six DPP maxima,
+            // ballot, 1 / u from v_rcp_f64 + three Newton steps) -- is issued in slices between the updates of the
+            // other columns, which hide its latency (two wavefronts per SIMD cannot).  The search runs on the upper
+            // 32 bits of |a| as an unsigned key (v_max_u32 with a DPP operand: one instruction per reduction step
+            // instead of three); keys that tie (one in 2^20 per pair of rows, or exact ties) are settled by the
+            // same reduction on the lower 32 bits of the tying rows, so the choice is dgetf2's as before.
+            unsigned key = 0, kmax = 0;
+            int pn = 0;
+            double ukkn = 1.0, invn = 1.0;
+            auto stage = [&](auto knc, auto sc_) {
+                constexpr int kn = decltype(knc)::value, S = decltype(sc_)::value;
+                if constexpr (kn < NP) {
+                    if constexpr (S == 0) {
+                        const bool open = pos < 0 && act;
+                        const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(a[kn]) >> 32) & 0x7fffffffu;
+                        key = (open && a[kn] == a[kn]) ? hi : 0u;          // a NaN never beats a number
+                        kmax = key;
+                    } else if constexpr (S == 1) {
+                        kmax = lu_dpp_umax<0x111, 0xf>(kmax);
+                        kmax = lu_dpp_umax<0x112, 0xf>(kmax);
+                    } else if constexpr (S == 2) {
+                        kmax = lu_dpp_umax<0x114, 0xf>(kmax);
+                        kmax = lu_dpp_umax<0x118, 0xf>(kmax);
+                    } else if constexpr (S == 3) {
+                        kmax = lu_dpp_umax<0x142, 0xa>(kmax);
+                        kmax = lu_dpp_umax<0x143, 0xc>(kmax);
+                    } else if constexpr (S == 4) {
+                        const unsigned mx = (unsigned)__builtin_amdgcn_readlane((int)kmax, 63);
+                        const bool in = (pos < 0) & act & (key == mx);
+                        unsigned long long hit = __builtin_amdgcn_ballot_w64(in);
+                        if (__builtin_popcountll(hit) > 1) {        // (wavefront-uniform, rare)
+                            // the same reduction on the lower 32 bits of the tying rows
+                            const unsigned k2 = (in && a[kn] == a[kn]) ? (unsigned)(unsigned long long)__double_as_longlong(a[kn]) : 0u;
+                            unsigned m2 = k2;
+                            m2 = lu_dpp_umax<0x111, 0xf>(m2);
+                            m2 = lu_dpp_umax<0x112, 0xf>(m2);
+                            m2 = lu_dpp_umax<0x114, 0xf>(m2);
+                            m2 = lu_dpp_umax<0x118, 0xf>(m2);
+                            m2 = lu_dpp_umax<0x142, 0xa>(m2);
+                            m2 = lu_dpp_umax<0x143, 0xc>(m2);
+                            const unsigned mx2 = (unsigned)__builtin_amdgcn_readlane((int)m2, 63);
+                            hit = __builtin_amdgcn_ballot_w64(in && k2 == mx2);      // (never empty)
+                        }
+                        pn = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit | (1ull << 63)));
+                        ukkn = lu_readlane(a[kn], pn);
+                    } else if constexpr (S == 5) {
+                        invn = __builtin_amdgcn_rcp(ukkn);
+                        invn = __builtin_fma(__builtin_fma(-ukkn, invn, 1.0), invn, invn);
+                    } else if constexpr (S == 6) {
+                        invn = __builtin_fma(__builtin_fma(-ukkn, invn, 1.0), invn, invn);
+                        invn = __builtin_fma(__builtin_fma(-ukkn, invn, 1.0), invn, invn);
+                    }
+                }
+            };
+            constexpr int NSTAGE = 7;
+            lu_for<0, NSTAGE>([&](auto sc_) { stage(std::integral_constant<int, 0>{}, sc_); });
+            lu_for<0, NP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k < nsp) {                                   // wavefront-uniform
+                    const int p = pn;
+                    const double inv = invn;
+                    if (lane == p) { pos = k; myinv = inv; }
+                    const bool below = pos < 0;                  // rows not chosen yet: eliminated by this pivot
+                    const double l = below ? a[k] * inv : 0.0;
+                    if (below) a[k] = l;
+                    // slices of the next search after columns k + 1, k + 1 + SP, k + 1 + 2 SP ...
+                    constexpr int NC = NP - 1 - k;
+                    constexpr int SP = NC >= 4 * NSTAGE ? 4 : NC >= 2 * NSTAGE ? 2 : 1;
+                    lu_for<k + 1, NP>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const double ukj = lu_via_lds(j - k) ? lu_bpermute(a[j], p * 4) : lu_readlane(a[j], p);
+                        a[j] = __builtin_fma(-l, ukj, a[j]);     // l = 0 in the rows already chosen
+                        constexpr int d = j - k - 1;
+                        if constexpr (d % SP == 0 && d / SP < NSTAGE) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            stage(std::integral_constant<int, k + 1>{}, std::integral_constant<int, d / SP>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if constexpr (((j - k) & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                    });
+                    constexpr int DONE = NC <= 0 ? 0 : ((NC - 1) / SP + 1 < NSTAGE ? (NC - 1) / SP + 1 : NSTAGE);
+                    lu_for<DONE, NSTAGE>([&](auto sc_) { stage(std::integral_constant<int, k + 1>{}, sc_); });
+                    // forward substitution rides along: y_k is the pivot row's right-hand side
+                    if (mode & LU_SOLVE) {
+                        const double yk = lu_readlane(bb, p);
+                        bb = __builtin_fma(-l, yk, bb);
+                    }
+                }
+            });
+#else
         if (!(mode & LU_PREFACTORED)) {
             lu_for<0, NP>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
@@ -225,8 +340,7 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
                     lu_for<k + 1, NP>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
                         // (the VALU issues the v_readlane pairs and the updates, the LDS pipeline the other broadcasts)
-                        const double ukj = (PJ_LU_BPERM == 1 || (PJ_LU_BPERM == 2 && ((j - k) & 1) == 0))
-                                               ? lu_bpermute(a[j], p * 4) : lu_readlane(a[j], p);
+                        const double ukj = lu_via_lds(j - k) ? lu_bpermute(a[j], p * 4) : lu_readlane(a[j], p);
                         a[j] = __builtin_fma(-l, ukj, a[j]);     // l = 0 in the rows already chosen
                         // the broadcasts of a step are independent of its updates: left alone the scheduler issues
                         // them all first and spills a thousand scalar registers; four columns at a time
@@ -239,6 +353,7 @@ __global__ void __launch_bounds__(256) k_lu(const int nsp, const long n, const d
                     }
                 }
             });
+#endif
         } else {
             // L y = P b, column by column: position k's lane is lane k
             lu_for<0, NP>([&](auto kc) {
@@ -668,6 +783,10 @@ inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, do
         hipLaunchKernelGGL(k_lu_lds, dim3((unsigned)blocks), dim3(256), lds, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
         return 0;
     }
+#ifdef PJ_LU_ONLY_NP    // (microbenchmark builds: one instantiation)
+    lu_launch_np<PJ_LU_ONLY_NP>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st);
+    return 0;
+#endif
     switch ((nsp + 7) / 8) {
     case 1: lu_launch16<8, 16>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
     case 2: lu_launch16<16, 16>(nsp, n, A, Y, gamma, lu, perm, b, x, mode, cus, st); break;
