@@ -211,12 +211,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PJ_LU_
             });
         }
         {
+            // a -> sh * delta_ij + sc * a in the block, delta_ij in the padding: one FMA per entry with a per-lane scale
+            // (0 in the padding rows, whose loads are clamped copies) and a diagonal term picked by its upper word
+            // (0.0 and 1.0 share the lower one)
             const bool newton = !(mode & LU_PREFACTORED) && gamma != 0.0;
-            const double sc = newton ? -gamma : 1.0, sh = newton ? 1.0 : 0.0;     // a -> sh * delta_ij + sc * a
+            const double sc = newton ? -gamma : 1.0, sh = newton ? 1.0 : 0.0;
+            const double sc_l = act ? sc : 0.0;
+            const int dg_l = act ? (int)((unsigned long long)__double_as_longlong(sh) >> 32) : 0x3ff00000;
             lu_for<0, NP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                const double id = (j == lane) ? 1.0 : 0.0;
-                a[j] = (act && j < nsp) ? __builtin_fma(sc, a[j], sh * id) : id;
+                const bool col = j < NP - 7 || j < nsp;          // (uniform; compile-time for all but seven columns)
+                const double dj = __hiloint2double(j == lane ? (col ? dg_l : 0x3ff00000) : 0, 0);
+                a[j] = __builtin_fma(col ? sc_l : 0.0, a[j], dj);
             });
         }
         // pos: the position this lane's row was chosen for (-1: not yet); a prefactored block is read row by position
@@ -236,6 +242,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PJ_LU_
             // 32 bits of |a| as an unsigned key (v_max_u32 with a DPP operand: one instruction per reduction step
             // instead of three); keys that tie (one in 2^20 per pair of rows, or exact ties) are settled by the
             // same reduction on the lower 32 bits of the tying rows, so the choice is dgetf2's as before.
+            // the rows not chosen yet as a wavefront mask: lane predicates come out of it for free (inverse ballot)
+            unsigned long long openmask = nsp >= 64 ? ~0ull : (1ull << nsp) - 1ull;
             unsigned key = 0, kmax = 0;
             int pn = 0;
             double ukkn = 1.0, invn = 1.0;
@@ -243,9 +251,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PJ_LU_
                 constexpr int kn = decltype(knc)::value, S = decltype(sc_)::value;
                 if constexpr (kn < NP) {
                     if constexpr (S == 0) {
-                        const bool open = pos < 0 && act;
+                        const bool open = __builtin_amdgcn_inverse_ballot_w64(openmask);
                         const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(a[kn]) >> 32) & 0x7fffffffu;
-                        key = (open && a[kn] == a[kn]) ? hi : 0u;          // a NaN never beats a number
+                        key = (open & (a[kn] == a[kn])) ? hi : 0u;         // a NaN never beats a number
                         kmax = key;
                     } else if constexpr (S == 1) {
                         kmax = lu_dpp_umax<0x111, 0xf>(kmax);
@@ -258,9 +266,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PJ_LU_
                         kmax = lu_dpp_umax<0x143, 0xc>(kmax);
                     } else if constexpr (S == 4) {
                         const unsigned mx = (unsigned)__builtin_amdgcn_readlane((int)kmax, 63);
-                        const bool in = (pos < 0) & act & (key == mx);
-                        unsigned long long hit = __builtin_amdgcn_ballot_w64(in);
+                        unsigned long long hit = __builtin_amdgcn_ballot_w64(key == mx) & openmask;
                         if (__builtin_popcountll(hit) > 1) {        // (wavefront-uniform, rare)
+                            const bool in = __builtin_amdgcn_inverse_ballot_w64(hit);
                             // the same reduction on the lower 32 bits of the tying rows
                             const unsigned k2 = (in && a[kn] == a[kn]) ? (unsigned)(unsigned long long)__double_as_longlong(a[kn]) : 0u;
                             unsigned m2 = k2;
@@ -291,8 +299,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PJ_LU_
                 if (k < nsp) {                                   // wavefront-uniform
                     const int p = pn;
                     const double inv = invn;
-                    if (lane == p) { pos = k; myinv = inv; }
-                    const bool below = pos < 0;                  // rows not chosen yet: eliminated by this pivot
+                    const bool me = __builtin_amdgcn_inverse_ballot_w64(1ull << (p & 63));
+                    pos = me ? k : pos;
+                    myinv = me ? inv : myinv;
+                    openmask &= ~(1ull << (p & 63));
+                    const bool below = __builtin_amdgcn_inverse_ballot_w64(openmask);   // rows not chosen yet: eliminated by this pivot
                     const double l = below ? a[k] * inv : 0.0;
                     if (below) a[k] = l;
                     // slices of the next search after columns k + 1, k + 1 + SP, k + 1 + 2 SP ...
