@@ -472,11 +472,16 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
                 const unsigned long long hit = __builtin_amdgcn_ballot_w64(mine);
                 if (hit == 0) { if (tid == 0) red_i[0] = c0; }             // a column of NaNs
                 else {
-                    int lowest = mine ? brow : 0x7fffffff;
+                    int lowest;
+                    if (__builtin_popcountll(hit) == 1) {        // (uniform; the usual case: no tie, no reduction)
+                        lowest = __builtin_amdgcn_readlane(brow, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit)));
+                    } else {
+                        lowest = mine ? brow : 0x7fffffff;
 #pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        const int o = __shfl_xor(lowest, off, 64);
-                        lowest = o < lowest ? o : lowest;
+                        for (int off = 32; off >= 1; off >>= 1) {
+                            const int o = __shfl_xor(lowest, off, 64);
+                            lowest = o < lowest ? o : lowest;
+                        }
                     }
                     if (lane == 0) red_i[0] = lowest;
                 }
