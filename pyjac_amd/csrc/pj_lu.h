@@ -183,15 +183,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PJ_LU_
             const long s4 = s_ & ~3L;                         // first block of this round's four
             const int tid = (int)threadIdx.x, w4 = tid & 3, e0 = tid >> 2;
             const long sl = s4 + w4 < n ? s4 + w4 : n - 1;
-            lu_for<0, (NP + 7) / 8>([&](auto cc) {
+            // (the loads of chunk c + 1 are issued before chunk c goes through its two barriers and the LDS: one memory
+            // round trip per chunk off the critical path)
+            constexpr int NCH = (NP + 7) / 8;
+            double v0[8], v1[8];
+            // a thread's eight entries of a chunk: row e0 of columns j0 .. j0 + 7 -- a per-thread base and uniform
+            // column offsets (scalar arithmetic; the general index expression cost ~10 vector instructions per load)
+            const double* const Ab = A + (long)(e0 < nsp ? e0 : nsp - 1) * Y.a_si + sl;
+            const long cs = (long)nsp * Y.a_si;
+            auto fetch = [&](auto cc, double (&v)[8]) {
                 constexpr int j0 = 8 * decltype(cc)::value;
-                double v[(8 * 64 + 63) / 64];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {                  // 8 columns x 64 rows = 512 entries, 64 per pass
-                    const int e = e0 + 64 * q, r = e & 63, c = j0 + (e >> 6);
-                    const int rc = r < nsp ? r : nsp - 1, ccl = c < nsp ? c : nsp - 1;
-                    v[q] = A[((long)rc + (long)nsp * ccl) * Y.a_si + sl];
+                    const int c = j0 + q;
+                    v[q] = Ab[(long)(c < nsp ? c : nsp - 1) * cs];
                 }
+            };
+            fetch(std::integral_constant<int, 0>{}, v0);
+            lu_for<0, NCH>([&](auto cc) {
+                constexpr int ci = decltype(cc)::value, j0 = 8 * ci;
+                double (&v)[8] = (ci & 1) ? v1 : v0;
+                if constexpr (ci + 1 < NCH) fetch(std::integral_constant<int, ci + 1>{}, (ci & 1) ? v0 : v1);
                 __syncthreads();                               // the previous chunk has been picked up
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
