@@ -656,6 +656,25 @@ __device__ __forceinline__ double lu_group_max(double mx)
     return mx;
 }
 
+// the same on unsigned keys: v_max_u32 takes the rotated operand itself
+template <int GW>
+__device__ __forceinline__ unsigned lu_group_umax(unsigned m)
+{
+    auto rot = [](const unsigned v, auto ctrl) {
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, true);
+        return v > o ? v : o;
+    };
+    m = rot(m, std::integral_constant<int, 0x121>{});      // row_ror:1, 2, 4, 8
+    m = rot(m, std::integral_constant<int, 0x122>{});
+    m = rot(m, std::integral_constant<int, 0x124>{});
+    m = rot(m, std::integral_constant<int, 0x128>{});
+    if constexpr (GW == 32) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+        m = sw[0] > sw[1] ? sw[0] : sw[1];
+    }
+    return m;
+}
+
 template <int NP, int GW>      // NP <= GW: 16 (four blocks per wavefront) or 32 (two)
 __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const double* A, const LuLay Y, const double gamma,
                                               double* lu, int* __restrict__ perm, const double* __restrict__ b,
@@ -707,13 +726,24 @@ __global__ void __launch_bounds__(256) k_lu16(const int nsp, const long n, const
             lu_for<0, NP>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 if (k < nsp) {
-                    const bool open = pos < 0 && act;
-                    double mx = open ? fabs(a[k]) : -1.0;
-                    const double cand = mx;
-                    mx = lu_group_max<GW>(mx);          // the maximum of the group, in all of its lanes
-                    int p = lu_group_first<GW>(open && cand == mx, lane);
-                    const int p_any = lu_group_first<GW>(open, lane);
-                    if (p > (lane | (GW - 1))) p = p_any;                     // a column of NaNs: any open row of the group
+                    // pivot search on unsigned keys, as in k_lu: the upper 32 bits of |a| (a NaN counts as 0, so the
+                    // rows that tie with the group's maximum are never none while a row is open), ties settled on the
+                    // lower 32 bits -- for every group at once if any group has one (wavefront-uniform, rare)
+                    const bool open = (pos < 0) & act;
+                    const unsigned long long ub = (unsigned long long)__double_as_longlong(a[k]);
+                    const bool num = a[k] == a[k];
+                    const unsigned key = (open & num) ? (unsigned)(ub >> 32) & 0x7fffffffu : 0u;
+                    const unsigned km = lu_group_umax<GW>(key);          // the maximum of the group, in all of its lanes
+                    const bool in = open & (key == km);
+                    const int base = lane & ~(GW - 1);
+                    constexpr unsigned long long GMASK = (1ull << GW) - 1ull;
+                    unsigned long long f = (__builtin_amdgcn_ballot_w64(in) >> base) & GMASK;
+                    if (__builtin_amdgcn_ballot_w64((f & (f - 1ull)) != 0ull) != 0ull) {
+                        const unsigned k2 = (in & num) ? (unsigned)ub : 0u;
+                        const unsigned k2m = lu_group_umax<GW>(k2);
+                        f = (__builtin_amdgcn_ballot_w64(in & (k2 == k2m)) >> base) & GMASK;
+                    }
+                    int p = base + (int)__builtin_ctzll(f | (1ull << GW));    // first row of maximum magnitude (dgetf2)
                     p = p > 63 ? lane : p;                                     // (a group without blocks: harmless values)
                     if (lane == p) pos = k;
                     const int src = p * 4;
