@@ -613,20 +613,9 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
 // ---- blocks of up to 16 rows: four blocks per wavefront ---------------------------------------------------------
 // A 10 x 10 block (the H2-size mechanisms) leaves 54 of k_lu's 64 lanes idle.  k_lu16 gives every block one DPP row
 // of 16 lanes: lane = 16 g + i holds row i of block g, the pivot is a maximum over the row of lanes (four DPP
-// rotations: every lane ends up with it), the first lane that holds it comes out of the ballot's 16-bit field of the
-// group, and the pivot row travels through the LDS crossbar (ds_bpermute_b32 with a per-lane source: each group
+// rotations of unsigned magnitude keys: every lane ends up with it), the first lane that holds it comes out of the
+// ballot's 16-bit field of the group, and the pivot row travels through the LDS crossbar (ds_bpermute_b32 with a per-lane source: each group
 // reads its own pivot lane).  Same (lu, perm) results as k_lu.
-template <int CTRL>
-__device__ __forceinline__ double lu_dpp_rot_max(const double v)
-{
-    const long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);       // a rotation: every lane has a source
-    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
-    const double o = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
-    return r;
-}
 // first lane of this lane's group of GW for which `pred` holds (the lane after the group if none does)
 template <int GW>
 __device__ __forceinline__ int lu_group_first(const bool pred, const int lane)
@@ -636,27 +625,9 @@ __device__ __forceinline__ int lu_group_first(const bool pred, const int lane)
     const unsigned long long f = (m >> base) & ((1ull << GW) - 1ull);
     return base + (int)__builtin_ctzll(f | (1ull << GW));
 }
-// maximum over the group of GW lanes, in every lane of it: four rotations inside the DPP rows of 16; for groups of
-// 32 the two rows of a group then exchange through v_permlane16_swap (odd rows of one copy <-> even rows of the other)
-template <int GW>
-__device__ __forceinline__ double lu_group_max(double mx)
-{
-    mx = lu_dpp_rot_max<0x121>(mx);      // row_ror:1, 2, 4, 8
-    mx = lu_dpp_rot_max<0x122>(mx);
-    mx = lu_dpp_rot_max<0x124>(mx);
-    mx = lu_dpp_rot_max<0x128>(mx);
-    if constexpr (GW == 32) {
-        const unsigned long long u = (unsigned long long)__double_as_longlong(mx);
-        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
-        const double e = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));   // even rows' value
-        const double o = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));   // odd rows' value
-        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(e), "v"(o));
-    }
-    return mx;
-}
-
-// the same on unsigned keys: v_max_u32 takes the rotated operand itself
+// maximum of unsigned keys over the group of GW lanes, in every lane of it: four rotations inside the DPP rows of 16
+// (v_max_u32 takes the rotated operand itself); for groups of 32 the two rows of a group then exchange through
+// v_permlane16_swap (odd rows of one copy <-> even rows of the other)
 template <int GW>
 __device__ __forceinline__ unsigned lu_group_umax(unsigned m)
 {
