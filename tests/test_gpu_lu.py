@@ -41,7 +41,7 @@ def _scipy_perm(piv):
     return perm
 
 
-@pytest.mark.parametrize('nsp', [1, 2, 7, 8, 9, 10, 16, 17, 24, 32, 33, 48, 53, 56, 57, 64, 65, 100, 111, 128, 129, 140])
+@pytest.mark.parametrize('nsp', [1, 2, 7, 8, 9, 10, 16, 17, 24, 32, 33, 48, 53, 54, 55, 56, 57, 64, 65, 100, 111, 128, 129, 140])
 def test_lu_factor_matches_lapack(nsp, torch_cuda):
     """P A = L U with LAPACK's pivot rows; factors agree to rounding; also through I - gamma A."""
     import scipy.linalg
