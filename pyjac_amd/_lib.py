@@ -87,6 +87,14 @@ def lib():
             raise PyjacError(
                 'HIP extension %s is not built; run `python -c "import __graft_entry__ as g; '
                 'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+        # One HIP runtime per process: the device buffers this package hands to the library are torch's, and torch
+        # brings its own libamdhip64.  Loaded first, it also satisfies libpyjac_hip's dependency; loaded second (the
+        # library before torch, as `build(); smoke()` in one process does), /opt/rocm's copy would be a second runtime
+        # in the process and its hipGetDeviceCount fails once torch's has the device ("no HIP device available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass    # a torch-free consumer of the C ABI: the system runtime is then the only one
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
