@@ -102,6 +102,11 @@ using namespace pj;
 #define PJQ_SUMSETS (PJQ_SINGLE ? 0 : 2 * PJQ_HALVES)   // slot sets of the energy-row sums between row kernels: a pair
                             // per lane group of the ROW kernels (every translation unit of a library gets the same value)
 #endif
+#ifndef PJQ_ECL
+#define PJQ_ECL 0           // 1: what the block of row j cannot see of column j of the energy row (enhanced colliders, a falloff
+                            // collider, a species on both sides) is summed ONCE per state by k_pre and handed over: the row
+                            // kernels carry no long-lived energy-row sums at all (every translation unit gets the same value)
+#endif
 #ifndef PJQ_CONC_AHEAD
 #define PJQ_CONC_AHEAD 1    // 1: a visit's concentration reads are issued during the previous visit (-1 %)
 #endif
@@ -236,7 +241,31 @@ constexpr BCols BCOL = make_bcols();
 // slot per column behind the slot sets (written once, by the kernel that holds the row)
 #define PJQ_ECOLS (PJQ_SUMSETS > 2)
 constexpr int E_COL0 = pjs::NSCQ + PJQ_SUMSETS * NSUM;
-constexpr int NSLOTS = E_COL0 + (PJQ_ECOLS ? pjs::NSP - 1 : 0);
+// PJQ_ECL: one slot per marked column (BCOL) behind them, written by k_pre, read by the last row kernel's epilogue
+constexpr int ECL0 = E_COL0 + (PJQ_ECOLS ? pjs::NSP - 1 : 0);
+constexpr int ecl_index(int j)
+{
+    int c = 0;
+    for (int q = 0; q < j; ++q) c += BCOL.b[q] ? 1 : 0;
+    return c;
+}
+constexpr int NSLOTS = ECL0 + (PJQ_ECL ? BCOL.n : 0);
+// does reaction i put anything into a column whose species is not one of its net species?
+constexpr bool has_ecl(int i)
+{
+    bool any = false;
+    auto mark = [&](int sp) { if (sp >= 0 && sp < pjs::NSP - 1 && !in_net(i, sp)) any = true; };
+    const int fl = pjs::RI[i][RI_FLAGS];
+    for (int c = RI_R0; c <= RI_R2; ++c) mark(pjs::RI[i][c]);
+    if (fl & F_REV) for (int c = RI_P0; c <= RI_P2; ++c) mark(pjs::RI[i][c]);
+    if (fl & F_GEN) {
+        const int nf = pjs::RI[i][RI_GEN_NR] + ((fl & F_REV) ? pjs::RI[i][RI_GEN_NP] : 0);
+        for (int f = 0; f < nf; ++f) mark(pjs::GEN_SP[pjs::RI[i][RI_GEN_PTR] + f][0]);
+    }
+    if (fl & F_EFFTYPE) for (int e = 0; e < pjs::RI[i][RI_EFF_CNT]; ++e) mark(pjs::EFF_SP[pjs::RI[i][RI_EFF_PTR] + e][0]);
+    if ((fl & F_COLLIDER) && pjs::RI[i][RI_COLLIDER] >= 0) mark(pjs::RI[i][RI_COLLIDER]);
+    return any;
+}
 
 // reactions evaluated once per state by k_pre and handed over
 constexpr bool is_pre(int i) { return (pjs::RI[i][RI_FLAGS] & (F_PDEP | F_PLOG | F_CHEB)) != 0; }
@@ -434,11 +463,17 @@ struct __attribute__((aligned(16))) d2 { double x, y; };
 #define PJR_SLOT(i_, c_) pjs::SCQ[i_][c_]
 constexpr bool kf_plain(int) { return false; }
 constexpr int NEFF = (int)(sizeof(pjs::EFF_AM1) / sizeof(pjs::EFF_AM1[0]));
+// k_pre's reactions: the hand-over reactions and -- PJQ_ECL -- every reaction that puts something into a column of the
+// energy row whose species is not one of its net species (enhanced colliders, a falloff collider, a species on both
+// sides: the block that finishes the column never sees it).  Those are summed here, once per state:
+// E^B_j = sum_i Hr_i G_ij over exactly the (i, j) that make_bcols marks.
+constexpr bool in_pre(int i) { return is_pre(i) || (PJQ_ECL && has_ecl(i)); }
+constexpr int NECL = PJQ_ECL ? BCOL.n : 0;
 constexpr KcMap make_kcmap()
 {
     KcMap m{};
     for (int g = 0; g < NKC_ALL; ++g) m.loc[g] = -1;
-    for (int i = 0; i < NRXN; ++i) if (is_pre(i)) kcmap_add(m, i);
+    for (int i = 0; i < NRXN; ++i) if (in_pre(i)) kcmap_add(m, i);
     return m;
 }
 constexpr KcMap KCM = make_kcmap();
@@ -447,11 +482,11 @@ struct KcList { int v[NKC > 0 ? NKC : 1]; };
 constexpr KcList make_list() { KcList l{}; for (int q = 0; q < NKC; ++q) l.v[q] = KCM.list[q]; return l; }
 __device__ const KcList KCL = make_list();
 
-// ordinal of reaction i among the hand-over reactions (PJQ_HALVES == 2: even ones to half 0, odd ones to half 1)
+// ordinal of reaction i among k_pre's reactions (PJQ_HALVES == 2: even ones to half 0, odd ones to half 1)
 constexpr int pre_ordinal(int i)
 {
     int c = 0;
-    for (int q = 0; q < i; ++q) c += is_pre(q) ? 1 : 0;
+    for (int q = 0; q < i; ++q) c += in_pre(q) ? 1 : 0;
     return c;
 }
 constexpr int NTHR = PJQ_BLOCK * PJQ_HALVES;
@@ -484,11 +519,10 @@ __global__ void __launch_bounds__(NTHR) k_pre(PjqArgs A)
             static_for<NSP>([&](auto kc) PJR_INL { CLr[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
     }
     __syncthreads();
-    if (s_nom >= A.n) return;
+    // (lanes past the end repeat the last state: same values to the same addresses)
 #define CC(idx) ((idx) == ONE ? 1.0 : CLr[(idx) == ONE ? 0 : (idx)][tid])
 #else
     __syncthreads();
-    if (s_nom >= A.n) return;
     State L;
     load_state(A, s, L);
     to_conc(L);
@@ -507,11 +541,13 @@ __global__ void __launch_bounds__(NTHR) k_pre(PjqArgs A)
 #endif
     double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
     double jt[NSP], jtq = 0.0;          // d/dT sums are taken by the row kernels: dead here
+    double ecl[NECL > 0 ? NECL : 1];
+    static_for<NECL>([&](auto cc) PJR_INL { ecl[decltype(cc)::value] = 0.0; });
     auto run_pre = [&](auto hc) PJR_INL {
     constexpr int HALF_ = decltype(hc)::value;
     static_for<NRXN>([&](auto ic) PJR_INL {
         constexpr int i = decltype(ic)::value;
-        if constexpr (is_pre(i) && (PJQ_HALVES == 1 || pre_ordinal(i) % 2 == HALF_)) {
+        if constexpr (in_pre(i) && (PJQ_HALVES == 1 || pre_ordinal(i) % 2 == HALF_)) {
 #define PJR_RD(i_) pjs::RD[i_]
 #define PJR_KCROW(g_) (LT + KCM.loc[g_] * 16)
 #define PJR_EFL(e_) pjs::EFF_AM1[e_][0]
@@ -520,8 +556,80 @@ __global__ void __launch_bounds__(NTHR) k_pre(PjqArgs A)
 #include "pj_rate_pre.inc"
 #undef PJR_RD
 #undef PJR_KCROW
-#undef PJR_EFL
 #undef PJR_KC_FIRST
+#if PJQ_ECL
+            if constexpr (has_ecl(i)) {
+                // the slots of k_rblk's visit (create_jacobian.py:341-489, 2850-2938) whose species is not a net species
+                // of the reaction, times the reaction enthalpy Hr_i = sum_k nu_ki h_kW_k = R T (T dlnK_c/dT + sum nu)
+                constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
+                double Hr;
+                if constexpr ((fl & F_REV) != 0) {
+                    Hr = (RU_ * T) * (TdlnKc + net_sum(i));
+                } else {
+                    Hr = 0.0;
+                    static_for<ncnt>([&](auto qc) PJR_INL {
+                        constexpr int k = pjs::NET_SP[np0 + decltype(qc)::value][0];
+                        const bool lo = T <= pjs::SP[k][2];
+                        double a[6];
+                        static_for<6>([&](auto cc) PJR_INL {
+                            constexpr int c_ = decltype(cc)::value;
+                            a[c_] = lo ? pjs::SP[k][4 + c_] : pjs::SP[k][11 + c_];
+                        });
+                        Hr += pjs::NET_NU[np0 + decltype(qc)::value][0] *
+                              (RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) +
+                                      T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T))))));
+                    });
+                }
+                double gkf = c * kf, gkr = c * kr;
+                if constexpr (pjs::SCQ[i][S_KR] >= 0) {       // Chebyshev: eval_jacob's own k_f (pj_rate_pre.inc)
+                    gkf = kfj_;
+                    if constexpr ((fl & F_REV) != 0) gkr = kfj_ * ekc[pjs::KC_CLASS[i][0]];
+                }
+                auto eslot = [&](auto spc, const double gv) PJR_INL {
+                    constexpr int sp = decltype(spc)::value;
+                    if constexpr (sp < LAST) {
+                        if constexpr (!in_net(i, sp)) {
+                            static_assert(BCOL.b[sp], "energy row: column not marked");
+                            ecl[ecl_index(sp)] += Hr * gv;
+                        }
+                    }
+                };
+                eslot(std::integral_constant<int, pjs::RI[i][RI_R0]>{}, gkf * (cr1 * cr2));
+                eslot(std::integral_constant<int, pjs::RI[i][RI_R1]>{}, gkf * (cr0 * cr2));
+                eslot(std::integral_constant<int, pjs::RI[i][RI_R2]>{}, gkf * (cr0 * cr1));
+                if constexpr ((fl & F_REV) != 0) {
+                    eslot(std::integral_constant<int, pjs::RI[i][RI_P0]>{}, -gkr * (cp1 * cp2));
+                    eslot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -gkr * (cp0 * cp2));
+                    eslot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -gkr * (cp0 * cp1));
+                }
+                if constexpr ((fl & F_GEN) != 0) {
+                    constexpr int GP = pjs::RI[i][RI_GEN_PTR], GNR = pjs::RI[i][RI_GEN_NR];
+                    constexpr int GNP = (fl & F_REV) ? pjs::RI[i][RI_GEN_NP] : 0;
+                    double gcf[GNR + GNP > 0 ? GNR + GNP : 1], gpw[GNR + GNP > 0 ? GNR + GNP : 1];
+                    static_for<GNR + GNP>([&](auto fc) PJR_INL {
+                        constexpr int f = decltype(fc)::value;
+                        gcf[f] = CC(pjs::GEN_SP[GP + f][0]);
+                        gpw[f] = gen_pow<GP + f>(gcf[f]);
+                    });
+                    static_for<GNR + GNP>([&](auto fc) PJR_INL {
+                        constexpr int f = decltype(fc)::value;
+                        constexpr int f0 = f < GNR ? 0 : GNR, f1 = f < GNR ? GNR : GNR + GNP;
+                        double gv = (f < GNR ? gkf : -gkr) * gen_dpow<GP + f>(gcf[f]);
+                        static_range<f0, f1>([&](auto hc2) PJR_INL { if constexpr (decltype(hc2)::value != f) gv *= gpw[decltype(hc2)::value]; });
+                        eslot(std::integral_constant<int, pjs::GEN_SP[GP + f][0]>{}, gv);
+                    });
+                }
+                if constexpr ((fl & F_COLLIDER) != 0)
+                    eslot(std::integral_constant<int, (pjs::RI[i][RI_COLLIDER] >= 0 ? pjs::RI[i][RI_COLLIDER] : ONE)>{}, bcol);
+                if constexpr ((fl & F_EFFTYPE) != 0) {
+                    static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
+                        constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                        eslot(std::integral_constant<int, pjs::EFF_SP[e][0]>{}, PJR_EFL(e) * bM);
+                    });
+                }
+            }
+#endif
+#undef PJR_EFL
             PJQ_SCHED_BARRIER();
         }
     });
@@ -533,6 +641,23 @@ __global__ void __launch_bounds__(NTHR) k_pre(PjqArgs A)
         run_pre(std::integral_constant<int, 0>{});
     }
     (void)jt; (void)jtq;
+    if constexpr (NECL > 0) {
+        if constexpr (PJQ_HALVES == 2) {
+#if PJQ_C_LDS
+            // the halves' shares meet in the concentration columns (nobody reads them any more)
+            __syncthreads();
+            if (half == 1) static_for<NECL>([&](auto cc) PJR_INL { CLr[decltype(cc)::value][tid] = ecl[decltype(cc)::value]; });
+            __syncthreads();
+            if (half == 0) static_for<NECL>([&](auto cc) PJR_INL {
+                SCR_ST(ECL0 + decltype(cc)::value, ecl[decltype(cc)::value] + CLr[decltype(cc)::value][tid]);
+            });
+#else
+            static_assert(PJQ_HALVES != 2, "k_pre: two lane groups need the concentration columns (PJQ_C_LDS)");
+#endif
+        } else {
+            static_for<NECL>([&](auto cc) PJR_INL { SCR_ST(ECL0 + decltype(cc)::value, ecl[decltype(cc)::value]); });
+        }
+    }
 #undef SCR_ST
 #undef CC
 }
@@ -633,7 +758,8 @@ constexpr int NTHR = PJQ_BLOCK * G_;
 static_assert(G_ == 1 || G_ == 2 || G_ == 4, "PJQ_HALVES: 1, 2 or 4 lane groups");
 // a column of the energy row has a long-lived sum only if something outside its own row's block contributes (BCOL) --
 // or, with one lane group, always: the block's finished column sum is then kept there until the epilogue
-constexpr bool e_live_col(int j) { return G_ == 1 || BCOL.b[j]; }
+// (PJQ_ECL: those contributions come from k_pre -- no long-lived sums with several lane groups)
+constexpr bool e_live_col(int j) { return G_ == 1 || (BCOL.b[j] && !PJQ_ECL); }
 constexpr int group_first_block(int g)
 {
 #if PJQ_PLAN
@@ -790,6 +916,23 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     double T, rho, invrho, Wbar, mconc;
     double cpa = 0.0, dcpa = 0.0;       // sum_k C_k cp_k / R and its d/dT: PJQ_KCF prologue, else the last kernel's epilogue
     PJQ_CONST_BASES()
+    // PJQ_ECL: k_pre's sums of the marked columns this lane group owns.  One row kernel with several lane groups: requested
+    // here, next to the state (nothing of this workgroup is in flight yet), and put where the finished column sums go
+    // (EJ, or w_0's share of a w = J v build) right behind the prologue; otherwise the epilogue fetches them.
+    constexpr bool ECL_PRO = PJQ_ECL && PJQ_SINGLE && G_ > 1;
+    constexpr int NCOLG = (LAST + G_ - 1) / G_ + 1;
+    double ECLV[PJQ_ECL ? NCOLG : 1];
+    auto ecl_fetch = [&]() PJR_INL {
+        const double* const scr_ = scr_of(A, s);
+        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (BCOL.b[j]) ECLV[j - group_first_col(g)] = PJQ_LOAD_NT(&scr_[(long)(ECL0 + ecl_index(j)) * PJQ_TILE]);
+            });
+        });
+    };
+    if constexpr (ECL_PRO) ecl_fetch();
 #if PJQ_KCF
     {
         // Cooperative prologue: group g loads the mass fractions of ITS species, the groups exchange partial sums,
@@ -896,6 +1039,16 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     }
     __syncthreads();
 #endif
+    if constexpr (ECL_PRO && EJ_LDS && !(PJQ_JV && EJ_LDS)) {
+        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (BCOL.b[j]) SM[SM_EJ + j * PJQ_BLOCK + tid] = ECLV[j - group_first_col(g)];
+            });
+        });
+        __syncthreads();        // (the block that holds row j ADDS its finished sum: any lane group)
+    }
 #if defined(PJQ_STAGGER) && !defined(PJR_HOST_EMU)
     // experiment: shift the compute / store phases of neighbouring workgroups against each other
     {
@@ -978,6 +1131,15 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         if constexpr (JV_LDS) return SM[SM_EJ + decltype(cc)::value * PJQ_BLOCK + tid];
         else return V[decltype(cc)::value];
     };
+    if constexpr (ECL_PRO && JV_LDS) {
+        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (BCOL.b[j]) WE += ECLV[j - group_first_col(g)] * pjs::SP[j][0] * vv(std::integral_constant<int, j + 1>{});
+            });
+        });
+    }
     double* const wp = A.w + s * A.w_ss;
 #endif
     // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
@@ -1344,7 +1506,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     // with sp as a net species); what that block cannot see is added once, at the reaction's first visit
                     if constexpr (in_net(i, sp)) {
                         if constexpr (pjs::ROW_BLK[sp][0] == b) EA[pjs::ROWLOC[sp][0]] += Hr * gv;
-                    } else if constexpr (OWNER.b[i] == b) {
+                    } else if constexpr (OWNER.b[i] == b && !PJQ_ECL) {
                         static_assert(BCOL.b[sp], "energy row: column not marked");
                         e_add(std::integral_constant<int, sp>{}, Hr * gv);
                     }
@@ -1498,6 +1660,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #if PJQ_JV
                 else if constexpr (JV_LDS) WE += EA[r] * pjs::SP[k][0] * vv(std::integral_constant<int, k + 1>{});
 #endif
+                else if constexpr (EJ_LDS && PJQ_ECL && BCOL.b[k < LAST ? k : 0]) SM[SM_EJ + k * PJQ_BLOCK + tid] += EA[r];
                 else if constexpr (EJ_LDS) SM[SM_EJ + k * PJQ_BLOCK + tid] = EA[r];
                 else PJQ_STORE(&scr_of(A, s)[(long)(E_COL0 + k) * PJQ_TILE], EA[r]);
             }
@@ -1612,6 +1775,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             });
             PJQ_SCHED_BARRIER();
         }
+        if constexpr (PJQ_ECL && !ECL_PRO) { ecl_fetch(); PJQ_SCHED_BARRIER(); }
         // the total of column j, for the lane group that owns it (called once per column, right where the value is
         // used: gathered in front of the energy row, the sums of 55 columns spill)
         auto ecol = [&](auto jc) PJR_INL {
@@ -1635,6 +1799,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 else if constexpr (EJ_LDS) e += SM[SM_EJ + j * PJQ_BLOCK + tid];
                 else e += ECOL[j - group_first_col(col_owner(j))];
             }
+            if constexpr (PJQ_ECL && !ECL_PRO && BCOL.b[j]) e += ECLV[j - group_first_col(col_owner(j))];
             return e;
         };
         // column j + 1 of the energy row (create_jacobian.py:2940-3120)

@@ -23,7 +23,7 @@ SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rblk': ('pj_rblk.hip', 'pj_mat
 # environment overrides that shape a binary (experiments): part of the digest
 ENV = ('PJ_LANE_FLAGS', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE', 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES',
        'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST', 'PJ_RBLK_RATE_GROUPS', 'PJ_RBLK_RATE_DEFINES',
-       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV')
+       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV', 'PJ_RBLK_ECL')
 
 # reciprocal instead of IEEE division sequences, contraction, no -0 special-casing; NO reassociation (it keeps
 # every product of an accumulation chain live: +40 AGPRs, -5 %); measured on MI355X against -ffast-math and
@@ -197,8 +197,11 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     check(L.pj_mech_emit_rblk_spec(handle, hdr.encode(), budget, fuse, block, halves, single, r_block, r_clds,
                                    int(rates_per_part or os.environ.get('PJ_RBLK_RATE_GROUPS', 0)), cv, ce, counts))
     nker, nrate, npre = counts[0], counts[1], counts[2]
+    # several lane groups: what a row block cannot see of its column of the energy row is summed once per state by the
+    # pre-pass (PJQ_ECL), so the row kernels carry no long-lived sums
+    ecl = int(os.environ.get('PJ_RBLK_ECL', 1 if halves > 1 else 0))
     common = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr, '-I', CSRC,
-              '-DPJQ_SUMSETS=%d' % (0 if nker == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1)]
+              '-DPJQ_SUMSETS=%d' % (0 if nker == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1), '-DPJQ_ECL=%d' % ecl]
     flags = os.environ.get('PJ_RBLK_FLAGS', RBLK_FLAGS).split()
     src = os.path.join(CSRC, 'pj_rblk.hip')
     # (the 111-species kernels are short of registers: without the one-visit look-ahead of the K_c rows and
@@ -215,7 +218,7 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     rate = common + flags + ['-DPJQ_BLOCK=%d' % r_block, '-DPJQ_C_LDS=%d' % r_clds, '-DPJQ_HALVES=%d' % r_halves] + \
         list(defines) + os.environ.get('PJ_RBLK_RATE_DEFINES', '').split() + [src]
     jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
-    if npre:
+    if npre or ecl:
         jobs.append((pre + ['-DPJQ_PART=1'], 'pre.o'))
     # each row kernel three times: with pair stores (SoA output, whole workgroups: the fast path), general,
     # and as w = J v (the Jacobian consumed in registers)

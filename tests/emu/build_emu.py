@@ -12,12 +12,15 @@ CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
 
 
 def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int = 128, c_lds: int = 0,
-               opt: str = '-O1', defines=(), halves: int = 1, kcf: int = 0, single: int = 0) -> str:
+               opt: str = '-O1', defines=(), halves: int = 1, kcf: int = 0, single: int = 0, ecl: int = None,
+               pre_halves: int = 1) -> str:
     """csrc/pj_rblk.hip for the host: row blocks that rebuild their rates + falloff / PLOG pre-pass (k_pre,
     k_rblk, also as w = J v) and the rate-output kernels (k_rate, one per `rates_per_part` reactions, with and
     without the per-reaction outputs), the way specbuild.build_rblk links them.  halves: lane groups of the row kernels
     (each one OS thread in the emulation); kcf: equilibrium constants from the per-species factor columns (the header
-    must carry the rows: pj_mech_set_kc_factors before it was emitted); single: one row kernel for every block."""
+    must carry the rows: pj_mech_set_kc_factors before it was emitted); single: one row kernel for every block;
+    ecl: the energy-row terms a row block cannot see summed by the pre-pass (PJQ_ECL; default as specbuild: with several
+    lane groups); pre_halves: lane groups of the pre-pass (2 needs c_lds)."""
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
     t = open(hdr).read()
@@ -29,12 +32,15 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     if single:
         blocks_per_part = nblk
     starts = list(range(0, nblk, blocks_per_part))
-    common += ['-DPJQ_SUMSETS=%d' % (0 if len(starts) == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(len(starts) == 1)]
+    if ecl is None:
+        ecl = 1 if halves > 1 else 0
+    common += ['-DPJQ_SUMSETS=%d' % (0 if len(starts) == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(len(starts) == 1),
+               '-DPJQ_ECL=%d' % ecl]
     base = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % c_lds, os.path.join(CSRC, 'pj_rblk.hip')]
     rblk = base + ['-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf]
     jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
-    if npre:
-        jobs.append((base + ['-DPJQ_PART=1'], 'pre.o'))
+    if npre or ecl:
+        jobs.append((base + ['-DPJQ_PART=1', '-DPJQ_HALVES=%d' % pre_halves], 'pre.o'))
     for n, b0 in enumerate(starts):
         jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % n, '-DPJQ_B0=%d' % b0,
                              '-DPJQ_B1=%d' % min(nblk, b0 + blocks_per_part), '-DPJQ_FIRST=%d' % (n == 0),

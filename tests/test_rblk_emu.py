@@ -78,6 +78,14 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     # __syncthreads): groups split the row blocks of a kernel, exchange the energy-row sums and share its columns
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
     ('synth_mid24', 40, dict(blocks_per_part=6, rates_per_part=40, halves=4)),
+    # the energy-row terms a row block cannot see (enhanced colliders, a falloff collider, a species on both sides): summed
+    # once per state by the pre-pass (PJQ_ECL, the default with several lane groups -- the cases above and below) -- here
+    # with a two-group pre-pass (the 111-species geometry), with one lane group, and the long-lived sums they replace
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, c_lds=1, pre_halves=2)),
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1, ecl=1)),
+    ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6, halves=2)),
+    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2)),
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, ecl=0)),
     # equilibrium constants from per-species factor columns (PJQ_KCF: cooperative prologue, products instead of a
     # polynomial + exp per visit): one group and several kernels; four groups and ONE kernel (the 53-species shape)
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, kcf=1)),
