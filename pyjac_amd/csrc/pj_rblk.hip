@@ -107,6 +107,15 @@ using namespace pj;
                             // collider, a species on both sides) is summed ONCE per state by k_pre and handed over: the row
                             // kernels carry no long-lived energy-row sums at all (every translation unit gets the same value)
 #endif
+#ifndef PJQ_COOP
+#define PJQ_COOP (PJQ_KCF && PJQ_HALVES > 1)   // k_rblk's prologue: lane group g loads the mass fractions of ITS species, the
+                            // groups exchange partial sums and each writes its species' concentration columns (the
+                            // factor-column builds always; the polynomial K_c builds on request: 4 KB of LDS per 64 states)
+#endif
+#ifndef PJQ_DEFER
+#define PJQ_DEFER 0         // 1: the Jacobian rows of block b are stored DURING the visits of block b + 1, a slice behind every
+                            // visit, instead of in one burst behind the block's own visits (k_rblk; not the w = J v builds)
+#endif
 #ifndef PJQ_CONC_AHEAD
 #define PJQ_CONC_AHEAD 1    // 1: a visit's concentration reads are issued during the previous visit (-1 %)
 #endif
@@ -239,7 +248,9 @@ constexpr BCols make_bcols()
 constexpr BCols BCOL = make_bcols();
 // With several lane groups AND several row kernels a finished column sum travels to the last kernel through one
 // slot per column behind the slot sets (written once, by the kernel that holds the row)
-#define PJQ_ECOLS (PJQ_SUMSETS > 2)
+#ifndef PJQ_ECOLS
+#define PJQ_ECOLS (PJQ_SUMSETS > 2)      // (also set for ONE row kernel whose LDS has no room for the column sums: EJ below)
+#endif
 constexpr int E_COL0 = pjs::NSCQ + PJQ_SUMSETS * NSUM;
 // PJQ_ECL: one slot per marked column (BCOL) behind them, written by k_pre, read by the last row kernel's epilogue
 constexpr int ECL0 = E_COL0 + (PJQ_ECOLS ? pjs::NSP - 1 : 0);
@@ -812,12 +823,14 @@ constexpr int SM_LTK = SM_IXT + (PJQ_KCF ? 2 * NSP * PJQ_BLOCK : 0);
 // EJ[LAST][BLOCK]: the finished column sums of the energy row on their way from the lane group that holds the row to
 // the group that writes the column (one kernel, several groups); the prologue's partial sums PRED[4][G][BLOCK] use the
 // same room before the first block ends
-constexpr bool EJ_LDS = PJQ_SINGLE && G_ > 1;
+constexpr bool EJ_LDS = PJQ_SINGLE && G_ > 1 && !PJQ_ECOLS;
 constexpr int SM_EJ = SM_LTK + (NKC > 0 ? NKC * 16 : 0);
 // (w = J v builds: the room holds the vector v instead -- NSP columns; a finished column sum is folded into w_0 at once)
 constexpr bool JV_LDS = PJQ_JV && EJ_LDS;
-constexpr int SM_EJ_DOUBLES = (EJ_LDS ? (JV_LDS ? NSP : LAST) * PJQ_BLOCK : 0) > (PJQ_KCF && G_ > 1 ? 4 * G_ * PJQ_BLOCK : 0)
-                                  ? (EJ_LDS ? (JV_LDS ? NSP : LAST) * PJQ_BLOCK : 0) : (PJQ_KCF && G_ > 1 ? 4 * G_ * PJQ_BLOCK : 0);
+static_assert(!PJQ_KCF || G_ == 1 || PJQ_COOP, "the factor-column builds with several lane groups have a cooperative prologue");
+constexpr int PRED_DOUBLES = (PJQ_COOP && G_ > 1) ? (PJQ_KCF ? 4 : 2) * G_ * PJQ_BLOCK : 0;
+constexpr int SM_EJ_DOUBLES = (EJ_LDS ? (JV_LDS ? NSP : LAST) * PJQ_BLOCK : 0) > PRED_DOUBLES
+                                  ? (EJ_LDS ? (JV_LDS ? NSP : LAST) * PJQ_BLOCK : 0) : PRED_DOUBLES;
 constexpr int SM_EL = SM_EJ + SM_EJ_DOUBLES;
 #ifndef PJQ_NEL
 #define PJQ_NEL 0           // long-lived energy-row sums per lane group that live in LDS (ds_add_f64); -1: as many as fit
@@ -835,9 +848,11 @@ constexpr int NEL_ = PJQ_NEL >= 0 ? (PJQ_NEL < LAST ? PJQ_NEL : LAST) : nel_fit(
 constexpr int SM_EL_DOUBLES = G_ * PJQ_BLOCK * NEL_;
 constexpr int SM_MAIN = SM_EL + SM_EL_DOUBLES;
 // (the epilogue's exchange area: over the then free columns if it fits below the sums that are still needed, else behind)
-constexpr int SM_EPI_SIZE = (G_ > 1 && LASTK_) ? (LAST - NEL_) * (G_ - 1) * PJQ_BLOCK + 6 * G_ * PJQ_BLOCK : 0;
+// (PJQ_ECL: no lane group carries long-lived sums, nothing is exchanged but the scalar sums)
+constexpr int NEX = PJQ_ECL ? 0 : LAST - NEL_;
+constexpr int SM_EPI_SIZE = (G_ > 1 && LASTK_) ? NEX * (G_ - 1) * PJQ_BLOCK + 6 * G_ * PJQ_BLOCK : 0;
 constexpr int SM_EX = SM_EPI_SIZE <= SM_EJ ? 0 : SM_MAIN;
-constexpr int SM_RED = SM_EX + (LAST - NEL_) * (G_ - 1) * PJQ_BLOCK;
+constexpr int SM_RED = SM_EX + NEX * (G_ - 1) * PJQ_BLOCK;
 constexpr int SM_EPI = SM_EPI_SIZE ? SM_EX + SM_EPI_SIZE : 0;
 constexpr int SM_DOUBLES = SM_MAIN > SM_EPI ? SM_MAIN : SM_EPI;
 static_assert(SM_DOUBLES * 8 <= 160 * 1024, "LDS: columns of PJQ_BLOCK states do not fit");
@@ -917,9 +932,10 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     double cpa = 0.0, dcpa = 0.0;       // sum_k C_k cp_k / R and its d/dT: PJQ_KCF prologue, else the last kernel's epilogue
     PJQ_CONST_BASES()
     // PJQ_ECL: k_pre's sums of the marked columns this lane group owns.  One row kernel with several lane groups: requested
-    // here, next to the state (nothing of this workgroup is in flight yet), and put where the finished column sums go
-    // (EJ, or w_0's share of a w = J v build) right behind the prologue; otherwise the epilogue fetches them.
-    constexpr bool ECL_PRO = PJQ_ECL && PJQ_SINGLE && G_ > 1;
+    // right behind the prologue (no store of this workgroup is in flight yet; requested next to the state they stay in
+    // registers through the prologue's exponentials and the kernel keeps 128 bytes of scratch memory) and put where the
+    // finished column sums go (EJ, or w_0's share of a w = J v build); otherwise the epilogue fetches them.
+    constexpr bool ECL_PRO = PJQ_ECL && EJ_LDS;
     constexpr int NCOLG = (LAST + G_ - 1) / G_ + 1;
     double ECLV[PJQ_ECL ? NCOLG : 1];
     auto ecl_fetch = [&]() PJR_INL {
@@ -932,7 +948,6 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             });
         });
     };
-    if constexpr (ECL_PRO) ecl_fetch();
 #if PJQ_KCF
     {
         // Cooperative prologue: group g loads the mass fractions of ITS species, the groups exchange partial sums,
@@ -1029,6 +1044,50 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         constexpr int NQ = (NKC * 8 + NTHR - 1) / NTHR;     // 16-byte pieces per thread
         d2 lt[NQ > 0 ? NQ : 1];
         kc_issue<NQ, NTHR>(KCL.v, NKC, lt);
+#if PJQ_COOP
+        // cooperative (several lane groups): group g loads the mass fractions of ITS species only; the groups exchange the
+        // partial sums of Y_N and W and each writes its species' concentration columns
+        static_assert(G_ > 1, "PJQ_COOP: several lane groups");
+        double (*const PRED)[G_][PJQ_BLOCK] = (double (*)[G_][PJQ_BLOCK])(SM + SM_EJ);
+        const double* const y = A.y + s * A.y_ss;
+        T = y[0];
+        const double p = A.pres[s];
+        constexpr int KMAXG = (NSP + G_ - 1) / G_ + 1;
+        double Y[KMAXG];
+        double sumY = 0.0, sumYW = 0.0;
+        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            constexpr int k0 = group_first_species(g), k1 = group_first_species(g + 1);
+            static_range<k0, k1>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < LAST) Y[k - k0] = y[(k + 1) * A.y_si];
+            });
+            PJQ_SCHED_BARRIER();
+            static_range<k0, k1>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < LAST) { sumY += Y[k - k0]; sumYW += Y[k - k0] * pjs::SP[k][0]; }
+            });
+        });
+        kc_land<NQ, NTHR>(LTK, NKC, lt);
+        PRED[0][grp][tid] = sumY; PRED[1][grp][tid] = sumYW;
+        __syncthreads();
+        sumY = 0.0; sumYW = 0.0;
+        static_for<G_>([&](auto gc) PJR_INL { sumY += PRED[0][decltype(gc)::value][tid]; sumYW += PRED[1][decltype(gc)::value][tid]; });
+        const double yN = 1.0 - sumY;
+        sumYW += yN * pjs::SP[LAST][0];
+        Wbar = 1.0 / sumYW;
+        rho = p * Wbar / (RU_ * T);
+        invrho = 1.0 / rho;
+        mconc = p / (RU_ * T);
+        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            constexpr int k0 = group_first_species(g), k1 = group_first_species(g + 1);
+            static_range<k0, k1>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                CL[k][tid] = rho * (k < LAST ? Y[k < LAST ? k - k0 : 0] : yN) * pjs::SP[k][0];
+            });
+        });
+#else
         State L;
         load_state(A, s, L);        // all loads, scheduling barrier, sums (every group: each needs T, rho, ...)
         kc_land<NQ, NTHR>(LTK, NKC, lt);
@@ -1036,9 +1095,11 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         T = L.T; rho = L.rho; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
         if (G_ == 1 || grp == 0)
             static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
+#endif
     }
     __syncthreads();
 #endif
+    if constexpr (ECL_PRO) ecl_fetch();
     if constexpr (ECL_PRO && EJ_LDS && !(PJQ_JV && EJ_LDS)) {
         group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
             constexpr int g = decltype(gc)::value;
@@ -1213,8 +1274,49 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         });
     };
 
+    // One row of a block as store instructions: `piece` h of row r is the column pair (2 h, 2 h + 1) of the pair-store builds
+    // (the odd last column alone), column h otherwise; WPr / WQNr / JTr: the row's constants, Sb: the block's sparse sums
+    constexpr int PIECES = PJQ_PAIR ? (NSP + 1) / 2 : NSP;
+    auto row_piece = [&](auto bc, auto rc, auto hc, const double WPr, const double WQNr, const double JTr, const double* Sb) PJR_INL {
+        constexpr int b = decltype(bc)::value, r = decltype(rc)::value, h = decltype(hc)::value;
+        constexpr int k = pjs::BLK_ROWS[pjs::BLK_ROW_PTR[b][0] + r][0];
+        // Jacobian column c of the row: c = 0 is the d/dT column, c = j + 1 belongs to species j
+        auto cv = [&](auto cc) PJR_INL {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c == 0) {
+                return pjs::SP[k][1] * JTr;                  // create_jacobian.py:2786-2818
+            } else {
+                constexpr int j = c - 1;
+                constexpr int si = pjs::SLOC[k][j];
+                if constexpr (si >= 0) return INVW(j) * (WPr + pjs::SP[k][1] * Sb[si]) - WQNr;
+                else return INVW(j) * WPr - WQNr;
+            }
+        };
+        if constexpr (k < LAST) {
+#if PJQ_PAIR
+            constexpr int c = 2 * h;
+            if constexpr (c + 1 < NSP) {
+                double v0 = cv(std::integral_constant<int, c>{});
+                double v1 = cv(std::integral_constant<int, c + 1>{});
+                swap_halves(v0, v1);
+                d2s out;
+                out.x = v0;
+                out.y = v1;
+                PJQ_STORE2((d2s*)((char*)(Jw + (long)(k + 1 + NSP * c) * A.j_si) + jvo2), out);
+            } else {
+                PJQ_STORE(&J_(k + 1 + NSP * c), cv(std::integral_constant<int, c>{}));
+            }
+#elif !PJQ_JV
+            PJQ_STORE(&J_(k + 1 + NSP * h), cv(hc));
+#endif
+        }
+    };
     auto run_blocks = [&](auto lo_c, auto hi_c) PJR_INL {
     constexpr int LO_ = decltype(lo_c)::value, HI_ = decltype(hi_c)::value;
+    // PJQ_DEFER: what the stores of a block need, kept until the next block has issued them
+    constexpr bool DEFER = PJQ_DEFER && !PJQ_JV;
+    double pWP[DEFER ? pjs::BLK_MAXROWS : 1], pWQN[DEFER ? pjs::BLK_MAXROWS : 1], pJT[DEFER ? pjs::BLK_MAXROWS : 1];
+    double pS[DEFER ? pjs::BLK_MAXNNZ : 1];
     static_range<LO_, HI_>([&](auto bc) PJR_INL {
         constexpr int b = decltype(bc)::value;
         constexpr int r0 = pjs::BLK_ROW_PTR[b][0], nrows = pjs::BLK_ROW_PTR[b + 1][0] - r0;
@@ -1285,6 +1387,17 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         };
         if constexpr (nv > 0) fetch_c(std::integral_constant<int, 0>{});
 #endif
+        if constexpr (DEFER && b > LO_ && nv - npre == 0) {
+            // (a block without Arrhenius visits: the previous block's rows go out here)
+            constexpr int pb = b > LO_ ? b - 1 : b;      // (b - 1; the first block has none)
+            constexpr int pnrows = pjs::BLK_ROW_PTR[pb + 1][0] - pjs::BLK_ROW_PTR[pb][0];
+            static_for<pnrows>([&](auto rc) PJR_INL {
+                static_for<PIECES>([&](auto hc) PJR_INL {
+                    row_piece(std::integral_constant<int, pb>{}, rc, hc, pWP[decltype(rc)::value], pWQN[decltype(rc)::value],
+                              pJT[decltype(rc)::value], pS);
+                });
+            });
+        }
         static_for<nv>([&](auto vc) PJR_INL {
             constexpr int v = decltype(vc)::value;
             constexpr int i = pjs::BLK_RX[v0 + v][0];
@@ -1557,6 +1670,20 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     if constexpr (k == LAST && i == pjs::LASTQ) JTQ = nu * theta;
                 }
             });
+            if constexpr (DEFER && b > LO_ && v < nv - npre) {
+                // the previous block's rows: an even share of their store instructions behind every Arrhenius visit
+                // (the hand-over visits at the block's end see no new store in front of their ring loads)
+                constexpr int pb = b > LO_ ? b - 1 : b;      // (b - 1; the first block has none)
+                constexpr int pnrows = pjs::BLK_ROW_PTR[pb + 1][0] - pjs::BLK_ROW_PTR[pb][0];
+                constexpr int NP_ = pnrows * PIECES, na = nv - npre;
+                constexpr int e0 = (int)((long)NP_ * v / na), e1 = (int)((long)NP_ * (v + 1) / na);
+                static_range<e0, e1>([&](auto ec) PJR_INL {
+                    constexpr int e = decltype(ec)::value, r = e / PIECES, h = e % PIECES;
+                    row_piece(std::integral_constant<int, pb>{}, std::integral_constant<int, r>{}, std::integral_constant<int, h>{},
+                              pWP[r], pWQN[r], pJT[r], pS);
+                });
+                PJQ_SCHED_BARRIER();
+            }
 #if PJQ_SB_EVERY
             if constexpr ((v + 1) % PJQ_SB_EVERY == 0) PJQ_SCHED_BARRIER();
 #endif
@@ -1623,32 +1750,24 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 double wk = 0.0;
                 static_for<NSP>([&](auto cc) PJR_INL { wk += col_val(rc, cc) * vv(cc); });
                 wp[(k + 1) * A.w_si] = wk;
-#elif PJQ_PAIR
-                // two columns per store instruction: the halves of the wavefront exchange one value each,
-                // the lower half then writes two states of column c, the upper half the same two states of
-                // column c + 1 (16 bytes per lane: half the store instructions in flight for the same bytes)
-                static_for<NSP / 2>([&](auto hc) PJR_INL {
-                    constexpr int c = 2 * decltype(hc)::value;
-                    double v0 = col_val(rc, std::integral_constant<int, c>{});
-                    double v1 = col_val(rc, std::integral_constant<int, c + 1>{});
-                    swap_halves(v0, v1);
-                    d2s out;
-                    out.x = v0;
-                    out.y = v1;
-                    PJQ_STORE2((d2s*)((char*)(Jw + (long)(k + 1 + NSP * c) * A.j_si) + jvo2), out);
-                });
-                if constexpr (NSP % 2 != 0)
-                    PJQ_STORE(&J_(k + 1 + NSP * (NSP - 1)), col_val(rc, std::integral_constant<int, NSP - 1>{}));
 #else
-                static_for<NSP>([&](auto cc) PJR_INL {
-                    PJQ_STORE(&J_(k + 1 + NSP * decltype(cc)::value), col_val(rc, cc));
-                });
+                if constexpr (DEFER && b + 1 < HI_) {
+                    // (stored during the next block's visits)
+                    pWP[r] = WP[r]; pWQN[r] = WQN[r]; pJT[r] = JT[r];
+                } else {
+                    // pair stores: two columns per store instruction -- the halves of the wavefront exchange one value each,
+                    // the lower half then writes two states of column c, the upper half the same two states of column c + 1
+                    // (16 bytes per lane: half the store instructions in flight for the same bytes)
+                    static_for<PIECES>([&](auto hc) PJR_INL { row_piece(bc, rc, hc, WP[r], WQN[r], JT[r], S); });
+                }
 #endif
             } else {
                 // the last species has no row of its own; its terms still enter the energy row
                 static_for<LAST>([&](auto jc) PJR_INL { (void)col_val(rc, std::integral_constant<int, decltype(jc)::value + 1>{}); });
             }
         });
+        if constexpr (DEFER && b + 1 < HI_)
+            static_for<pjs::BLK_NNZ[b][0]>([&](auto ec) PJR_INL { pS[decltype(ec)::value] = S[decltype(ec)::value]; });
         // the block's finished columns of the energy row: to the long-lived sums (one lane group), to the LDS
         // array the epilogue reads (one kernel), or to the column's slot of the hand-over array (several kernels)
 #ifndef PJQ_NO_E

@@ -29,6 +29,7 @@ from . import tables as T
 
 LNX_LIMIT = 200.0       # |shifted ln X_k| over the temperature window: three factors multiply before any divides
 T_WINDOW = (200.0, 6000.0)
+PARTIAL_LIMIT = 650.0   # |ln| of any partial product of a reaction's factors (double range: e^+-708)
 
 
 def _basis(Tt):
@@ -108,6 +109,26 @@ def kc_factor_rows(tab, max_nu: int = 4):
     Fw = np.where(Tw[None, :] <= tmid[:, None], shift_lo @ pw.T, shift_hi @ pw.T)
     if not np.isfinite(Fw).all() or np.abs(Fw).max() > LNX_LIMIT:
         return None
+    # ... and of what the kernel actually forms: 1 / K_c,i = (p_atm / R_u)^(-sum nu) * prod X_k^(-nu_ki), multiplied up
+    # factor by factor in the order of the reaction's net species, |nu| times each (pj_rblk.hip) -- no partial product may
+    # leave the double range (overflow: inf * 0 = NaN further on; underflow: digits lost without a trace)
+    I, D = tab.I, tab.D
+    flags = I[I[16 + T.IA_FLAGS]:I[16 + T.IA_FLAGS] + tab.nrxn]
+    ptr = I[I[16 + T.IA_NET_PTR]:I[16 + T.IA_NET_PTR] + tab.nrxn + 1]
+    nsp_ = I[I[16 + T.IA_NET_SP]:I[16 + T.IA_NET_SP] + int(ptr[-1])]
+    nnu = D[I[48 + T.DA_NET_NU]:I[48 + T.DA_NET_NU] + int(ptr[-1])]
+    pref = D[I[48 + T.DA_KCPREF]:I[48 + T.DA_KCPREF] + tab.nrxn]
+    for i in range(tab.nrxn):
+        if not (int(flags[i]) & T.F_REV):
+            continue
+        part = np.full(Tw.shape, -np.log(pref[i]))
+        worst = np.abs(part).max()
+        for q in range(int(ptr[i]), int(ptr[i + 1])):
+            for _ in range(int(abs(nnu[q]))):
+                part = part - np.sign(nnu[q]) * Fw[int(nsp_[q])]
+                worst = max(worst, np.abs(part).max())
+        if worst > PARTIAL_LIMIT:
+            return None
     # the shift must cancel in every reversible reaction (it does by construction; guards the SVD threshold)
     resid = np.abs((lo - shift_lo)[used].T @ N[used]).max() if used.any() else 0.0
     scale_c = np.abs(lo - shift_lo).max() + 1e-300

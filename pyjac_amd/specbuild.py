@@ -23,7 +23,7 @@ SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rblk': ('pj_rblk.hip', 'pj_mat
 # environment overrides that shape a binary (experiments): part of the digest
 ENV = ('PJ_LANE_FLAGS', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE', 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES',
        'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST', 'PJ_RBLK_RATE_GROUPS', 'PJ_RBLK_RATE_DEFINES',
-       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV', 'PJ_RBLK_ECL')
+       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV', 'PJ_RBLK_ECL', 'PJ_RBLK_WIDE')
 
 # reciprocal instead of IEEE division sequences, contraction, no -0 special-casing; NO reassociation (it keeps
 # every product of an accumulation chain live: +40 AGPRs, -5 %); measured on MI355X against -ffast-math and
@@ -134,33 +134,73 @@ def build_lane(L, handle, so: str):
     _finish(tmp, hdr, None, so)
 
 
-def rblk_geometry(nsp: int, kcf_ok: bool):
-    """(block, halves, kcf, single) of the row kernels of a mechanism.
-    * Per-species equilibrium-constant factors available and the columns of 64 states fit the LDS five times over
-      (concentration + two 16-byte factor columns: 40 NSP bytes per state, NSP <= 62): 64 states per workgroup, four
-      lane groups on them, ONE row kernel (PJQ_KCF, PJQ_SINGLE).
+LDS_BYTES = 160 * 1024
+
+
+def rblk_lds_bytes(nsp: int, block: int, halves: int, kcf: int, single: int, nkc_rows: int = 0, jv: bool = False,
+                   ecols: bool = False, coop: bool = None, ecl: bool = True, last: bool = True) -> int:
+    """LDS bytes of a k_rblk workgroup: the mirror of SM_DOUBLES in csrc/pj_rblk.hip (concentration columns | factor
+    columns or the kernel's K_c polynomial rows | the finished column sums of the energy row (one kernel, several lane
+    groups, room permitting) or the cooperative prologue's partial sums | the epilogue's exchange area)."""
+    g = halves
+    if coop is None:
+        coop = bool(kcf) and g > 1
+    cl = nsp * block
+    xt = 4 * nsp * block if kcf else 0
+    ltk = 0 if kcf else 16 * nkc_rows
+    off_ej = cl + xt + ltk
+    ej_lds = bool(single) and g > 1 and not ecols
+    ej = ((nsp if jv else nsp - 1) * block) if ej_lds else 0
+    pred = ((4 if kcf else 2) * g * block) if (coop and g > 1) else 0
+    main = off_ej + max(ej, pred)
+    nex = 0 if ecl else nsp - 1
+    epi_size = (nex * (g - 1) * block + 6 * g * block) if (g > 1 and last) else 0
+    epi = (0 if epi_size <= off_ej else main) + epi_size if epi_size else 0
+    return 8 * max(main, epi)
+
+
+def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0):
+    """(block, halves, kcf, single, ecols, coop) of the row kernels of a mechanism; nkc: its K_c groups (polynomial row
+    pairs, 128 bytes each).
+    * Per-species equilibrium-constant factors available and ONE kernel's columns of 64 states fit the LDS (concentration
+      + two 16-byte factor columns + the finished column sums / the vector of the w = J v build: 48 NSP bytes per state,
+      NSP <= 53): 64 states per workgroup, four lane groups on them, ONE row kernel (PJQ_KCF, PJQ_SINGLE).
     * Otherwise the concentration columns (8 NSP bytes per lane) + the K_c rows of the kernel's reactions must fit:
-      256 states, or 128 states and two lane groups (57..120 species), several row kernels."""
+      256 states (up to 56 species), or 128 states and two lane groups, several row kernels -- or (PJ_RBLK_WIDE=1) 64
+      states, four lane groups with a cooperative prologue, and ONE row kernel if every K_c row of the mechanism fits
+      next to the columns (the column sums of the energy row then travel through the hand-over array: PJQ_ECOLS)."""
     env = os.environ.get
-    kcf = int(env('PJ_RBLK_KCF', 1 if (kcf_ok and 40 * nsp * 64 + 8192 <= 160 * 1024) else 0))
+    fits = lambda **kw: rblk_lds_bytes(nsp, **kw) <= LDS_BYTES
+    kcf_default = int(kcf_ok and fits(block=64, halves=4, kcf=1, single=1, jv=True))
+    kcf = int(env('PJ_RBLK_KCF', kcf_default))
     if kcf and not kcf_ok:
         raise ValueError('PJ_RBLK_KCF=1: the mechanism has no per-species factor rows (pyjac_amd/kcfactors.py)')
+    ecols, coop = 0, 0
     if kcf:
         block = int(env('PJ_RBLK_BLOCK', 64))
         halves = int(env('PJ_RBLK_HALVES', 4))
         single = int(env('PJ_RBLK_SINGLE', 1))
+        coop = int(halves > 1)
     else:
-        block = 256 if nsp * 256 * 8 <= 112 * 1024 else 128 if nsp * 128 * 8 <= 120 * 1024 else 64
+        wide = int(env('PJ_RBLK_WIDE', 0)) and nsp * 256 * 8 > 112 * 1024
+        if wide:
+            block, halves, coop = 64, 4, 1
+            single = int(fits(block=64, halves=4, kcf=0, single=1, nkc_rows=nkc, ecols=True, coop=True))
+            ecols = single
+        else:
+            block = 256 if nsp * 256 * 8 <= 112 * 1024 else 128 if nsp * 128 * 8 <= 120 * 1024 else 64
+            single = 0
+            # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on the
+            # same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
+            halves = 2 if block == 128 else 1
         block = int(env('PJ_RBLK_BLOCK', block))
-        # 128 states per workgroup leave two SIMDs of a CU idle: the workgroup is then two groups of lanes on the
-        # same states (shared concentration columns), each running its own row blocks (pj_rblk.hip)
-        halves = int(env('PJ_RBLK_HALVES', 2 if block == 128 else 1))
-        single = int(env('PJ_RBLK_SINGLE', 0))
-    return block, halves, kcf, single
+        halves = int(env('PJ_RBLK_HALVES', halves))
+        single = int(env('PJ_RBLK_SINGLE', single))
+    return block, halves, kcf, single, ecols, coop
 
 
 def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=(),
-               kcf_rows=None):
+               kcf_rows=None, nkc: int = 0):
     """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the falloff / PLOG
     reactions) and the one-pass rate-output kernels (k_rate: pj_spec_rates).  One translation unit per kernel,
     compiled in parallel; which row blocks / reactions a kernel takes is planned by the C side
@@ -175,7 +215,7 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     work = so[:-3] + '.%d.obj' % pid
     os.makedirs(work, exist_ok=True)
     fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', RBLK_FUSE))
-    block, halves, kcf, single = rblk_geometry(nsp, kcf_rows is not None)
+    block, halves, kcf, single, ecols, coop = rblk_geometry(nsp, kcf_rows is not None, nkc)
     if kcf_rows is not None:
         rows = np.ascontiguousarray(kcf_rows, dtype=np.float64)
         check(L.pj_mech_set_kc_factors(handle, rows.ctypes.data_as(ct.POINTER(ct.c_double)), rows.size))
@@ -201,7 +241,8 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     # pre-pass (PJQ_ECL), so the row kernels carry no long-lived sums
     ecl = int(os.environ.get('PJ_RBLK_ECL', 1 if halves > 1 else 0))
     common = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr, '-I', CSRC,
-              '-DPJQ_SUMSETS=%d' % (0 if nker == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1), '-DPJQ_ECL=%d' % ecl]
+              '-DPJQ_SUMSETS=%d' % (0 if nker == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1), '-DPJQ_ECL=%d' % ecl] + \
+        (['-DPJQ_ECOLS=1'] if (ecols and nker == 1) else [])
     flags = os.environ.get('PJ_RBLK_FLAGS', RBLK_FLAGS).split()
     src = os.path.join(CSRC, 'pj_rblk.hip')
     # (the 111-species kernels are short of registers: without the one-visit look-ahead of the K_c rows and
@@ -209,7 +250,8 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     # (the one-kernel builds must not keep anything in scratch memory, see below: three hand-over visits in flight
     # instead of four leave the register allocator the dozen registers it is short of at budget 48 -- GRI-shaped:
     # 12 bytes of scratch per lane at four, none at three or two)
-    rblk = common + flags + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf] + \
+    rblk = common + flags + ['-DPJQ_BLOCK=%d' % block, '-DPJQ_C_LDS=%d' % c_lds, '-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf,
+                             '-DPJQ_COOP=%d' % coop] + \
         (['-DPJQ_CONC_AHEAD=0', '-DPJQ_KC_AHEAD=0'] if (halves == 2 and not kcf) else []) + \
         (['-DPJQ_DEPTH=3'] if kcf and not any('PJQ_DEPTH' in d for d in list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split()) else []) + \
         list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [src]

@@ -280,3 +280,46 @@ def test_one_kernel_library_keeps_nothing_in_scratch_memory():
     name, spills, scratch, lds = res[0]
     assert scratch == 0, 'pair-store row kernel: %d bytes of scratch per lane (%d spilled registers)' % (scratch, spills)
     assert lds <= 160 * 1024
+
+
+def test_rblk_geometry_fits_the_lds(tmp_path):
+    """The geometry specbuild picks must fit the 160 KB of LDS in EVERY build of the library (round 4 admitted the
+    one-kernel factor-column geometry up to 62 species; its w = J v build needs 48 NSP bytes per state: 53).  The Python
+    model (specbuild.rblk_lds_bytes) mirrors SM_DOUBLES of csrc/pj_rblk.hip -- pinned here by compiling one row kernel of
+    a small 56-species mechanism for gfx950 with the geometry it picks (the kernel static_asserts its LDS layout)."""
+    import subprocess
+    import pyjac_amd
+    from pyjac_amd import specbuild, synth_mech, _lib
+    from pyjac_amd.kcfactors import kc_factor_rows
+    for nsp in range(8, 141):
+        for kcf_ok in (False, True):
+            block, halves, kcf, single, ecols, coop = specbuild.rblk_geometry(nsp, kcf_ok, nkc=0)
+            assert kcf == 0 or kcf_ok
+            for jv in (False, True):
+                # (K_c rows: the planner cuts the kernels where they stop fitting -- checked with none here)
+                assert specbuild.rblk_lds_bytes(nsp, block, halves, kcf, single, 0, jv=jv, ecols=bool(ecols), coop=bool(coop)) \
+                    <= specbuild.LDS_BYTES, (nsp, kcf_ok, jv)
+    assert specbuild.rblk_geometry(53, True)[2:4] == (1, 1) and specbuild.rblk_geometry(54, True)[2] == 0
+    if not os.path.exists(specbuild._hipcc()):
+        pytest.skip('no hipcc')
+    inp = str(tmp_path / 'm56.inp')
+    with open(inp, 'w') as f:
+        f.write(synth_mech.generate(56, 60, 6, 8, 0, 4, 1, seed=5, title='56-species test mechanism'))
+    ev = pyjac_amd.Evaluator(inp, specialize='off')
+    rows = kc_factor_rows(ev.tables)
+    L = _lib.lib()
+    import ctypes as ct
+    if rows is not None:
+        _lib.check(L.pj_mech_set_kc_factors(ev._h, rows.ctypes.data_as(ct.POINTER(ct.c_double)), rows.size))
+    block, halves, kcf, single, ecols, coop = specbuild.rblk_geometry(ev.nsp, rows is not None, int(ev.tables.I[10]))
+    hdr = str(tmp_path / 'm56.h')
+    counts = (ct.c_int * 5)()
+    _lib.check(L.pj_mech_emit_rblk_spec(ev._h, hdr.encode(), 56, 13, block, halves, single, 256, 0, 0, 0.0, 0.0, counts))
+    nker = counts[0]
+    for jv in (0, 1):
+        subprocess.check_call([specbuild._hipcc(), '--offload-arch=gfx950', '-O1', '-std=c++17', '-fPIC', '-c', '-fsyntax-only',
+                               '-DPJS_HEADER="%s"' % hdr, '-I', specbuild.CSRC, '-DPJQ_SUMSETS=%d' % (0 if nker == 1 else 2 * halves),
+                               '-DPJQ_SINGLE=%d' % int(nker == 1), '-DPJQ_ECL=%d' % int(halves > 1), '-DPJQ_BLOCK=%d' % block,
+                               '-DPJQ_C_LDS=0', '-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf, '-DPJQ_COOP=%d' % coop,
+                               '-DPJQ_PART=2', '-DPJQ_ID=%d' % (nker - 1), '-DPJQ_PAIR=0', '-DPJQ_JV=%d' % jv,
+                               os.path.join(specbuild.CSRC, 'pj_rblk.hip')])

@@ -86,6 +86,16 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6, halves=2)),
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, ecl=0)),
+    # ONE row kernel with polynomial K_c rows (the 111-species geometry: no LDS room for the finished column sums, which
+    # travel through the hand-over array -- PJQ_ECOLS), four lane groups with a cooperative prologue (PJQ_COOP)
+    ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
+    ('synth_srichb', 16, dict(rates_per_part=5, halves=2, single=1, c_lds=1, pre_halves=2,
+                              defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1', '-DPJQ_DEFER=1'))),
+    ('synth_mid24', 40, dict(blocks_per_part=6, rates_per_part=40, halves=4, defines=('-DPJQ_COOP=1',))),
+    # PJQ_DEFER: the rows of a block are stored during the visits of the next one
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, defines=('-DPJQ_DEFER=1',))),
+    ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1, defines=('-DPJQ_DEFER=1',))),
+    ('synth_srichb', 16, dict(blocks_per_part=3, rates_per_part=5, defines=('-DPJQ_DEFER=1',))),
     # equilibrium constants from per-species factor columns (PJQ_KCF: cooperative prologue, products instead of a
     # polynomial + exp per visit): one group and several kernels; four groups and ONE kernel (the 53-species shape)
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, kcf=1)),
@@ -171,6 +181,8 @@ def test_rblk_kernels_vs_reference_golden(tmp_path_factory, golden):
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1)),
     # two lane groups over several kernels: v in registers, column sums through the hand-over array
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
+    # one kernel, four lane groups, polynomial K_c rows, column sums through the hand-over array
+    ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
 ])
 def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
     """N2 for the row-block family: w = J v per state with the Jacobian consumed in registers
