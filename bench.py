@@ -150,7 +150,7 @@ def kernel_label(ev, inject=None):
         # PJ_BENCH_EVALUATOR: not the HIP path at all (tests/test_bench_gloo.py); the line must say so
         return 'INJECTED evaluator %s (PJ_BENCH_EVALUATOR): not a measurement of the HIP path' % inject
     return {'pj_lane': 'pj_lane (register-resident state-per-lane kernel)',
-            'pj_rblk': 'pj_rblk (state-per-lane row-block kernels that rebuild their rates + falloff/PLOG pre-pass; up to 62 '
+            'pj_rblk': 'pj_rblk (state-per-lane row-block kernels that rebuild their rates + falloff/PLOG pre-pass; up to 53 '
                        'species: one row kernel, four lane groups on 64 states, K_c from per-species factor columns in LDS)',
             }.get(
                 ev.spec_kernel if ev.has_spec else '', 'k_tab / k_eval (table-driven: NO mechanism-specific library attached)')
@@ -222,9 +222,14 @@ def main():
     if not inject:
         assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # a process group whenever the launcher set one up (torch.distributed.run exports WORLD_SIZE also for ONE process):
+    # the N = 1 leg of a scaling run then goes through RCCL, the chunked validation gather and the recomputation too
+    # (peer = this rank itself)
+    grouped = world > 1 or ('WORLD_SIZE' in os.environ and 'MASTER_PORT' in os.environ)
+    if grouped:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = {} if inject else {'device_id': torch.device('cuda', local_rank)}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     assert world == a.gpus, 'launch with --nproc-per-node equal to --gpus'
 
     wl = a.workload
@@ -238,7 +243,7 @@ def main():
         mod, fn = inject.split(':')
         ev = getattr(importlib.import_module(mod), fn)(w['mech'])
     else:
-        ev = open_mechanism(pyjac_amd, w['mech'], dist if world > 1 else None, local_rank, build_rblk=True)
+        ev = open_mechanism(pyjac_amd, w['mech'], dist if grouped else None, local_rank, build_rblk=True)
     n = a.states or w['n']
     # every rank owns n states (weak scaling); global batch = world * n
     pres, y = make_states(w, ev.nsp, n, seed=20240901 + rank)
@@ -262,18 +267,18 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert float(t.item()) >= elapsed
@@ -284,7 +289,7 @@ def main():
 
     finite = bool(torch.isfinite(jac[:, ::997] if L == pyjac_amd.LAYOUT_SOA else jac[::997]).all())
     validation = None
-    if world > 1:
+    if grouped:
         # The single RCCL all-gather of the path (outside the timed region): reassemble a validation batch of the
         # first nv states of every rank, a chunk at a time through one receive buffer (dist.iter_gathered).
         #  * every chunk: what arrived from rank r is finite, this rank's own piece came back bit-identical, and
@@ -487,7 +492,7 @@ def main():
             except Exception as ex:   # the baseline is reported, never required
                 line['cpu_baseline'] = {'error': repr(ex)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -69,3 +69,32 @@ def test_dist_collectives_through_rccl_on_a_real_shard(name, n, rccl_world1):
     dist.barrier()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert float(t) == 1.25
+
+
+def test_bench_under_torchrun_at_world_size_one():
+    """bench.py launched the way the driver launches the legs of a scaling run (`python -m torch.distributed.run
+    --nproc-per-node N ... bench.py --gpus N`), with N = 1 on this box's one GPU: the process group is RCCL, the barriers,
+    the MAX-reduce of the elapsed time, the chunked validation all-gather, the checksum gather and the recomputation of the
+    peer's (= its own) states run on the device, on Jacobians from the HIP path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', PJ_VALIDATE_CHUNK='1000')
+    env.pop('PJ_BENCH_EVALUATOR', None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+                          '--gpus', '1', '--steps', '2', '--warmup', '1', '--states', '4096', '--no-cpu-baseline', '--no-also'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    v = j['validation_allgather']
+    assert v['ok'] is True and v['states_per_rank'] == 4096 and v['remote_rank_checked'] == 0
+    assert v['remote_max_err_over_tolerance'] <= 1.0 and v['gathered_bytes'] == 53 * 53 * 4096 * 8
+    assert j['n_gpus'] == 1 and j['evaluator'].startswith('native') and j['config']['kernel'].startswith('pj_rblk')
