@@ -42,8 +42,8 @@ def build_ref(mech_path: str, name: str, last_spec: str = None, force: bool = Fa
     """Returns the path of the default-flags library; `variants`: keys of VARIANTS to build from the same
     generated sources (one generator run)."""
     path = lambda v: os.path.join(HERE, '_ref', 'libpyjac_ref_%s%s.so' % (name, v))
-    todo = [v for v in variants if force or not os.path.exists(path(v)) or
-            os.path.getmtime(path(v)) < os.path.getmtime(mech_path)]
+    newest_input = max(os.path.getmtime(p) for p in (mech_path, therm_path) if p)
+    todo = [v for v in variants if force or not os.path.exists(path(v)) or os.path.getmtime(path(v)) < newest_input]
     if not todo:
         return path('')
     if not os.path.isdir(os.path.join(REF, 'pyjac')):

@@ -40,6 +40,7 @@ def _check_vs_self_noise(label, name, jac, pres, y_aos):
     from oracle.oracle import Reference
     from test_conditioning import self_noise_report
     if not (Reference.available(name) and Reference.available(name + '_fma')):
+        print('%s: variant libraries of the reference (oracle/_ref/*_fma) absent -- self-noise check SKIPPED' % label)
         return None
     y_aos = np.ascontiguousarray(y_aos)
     ref, ref_fma = Reference(name).batch_jacob(pres, y_aos), Reference(name + '_fma').batch_jacob(pres, y_aos)
