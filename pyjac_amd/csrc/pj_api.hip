@@ -460,6 +460,9 @@ int launch_tab(pj_mech* m, const Batch& B, hipStream_t st)
     std::lock_guard<std::mutex> lock(m->tab_mutex);
     if (!m->tab_event) HIPCHK(hipEventCreateWithFlags(&m->tab_event, hipEventDisableTiming));
     else if (m->tab_last_stream != (void*)st) HIPCHK(hipStreamWaitEvent(st, m->tab_event, 0));
+    // (from here to the event record below: an error return leaves the scratch's last user unknown -- the next call,
+    // on whichever stream, waits for the event again)
+    m->tab_last_stream = nullptr;
     if (m->tab_scr_ld < B.n) {
         if (m->tab_scr) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(m->tab_scr); m->tab_scr = nullptr; m->tab_scr_ld = 0; }
         hipError_t e = hipMalloc((void**)&m->tab_scr, sizeof(double) * (size_t)(nsp + 1) * (size_t)B.n);
@@ -647,6 +650,7 @@ void pj_mech_destroy(pj_mech* m)
         m->net_sp.release(); m->sp_ptr.release(); m->sp_rxn.release(); m->gen_sp.release(); m->gen_nu.release();
         m->tab_I.release(); m->tab_D.release();
         if (m->tab_scr) (void)hipFree(m->tab_scr);
+        if (m->tab_event) (void)hipEventDestroy(m->tab_event);
         if (m->d_bad) (void)hipFree(m->d_bad);
         m->ws.release(); m->ws1.release();
     }

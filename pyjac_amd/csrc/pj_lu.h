@@ -135,7 +135,9 @@ enum { LU_FACTOR = 1, LU_SOLVE = 2, LU_PREFACTORED = 4 };
 struct LuLay { long a_si, a_ss, v_si, v_ss; };
 
 // NP: NSP rounded up to a multiple of 8, or 54 for 53 / 54 rows (rows / columns beyond NSP are the identity's: they are never pivots of a
-// real column and contribute zeros).  mode: LU_FACTOR (A -> lu, perm), LU_FACTOR | LU_SOLVE (A, b -> x, and lu / perm
+// real column and contribute zeros -- for FINITE input: the padding is formed as 0 * (a clamped copy of the last row /
+// column) + delta_ij, so an Inf / NaN there puts NaN into the padding as well; a block with non-finite entries gives
+// non-finite factors either way, only which of them are NaN differs from a select-based padding).  mode: LU_FACTOR (A -> lu, perm), LU_FACTOR | LU_SOLVE (A, b -> x, and lu / perm
 // if given), LU_PREFACTORED | LU_SOLVE (lu, perm, b -> x).  gamma != 0: the matrix is I - gamma A (the Newton
 // matrix of an implicit step).
 template <int NP>
@@ -610,6 +612,203 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
     }
 }
 
+// ---- blocks of 65 .. 128 rows: FOUR wavefronts per block, the matrix in registers ------------------------------------
+// k_lu_lds keeps the block in LDS and pays ~4 barriers and an LDS round trip per entry and column: 168 ms per 2e5
+// 111 x 111 blocks, 0.03 of the HBM roofline, 27x the time of the Jacobians it consumes.  Here the
+// workgroup's four wavefronts are (row half rh) x (column parity ch): lane l of wavefront (rh, ch) holds row
+// rh * NC + l, and of it the columns 2 c + ch, c < NC -- NC doubles per lane (112 registers for 111 x 111), compile-time
+// indices, columns dealt cyclically so that all four wavefronts have work until the last step.  Elimination step
+// k = 2 c + h (TWO barriers):
+//   1. the two wavefronts that hold column k (ch == h) reduce their open rows' |a_k| to a candidate each (unsigned keys,
+//      DPP maxima, ties to the lowest row, as k_lu) and leave value + lane in LDS;                          -- barrier --
+//   2. every wavefront picks the winner (the larger magnitude, the lower row half on a tie: dgetf2's choice unless an
+//      earlier step displaced a tied row, as k_lu); the winner row's lane in either column half parks its remaining
+//      entries in LDS (one lane, 16-byte writes), the column owners scale their column (multipliers: kept as L, and
+//      left in LDS for the other column half);                                                              -- barrier --
+//   3. a[c'] -= l * u[c'] for the columns right of k: the pivot row arrives as uniform 16-byte LDS reads.
+// Rows are never exchanged (implicit pivoting: a row remembers its position), forward substitution rides along, the
+// back substitution runs on an LDS copy of the right-hand side (two barriers per column as well).  Same (lu, perm)
+// convention as k_lu / k_lu_lds; stored factors are solved by k_lu_lds (LU_PREFACTORED).
+template <int NC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_lu4(const int nsp, const long n, const double* A, const LuLay Y, const double gamma, double* lu, int* __restrict__ perm,
+      const double* __restrict__ b, double* __restrict__ x, const int mode)
+{
+    static_assert(NC % 2 == 0 && NC <= 64, "k_lu4: up to 128 rows, an even number of columns per wavefront");
+    __shared__ __attribute__((aligned(16))) double prow[2][NC];     // the pivot row, per column parity
+    __shared__ double lcol[128];                                     // the multipliers of the step, per row
+    __shared__ double candv[2];
+    __shared__ int candl[2];
+    __shared__ double ys[2 * NC + 2];                                // right-hand side by position (back substitution)
+    __shared__ double yk_s;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane0 = tid & 63;
+    const int rh = __builtin_amdgcn_readfirstlane(wave >> 1), ch = __builtin_amdgcn_readfirstlane(wave & 1);
+    const long ne = (long)nsp * nsp;
+    const bool solve = (mode & LU_SOLVE) != 0;
+    const int nsp0 = nsp;
+    // workgroups b, b + 8, ... b + 120 sit on one XCD (round-robin dispatch) and take 16 consecutive blocks: in the
+    // batch layout a 128-byte line of 16 states is fetched into one L2 instead of eight (as k_lu_lds)
+    for (long t = blockIdx.x; t < ((n + 127) / 128) * 128; t += gridDim.x) {
+        const long s = (t / 128) * 128 + 16 * (t % 8) + (t % 128) / 8;
+        if (s >= n) continue;                            // (uniform in the workgroup)
+        int nsp = nsp0, lane = lane0;
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        const int row = rh * NC + lane;
+        const bool act = lane < NC && row < nsp;
+        const int row_c = act ? row : nsp - 1;
+        double a[NC];
+        {
+            const double* As = A + s * Y.a_ss;
+            // all loads first (clamped addresses instead of predicates), then identity padding / I - gamma A branch-free
+            lu_for<0, NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const int g = 2 * c + ch;
+                a[c] = As[(row_c + (long)nsp * (g < nsp ? g : nsp - 1)) * Y.a_si];
+            });
+            const bool newton = gamma != 0.0;
+            const double sc = newton ? -gamma : 1.0, sh = newton ? 1.0 : 0.0;
+            lu_for<0, NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const int g = 2 * c + ch;
+                const double id = (g == row && lane < NC) ? 1.0 : 0.0;
+                a[c] = (act && g < nsp) ? __builtin_fma(sc, a[c], sh * id) : id;
+            });
+        }
+        int pos = -1;
+        double bb = 0.0;
+        if (solve && ch == 0) bb = act ? b[row * Y.v_si + s * Y.v_ss] : 0.0;
+        unsigned long long openmask = 0;
+        {
+            const int nrow = nsp - rh * NC;                  // open rows of this row half: lanes 0 .. nrow - 1
+            openmask = nrow >= 64 ? ~0ull : nrow > 0 ? (1ull << (nrow < NC ? nrow : NC)) - 1ull : 0ull;
+        }
+        lu_for<0, NC>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            lu_for<0, 2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value, k = 2 * c + h;
+                if (k < nsp) {                                   // (uniform)
+                    // ---- 1. candidates of the two wavefronts that hold column k
+                    if (ch == h) {
+                        const bool open = __builtin_amdgcn_inverse_ballot_w64(openmask);
+                        const unsigned long long ub = (unsigned long long)__double_as_longlong(a[c]);
+                        const bool num = a[c] == a[c];
+                        const unsigned key = (open & num) ? (unsigned)(ub >> 32) & 0x7fffffffu : 0u;   // a NaN never beats a number
+                        unsigned kmax = key;
+                        kmax = lu_dpp_umax<0x111, 0xf>(kmax);
+                        kmax = lu_dpp_umax<0x112, 0xf>(kmax);
+                        kmax = lu_dpp_umax<0x114, 0xf>(kmax);
+                        kmax = lu_dpp_umax<0x118, 0xf>(kmax);
+                        kmax = lu_dpp_umax<0x142, 0xa>(kmax);
+                        kmax = lu_dpp_umax<0x143, 0xc>(kmax);
+                        const unsigned mx = (unsigned)__builtin_amdgcn_readlane((int)kmax, 63);
+                        unsigned long long hit = __builtin_amdgcn_ballot_w64(key == mx) & openmask;
+                        if (__builtin_popcountll(hit) > 1) {        // (uniform, rare): the lower 32 bits of the tying rows
+                            const bool in = __builtin_amdgcn_inverse_ballot_w64(hit);
+                            const unsigned k2 = (in && num) ? (unsigned)ub : 0u;
+                            unsigned m2 = k2;
+                            m2 = lu_dpp_umax<0x111, 0xf>(m2);
+                            m2 = lu_dpp_umax<0x112, 0xf>(m2);
+                            m2 = lu_dpp_umax<0x114, 0xf>(m2);
+                            m2 = lu_dpp_umax<0x118, 0xf>(m2);
+                            m2 = lu_dpp_umax<0x142, 0xa>(m2);
+                            m2 = lu_dpp_umax<0x143, 0xc>(m2);
+                            const unsigned mx2 = (unsigned)__builtin_amdgcn_readlane((int)m2, 63);
+                            hit = __builtin_amdgcn_ballot_w64(in && k2 == mx2);
+                        }
+                        const int lp = hit ? __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit)) : -1;
+                        const double val = lu_readlane(a[c], lp < 0 ? 0 : lp);
+                        if (lane == 0) { candv[rh] = val; candl[rh] = lp; }
+                    }
+                    __syncthreads();
+                    // ---- 2. the winner; its row to LDS, the multipliers of column k
+                    const double v0 = candv[0], v1 = candv[1];
+                    const int l0 = candl[0], l1 = candl[1];
+                    // magnitudes as integers (a NaN counts as 0, as in the keys); the lower row half wins a tie
+                    const unsigned long long m0 = (v0 == v0) ? ((unsigned long long)__double_as_longlong(v0) & 0x7fffffffffffffffull) : 0ull;
+                    const unsigned long long m1 = (v1 == v1) ? ((unsigned long long)__double_as_longlong(v1) & 0x7fffffffffffffffull) : 0ull;
+                    const bool second = l0 < 0 || (l1 >= 0 && m1 > m0);
+                    const int rhp = __builtin_amdgcn_readfirstlane(second ? 1 : 0);
+                    const int lp = __builtin_amdgcn_readfirstlane(second ? l1 : l0);
+                    const double ukk = second ? v1 : v0;
+                    const double inv = lu_rcp(ukk);
+                    const bool mine = rh == rhp;                 // (uniform)
+                    if (mine) {
+                        const bool me = __builtin_amdgcn_inverse_ballot_w64(1ull << (lp & 63));
+                        pos = me ? k : pos;
+                        openmask &= ~(1ull << (lp & 63));
+                        if (me) {
+                            // the pivot row's entries right of column k (this wavefront's share), 16 bytes at a time
+                            constexpr int ST = c + 1, EV = ST + (ST & 1);            // first pair-aligned column
+                            if (ch > h) prow[ch][c] = a[c];                          // (column 2 c + 1 at step 2 c)
+                            if constexpr ((ST & 1) != 0 && ST < NC) prow[ch][ST] = a[ST];
+                            lu_for<0, (NC - EV) / 2>([&](auto qc) {
+                                constexpr int j = EV + 2 * decltype(qc)::value;
+                                double2 v;
+                                v.x = a[j];
+                                v.y = a[j + 1];
+                                *(double2*)&prow[ch][j] = v;
+                            });
+                            if (solve && ch == 0) yk_s = bb;
+                        }
+                    }
+                    const bool below = __builtin_amdgcn_inverse_ballot_w64(openmask);   // rows not chosen yet
+                    double l = 0.0;
+                    if (ch == h) {
+                        l = below ? a[c] * inv : 0.0;
+                        if (below) a[c] = l;
+                        lcol[rh * 64 + lane] = l;
+                    }
+                    __syncthreads();
+                    // ---- 3. update of the columns right of k
+                    if (ch != h) l = lcol[rh * 64 + lane];
+                    if (ch > h) a[c] = __builtin_fma(-l, prow[ch][c], a[c]);
+                    {
+                        constexpr int ST = c + 1, EV = ST + (ST & 1);
+                        if constexpr ((ST & 1) != 0 && ST < NC) a[ST] = __builtin_fma(-l, prow[ch][ST], a[ST]);
+                        lu_for<0, (NC - EV) / 2>([&](auto qc) {
+                            constexpr int j = EV + 2 * decltype(qc)::value;
+                            const double2 u = *(const double2*)&prow[ch][j];
+                            a[j] = __builtin_fma(-l, u.x, a[j]);
+                            a[j + 1] = __builtin_fma(-l, u.y, a[j + 1]);
+                        });
+                    }
+                    if (solve && ch == 0) bb = __builtin_fma(-l, yk_s, bb);      // forward substitution rides along
+                }
+            });
+        });
+        asm volatile("" : "+s"(nsp), "+v"(lane));
+        if (lu != nullptr && act) {
+            double* Ls = lu + s * ne;
+            lu_for<0, NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const int g = 2 * c + ch;
+                if (g < nsp) Ls[pos + (long)nsp * g] = a[c];
+            });
+            if (perm != nullptr && ch == 0) perm[s * nsp + pos] = row;
+        }
+        if (solve) {
+            // U x = y, last column first, on an LDS copy of y by position: the lane at position k divides, the column's
+            // owners (parity ch == k & 1) update the positions above
+            if (ch == 0 && act) ys[pos] = bb;
+            __syncthreads();
+            lu_for<0, NC>([&](auto cr) {
+                constexpr int c = NC - 1 - decltype(cr)::value;
+                lu_for<0, 2>([&](auto hr) {
+                    constexpr int h = 1 - decltype(hr)::value, k = 2 * c + h;
+                    if (k < nsp) {
+                        if (ch == h && pos == k) ys[k] = lu_div(ys[k], a[c], lu_rcp(a[c]));
+                        __syncthreads();
+                        if (ch == h && pos >= 0 && pos < k) ys[pos] = __builtin_fma(-a[c], ys[k], ys[pos]);
+                        __syncthreads();
+                    }
+                });
+            });
+            if (ch == 0 && act) x[pos * Y.v_si + s * Y.v_ss] = ys[pos];
+        }
+        __syncthreads();
+    }
+}
+
 // ---- blocks of up to 16 rows: four blocks per wavefront ---------------------------------------------------------
 // A 10 x 10 block (the H2-size mechanisms) leaves 54 of k_lu's 64 lanes idle.  k_lu16 gives every block one DPP row
 // of 16 lanes: lane = 16 g + i holds row i of block g, the pivot is a maximum over the row of lanes (four DPP
@@ -796,6 +995,21 @@ inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, do
                      int mode, int cus, hipStream_t st)
 {
     if (nsp < 1 || nsp > LU_MAX_LDS) return -1;
+#ifndef PJ_LU4
+#define PJ_LU4 1            // 65 .. 128 rows: the four-wavefront register-resident kernel (0: k_lu_lds for everything above 64)
+#endif
+    if (PJ_LU4 && nsp > 64 && nsp <= 128 && !(mode & LU_PREFACTORED)) {
+        const long slots = (n + 127) / 128 * 128;
+        const long blocks = slots < (long)cus * 8 ? slots : (long)cus * 8;
+        auto go = [&](auto ncc) {
+            hipLaunchKernelGGL((k_lu4<decltype(ncc)::value>), dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
+        };
+        if (nsp <= 80) go(std::integral_constant<int, 40>{});
+        else if (nsp <= 96) go(std::integral_constant<int, 48>{});
+        else if (nsp <= 112) go(std::integral_constant<int, 56>{});
+        else go(std::integral_constant<int, 64>{});
+        return 0;
+    }
     if (nsp > 64) {
         const int ld = nsp | 1;
         const size_t lds = sizeof(double) * ((size_t)ld * nsp + nsp + 4) + sizeof(int) * (4 + (size_t)nsp);
