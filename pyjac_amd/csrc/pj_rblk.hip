@@ -938,14 +938,25 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     constexpr bool ECL_PRO = PJQ_ECL && EJ_LDS;
     constexpr int NCOLG = (LAST + G_ - 1) / G_ + 1;
     double ECLV[PJQ_ECL ? NCOLG : 1];
+    // (by POSITION p within the group's column range, the slot picked by scalar selects on grp: with a branch per lane
+    // group around the loads the optimiser sinks the branches' common tail, the array index becomes a variable and ECLV
+    // lives in scratch memory -- 128 bytes that cost the one-kernel builds a third of their speed)
+    auto ecl_slot = [&](auto pc) PJR_INL {      // hand-over slot of this group's p-th column, -1: none / not marked
+        constexpr int p = decltype(pc)::value;
+        int sl = -1;
+        static_for<G_>([&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value, j = group_first_col(g) + p;
+            constexpr int v = (j < group_first_col(g + 1) && BCOL.b[j < LAST ? j : 0]) ? ECL0 + ecl_index(j < LAST ? j : 0) : -1;
+            sl = grp == g ? v : sl;
+        });
+        return sl;
+    };
     auto ecl_fetch = [&]() PJR_INL {
         const double* const scr_ = scr_of(A, s);
-        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
-            constexpr int g = decltype(gc)::value;
-            static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (BCOL.b[j]) ECLV[j - group_first_col(g)] = PJQ_LOAD_NT(&scr_[(long)(ECL0 + ecl_index(j)) * PJQ_TILE]);
-            });
+        static_for<(PJQ_ECL ? NCOLG : 0)>([&](auto pc) PJR_INL {
+            const int sl = ecl_slot(pc);
+            const double v = PJQ_LOAD_NT(&scr_[(long)(sl < 0 ? ECL0 : sl) * PJQ_TILE]);
+            ECLV[decltype(pc)::value] = sl < 0 ? 0.0 : v;
         });
     };
 #if PJQ_KCF
@@ -1101,12 +1112,11 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #endif
     if constexpr (ECL_PRO) ecl_fetch();
     if constexpr (ECL_PRO && EJ_LDS && !(PJQ_JV && EJ_LDS)) {
-        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
-            constexpr int g = decltype(gc)::value;
-            static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (BCOL.b[j]) SM[SM_EJ + j * PJQ_BLOCK + tid] = ECLV[j - group_first_col(g)];
-            });
+        int jfirst = 0;
+        static_for<G_>([&](auto gc) PJR_INL { jfirst = grp == decltype(gc)::value ? group_first_col(decltype(gc)::value) : jfirst; });
+        static_for<NCOLG>([&](auto pc) PJR_INL {
+            constexpr int p = decltype(pc)::value;
+            if (ecl_slot(pc) >= 0) SM[SM_EJ + (jfirst + p) * PJQ_BLOCK + tid] = ECLV[p];        // (wavefront-uniform)
         });
         __syncthreads();        // (the block that holds row j ADDS its finished sum: any lane group)
     }
@@ -1193,12 +1203,18 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         else return V[decltype(cc)::value];
     };
     if constexpr (ECL_PRO && JV_LDS) {
-        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
-            constexpr int g = decltype(gc)::value;
-            static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (BCOL.b[j]) WE += ECLV[j - group_first_col(g)] * pjs::SP[j][0] * vv(std::integral_constant<int, j + 1>{});
+        int jfirst = 0;
+        static_for<G_>([&](auto gc) PJR_INL { jfirst = grp == decltype(gc)::value ? group_first_col(decltype(gc)::value) : jfirst; });
+        static_for<NCOLG>([&](auto pc) PJR_INL {
+            constexpr int p = decltype(pc)::value;
+            // 1 / W_j of this group's p-th column (scalar selects) and v_{j+1} (LDS, run-time column); unmarked: ECLV = 0
+            double iw = 0.0;
+            static_for<G_>([&](auto gc) PJR_INL {
+                constexpr int g = decltype(gc)::value, j = group_first_col(g) + p;
+                iw = grp == g ? pjs::SP[j < LAST ? j : 0][0] : iw;
             });
+            const int jv_ = jfirst + p + 1 < NSP ? jfirst + p + 1 : 0;
+            WE += ECLV[p] * iw * SM[SM_EJ + jv_ * PJQ_BLOCK + tid];
         });
     }
     double* const wp = A.w + s * A.w_ss;

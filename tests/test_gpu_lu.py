@@ -41,14 +41,14 @@ def _scipy_perm(piv):
     return perm
 
 
-@pytest.mark.parametrize('nsp', [1, 2, 7, 8, 9, 10, 16, 17, 24, 32, 33, 48, 53, 54, 55, 56, 57, 64, 65, 100, 111, 128, 129, 140])
+@pytest.mark.parametrize('nsp', [1, 2, 7, 8, 9, 10, 16, 17, 24, 32, 33, 48, 53, 54, 55, 56, 57, 64, 65, 80, 81, 96, 97, 100, 111, 112, 113, 128, 129, 140])
 def test_lu_factor_matches_lapack(nsp, torch_cuda):
     """P A = L U with LAPACK's pivot rows; factors agree to rounding; also through I - gamma A."""
     import scipy.linalg
     from pyjac_amd import linsolve
     torch = torch_cuda
     rng = np.random.default_rng(100 + nsp)
-    n = 300 if nsp > 16 else 1000          # (65 rows and more: the LDS-resident kernel, a workgroup per block)
+    n = 300 if nsp > 16 else 1000          # (65 .. 128 rows: k_lu4, four wavefronts per block; beyond: the LDS-resident kernel)
     a = _blocks(rng, n, nsp)
     for gamma in (0.0, 0.37):
         m = a if gamma == 0.0 else np.eye(nsp) - gamma * a
