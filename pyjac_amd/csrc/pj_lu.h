@@ -615,34 +615,35 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
 // ---- blocks of 65 .. 128 rows: FOUR wavefronts per block, the matrix in registers ------------------------------------
 // k_lu_lds keeps the block in LDS and pays ~4 barriers and an LDS round trip per entry and column: 168 ms per 2e5
 // 111 x 111 blocks, 0.03 of the HBM roofline, 27x the time of the Jacobians it consumes.  Here the
-// workgroup's four wavefronts are (row half rh) x (column parity ch): lane l of wavefront (rh, ch) holds row
-// rh * NC + l, and of it the columns 2 c + ch, c < NC -- NC doubles per lane (112 registers for 111 x 111), compile-time
-// indices, columns dealt cyclically so that all four wavefronts have work until the last step.  Elimination step
-// k = 2 c + h (TWO barriers):
-//   1. the two wavefronts that hold column k (ch == h) reduce their open rows' |a_k| to a candidate each (unsigned keys,
-//      DPP maxima, ties to the lowest row, as k_lu) and leave value + lane in LDS;                          -- barrier --
-//   2. every wavefront picks the winner (the larger magnitude, the lower row half on a tie: dgetf2's choice unless an
-//      earlier step displaced a tied row, as k_lu); the winner row's lane in either column half parks its remaining
-//      entries in LDS (one lane, 16-byte writes), the column owners scale their column (multipliers: kept as L, and
-//      left in LDS for the other column half);                                                              -- barrier --
-//   3. a[c'] -= l * u[c'] for the columns right of k: the pivot row arrives as uniform 16-byte LDS reads.
-// Rows are never exchanged (implicit pivoting: a row remembers its position), forward substitution rides along, the
-// back substitution runs on an LDS copy of the right-hand side (two barriers per column as well).  Same (lu, perm)
+// workgroup's four wavefronts each hold EVERY row of a quarter of the columns: lane l of wavefront w holds rows l and
+// l + RH (RH = NP / 2) of the columns 4 c + w, c < NC = NP / 4 -- 2 NC doubles per lane (112 registers for 111 x 111),
+// compile-time indices, columns dealt cyclically so that all four wavefronts have work until the last step.  Since a
+// wavefront sees whole columns, the pivot search of column k is local to its owner (k mod 4), and since it sees every
+// row of its columns, the pivot row's entries reach its lanes without leaving the wavefront (one lane parks them in
+// the wavefront's LDS strip, 16 bytes at a time; the others read them back at a uniform address).  What has to cross
+// wavefronts is the multiplier column and the pivot's position: ONE barrier per elimination step, and the owner of
+// column k + 1 updates that column first, searches it and publishes step k + 1's multipliers while the others are
+// still updating (double-buffered), so the search is off the critical path.
+// (First version, round 5: wavefronts = row halves x column parity, two barriers per step, candidates exchanged through
+// LDS: 50.8 ms per 2e5 111 x 111 factorisations.)
+// Rows are never exchanged (implicit pivoting: a row remembers its position; ties go to the lowest original row, as
+// k_lu); the right-hand side and the positions are replicated in the four wavefronts, so forward substitution needs
+// no exchange; the back substitution exchanges one partial sum per wavefront and step (one barrier).  Same (lu, perm)
 // convention as k_lu / k_lu_lds; stored factors are solved by k_lu_lds (LU_PREFACTORED).
-template <int NC>
+template <int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_lu4(const int nsp, const long n, const double* A, const LuLay Y, const double gamma, double* lu, int* __restrict__ perm,
       const double* __restrict__ b, double* __restrict__ x, const int mode)
 {
-    static_assert(NC % 2 == 0 && NC <= 64, "k_lu4: up to 128 rows, an even number of columns per wavefront");
-    __shared__ __attribute__((aligned(16))) double prow[2][NC];     // the pivot row, per column parity
-    __shared__ double lcol[128];                                     // the multipliers of the step, per row
-    __shared__ double candv[2];
-    __shared__ int candl[2];
-    __shared__ double ys[2 * NC + 2];                                // right-hand side by position (back substitution)
-    __shared__ double yk_s;
-    const int tid = (int)threadIdx.x, wave = tid >> 6, lane0 = tid & 63;
-    const int rh = __builtin_amdgcn_readfirstlane(wave >> 1), ch = __builtin_amdgcn_readfirstlane(wave & 1);
+    static_assert(NP % 8 == 0 && NP <= 128, "k_lu4: up to 128 rows");
+    constexpr int RH = NP / 2, NC = NP / 4;
+    __shared__ __attribute__((aligned(16))) double prow[4][NC + (NC & 1)];     // a wavefront's share of the pivot row
+    __shared__ double lcol[2][2][64];                                          // multipliers of a step: [buffer][row set][lane]
+    __shared__ double hdr_inv[2];
+    __shared__ int hdr_lp[2], hdr_rs[2];
+    __shared__ double part[2][4];
+    const int tid = (int)threadIdx.x, lane0 = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long ne = (long)nsp * nsp;
     const bool solve = (mode & LU_SOLVE) != 0;
     const int nsp0 = nsp;
@@ -653,157 +654,221 @@ k_lu4(const int nsp, const long n, const double* A, const LuLay Y, const double 
         if (s >= n) continue;                            // (uniform in the workgroup)
         int nsp = nsp0, lane = lane0;
         asm volatile("" : "+s"(nsp), "+v"(lane));
-        const int row = rh * NC + lane;
-        const bool act = lane < NC && row < nsp;
-        const int row_c = act ? row : nsp - 1;
-        double a[NC];
+        const int row0 = lane, row1 = lane + RH;
+        const bool act0 = lane < RH && row0 < nsp, act1 = lane < RH && row1 < nsp;
+        double a0[NC], a1[NC];
         {
             const double* As = A + s * Y.a_ss;
+            const int r0c = act0 ? row0 : nsp - 1, r1c = act1 ? row1 : nsp - 1;
             // all loads first (clamped addresses instead of predicates), then identity padding / I - gamma A branch-free
             lu_for<0, NC>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                const int g = 2 * c + ch;
-                a[c] = As[(row_c + (long)nsp * (g < nsp ? g : nsp - 1)) * Y.a_si];
+                const int g = 4 * c + w;
+                const long col = (long)nsp * (g < nsp ? g : nsp - 1);
+                a0[c] = As[(r0c + col) * Y.a_si];
+                a1[c] = As[(r1c + col) * Y.a_si];
             });
             const bool newton = gamma != 0.0;
             const double sc = newton ? -gamma : 1.0, sh = newton ? 1.0 : 0.0;
             lu_for<0, NC>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                const int g = 2 * c + ch;
-                const double id = (g == row && lane < NC) ? 1.0 : 0.0;
-                a[c] = (act && g < nsp) ? __builtin_fma(sc, a[c], sh * id) : id;
+                const int g = 4 * c + w;
+                const double id0 = (g == row0 && lane < RH) ? 1.0 : 0.0, id1 = (g == row1 && lane < RH) ? 1.0 : 0.0;
+                a0[c] = (act0 && g < nsp) ? __builtin_fma(sc, a0[c], sh * id0) : id0;
+                a1[c] = (act1 && g < nsp) ? __builtin_fma(sc, a1[c], sh * id1) : id1;
             });
         }
-        int pos = -1;
-        double bb = 0.0;
-        if (solve && ch == 0) bb = act ? b[row * Y.v_si + s * Y.v_ss] : 0.0;
-        unsigned long long openmask = 0;
-        {
-            const int nrow = nsp - rh * NC;                  // open rows of this row half: lanes 0 .. nrow - 1
-            openmask = nrow >= 64 ? ~0ull : nrow > 0 ? (1ull << (nrow < NC ? nrow : NC)) - 1ull : 0ull;
+        int pos0 = -1, pos1 = -1;
+        double bb0 = 0.0, bb1 = 0.0, inv0 = 1.0, inv1 = 1.0;      // inv: 1 / u_kk in the lane whose row became row k
+        if (solve) {
+            bb0 = act0 ? b[row0 * Y.v_si + s * Y.v_ss] : 0.0;
+            bb1 = act1 ? b[row1 * Y.v_si + s * Y.v_ss] : 0.0;
         }
+        // rows not chosen yet, per row set, as wavefront masks
+        auto rows_mask = [&](const int first) {
+            const int cnt = nsp - first;
+            const int m = cnt < 0 ? 0 : cnt > RH ? RH : cnt;
+            return m >= 64 ? ~0ull : (1ull << m) - 1ull;
+        };
+        unsigned long long open0 = rows_mask(0), open1 = rows_mask(RH);
+
+        // pivot of the column whose entries are (c0, c1) among the open rows; publishes the step's multipliers
+        auto search_publish = [&](double& c0, double& c1, const unsigned long long o0, const unsigned long long o1, const int buf) {
+            const bool op0 = __builtin_amdgcn_inverse_ballot_w64(o0), op1 = __builtin_amdgcn_inverse_ballot_w64(o1);
+            const unsigned long long u0 = (unsigned long long)__double_as_longlong(c0), u1 = (unsigned long long)__double_as_longlong(c1);
+            const bool n0 = c0 == c0, n1 = c1 == c1;
+            const unsigned k0 = (op0 & n0) ? (unsigned)(u0 >> 32) & 0x7fffffffu : 0u;      // a NaN never beats a number
+            const unsigned k1 = (op1 & n1) ? (unsigned)(u1 >> 32) & 0x7fffffffu : 0u;
+            unsigned kmax = k0 > k1 ? k0 : k1;
+            kmax = lu_dpp_umax<0x111, 0xf>(kmax);
+            kmax = lu_dpp_umax<0x112, 0xf>(kmax);
+            kmax = lu_dpp_umax<0x114, 0xf>(kmax);
+            kmax = lu_dpp_umax<0x118, 0xf>(kmax);
+            kmax = lu_dpp_umax<0x142, 0xa>(kmax);
+            kmax = lu_dpp_umax<0x143, 0xc>(kmax);
+            const unsigned mx = (unsigned)__builtin_amdgcn_readlane((int)kmax, 63);
+            unsigned long long h0 = __builtin_amdgcn_ballot_w64(k0 == mx) & o0, h1 = __builtin_amdgcn_ballot_w64(k1 == mx) & o1;
+            if (__builtin_popcountll(h0) + __builtin_popcountll(h1) > 1) {      // (uniform, rare): the lower 32 bits decide
+                const bool i0 = __builtin_amdgcn_inverse_ballot_w64(h0), i1 = __builtin_amdgcn_inverse_ballot_w64(h1);
+                const unsigned q0 = (i0 && n0) ? (unsigned)u0 : 0u, q1 = (i1 && n1) ? (unsigned)u1 : 0u;
+                unsigned m2 = q0 > q1 ? q0 : q1;
+                m2 = lu_dpp_umax<0x111, 0xf>(m2);
+                m2 = lu_dpp_umax<0x112, 0xf>(m2);
+                m2 = lu_dpp_umax<0x114, 0xf>(m2);
+                m2 = lu_dpp_umax<0x118, 0xf>(m2);
+                m2 = lu_dpp_umax<0x142, 0xa>(m2);
+                m2 = lu_dpp_umax<0x143, 0xc>(m2);
+                const unsigned mx2 = (unsigned)__builtin_amdgcn_readlane((int)m2, 63);
+                h0 = __builtin_amdgcn_ballot_w64(i0 && q0 == mx2);
+                h1 = __builtin_amdgcn_ballot_w64(i1 && q1 == mx2);
+            }
+            // the first row of maximum magnitude in the original order: row set 0 (rows 0 .. RH-1) before row set 1
+            const int rs = h0 ? 0 : 1;
+            const unsigned long long hh = h0 ? h0 : (h1 ? h1 : (o0 ? o0 : o1));   // (a column of NaNs: any open row)
+            const int rs_ = h0 ? 0 : (h1 ? 1 : (o0 ? 0 : 1));
+            (void)rs;
+            const int lp = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hh | (1ull << 63)));
+            const double ukk = lu_readlane(rs_ ? c1 : c0, lp);
+            const double inv = lu_rcp(ukk);
+            // multipliers of the rows that stay open (kept as L in the column itself)
+            const unsigned long long o0n = rs_ == 0 ? o0 & ~(1ull << lp) : o0, o1n = rs_ == 1 ? o1 & ~(1ull << lp) : o1;
+            const bool b0 = __builtin_amdgcn_inverse_ballot_w64(o0n), b1 = __builtin_amdgcn_inverse_ballot_w64(o1n);
+            const double l0 = b0 ? c0 * inv : 0.0, l1 = b1 ? c1 * inv : 0.0;
+            if (b0) c0 = l0;
+            if (b1) c1 = l1;
+            lcol[buf][0][lane] = l0;
+            lcol[buf][1][lane] = l1;
+            if (lane == 0) { hdr_lp[buf] = lp; hdr_rs[buf] = rs_; hdr_inv[buf] = inv; }
+        };
+        if (w == 0) search_publish(a0[0], a1[0], open0, open1, 0);
         lu_for<0, NC>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            lu_for<0, 2>([&](auto hc) {
-                constexpr int h = decltype(hc)::value, k = 2 * c + h;
+            lu_for<0, 4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, k = 4 * c + q, buf = k & 1;
                 if (k < nsp) {                                   // (uniform)
-                    // ---- 1. candidates of the two wavefronts that hold column k
-                    if (ch == h) {
-                        const bool open = __builtin_amdgcn_inverse_ballot_w64(openmask);
-                        const unsigned long long ub = (unsigned long long)__double_as_longlong(a[c]);
-                        const bool num = a[c] == a[c];
-                        const unsigned key = (open & num) ? (unsigned)(ub >> 32) & 0x7fffffffu : 0u;   // a NaN never beats a number
-                        unsigned kmax = key;
-                        kmax = lu_dpp_umax<0x111, 0xf>(kmax);
-                        kmax = lu_dpp_umax<0x112, 0xf>(kmax);
-                        kmax = lu_dpp_umax<0x114, 0xf>(kmax);
-                        kmax = lu_dpp_umax<0x118, 0xf>(kmax);
-                        kmax = lu_dpp_umax<0x142, 0xa>(kmax);
-                        kmax = lu_dpp_umax<0x143, 0xc>(kmax);
-                        const unsigned mx = (unsigned)__builtin_amdgcn_readlane((int)kmax, 63);
-                        unsigned long long hit = __builtin_amdgcn_ballot_w64(key == mx) & openmask;
-                        if (__builtin_popcountll(hit) > 1) {        // (uniform, rare): the lower 32 bits of the tying rows
-                            const bool in = __builtin_amdgcn_inverse_ballot_w64(hit);
-                            const unsigned k2 = (in && num) ? (unsigned)ub : 0u;
-                            unsigned m2 = k2;
-                            m2 = lu_dpp_umax<0x111, 0xf>(m2);
-                            m2 = lu_dpp_umax<0x112, 0xf>(m2);
-                            m2 = lu_dpp_umax<0x114, 0xf>(m2);
-                            m2 = lu_dpp_umax<0x118, 0xf>(m2);
-                            m2 = lu_dpp_umax<0x142, 0xa>(m2);
-                            m2 = lu_dpp_umax<0x143, 0xc>(m2);
-                            const unsigned mx2 = (unsigned)__builtin_amdgcn_readlane((int)m2, 63);
-                            hit = __builtin_amdgcn_ballot_w64(in && k2 == mx2);
-                        }
-                        const int lp = hit ? __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit)) : -1;
-                        const double val = lu_readlane(a[c], lp < 0 ? 0 : lp);
-                        if (lane == 0) { candv[rh] = val; candl[rh] = lp; }
-                    }
                     __syncthreads();
-                    // ---- 2. the winner; its row to LDS, the multipliers of column k
-                    const double v0 = candv[0], v1 = candv[1];
-                    const int l0 = candl[0], l1 = candl[1];
-                    // magnitudes as integers (a NaN counts as 0, as in the keys); the lower row half wins a tie
-                    const unsigned long long m0 = (v0 == v0) ? ((unsigned long long)__double_as_longlong(v0) & 0x7fffffffffffffffull) : 0ull;
-                    const unsigned long long m1 = (v1 == v1) ? ((unsigned long long)__double_as_longlong(v1) & 0x7fffffffffffffffull) : 0ull;
-                    const bool second = l0 < 0 || (l1 >= 0 && m1 > m0);
-                    const int rhp = __builtin_amdgcn_readfirstlane(second ? 1 : 0);
-                    const int lp = __builtin_amdgcn_readfirstlane(second ? l1 : l0);
-                    const double ukk = second ? v1 : v0;
-                    const double inv = lu_rcp(ukk);
-                    const bool mine = rh == rhp;                 // (uniform)
-                    if (mine) {
-                        const bool me = __builtin_amdgcn_inverse_ballot_w64(1ull << (lp & 63));
-                        pos = me ? k : pos;
-                        openmask &= ~(1ull << (lp & 63));
-                        if (me) {
-                            // the pivot row's entries right of column k (this wavefront's share), 16 bytes at a time
-                            constexpr int ST = c + 1, EV = ST + (ST & 1);            // first pair-aligned column
-                            if (ch > h) prow[ch][c] = a[c];                          // (column 2 c + 1 at step 2 c)
-                            if constexpr ((ST & 1) != 0 && ST < NC) prow[ch][ST] = a[ST];
-                            lu_for<0, (NC - EV) / 2>([&](auto qc) {
-                                constexpr int j = EV + 2 * decltype(qc)::value;
+                    const int lp = __builtin_amdgcn_readfirstlane(hdr_lp[buf]), rs = __builtin_amdgcn_readfirstlane(hdr_rs[buf]);
+                    const double inv = hdr_inv[buf];
+                    const double l0 = lcol[buf][0][lane], l1 = lcol[buf][1][lane];
+                    const bool me = lane == lp;
+                    if (rs == 0) { pos0 = me ? k : pos0; inv0 = me ? inv : inv0; open0 &= ~(1ull << lp); }
+                    else { pos1 = me ? k : pos1; inv1 = me ? inv : inv1; open1 &= ~(1ull << lp); }
+                    // this wavefront's share of the pivot row, right of column k: parked by the pivot's lane, 16 bytes at a time
+                    constexpr int CF = c + 1;                    // columns c' >= CF are right of k in every wavefront; c' == c if w > q
+                    constexpr int EV = CF + (CF & 1);
+                    if (me) {
+                        auto park = [&](const double (&ar)[NC]) {
+                            if (w > q) prow[w][c] = ar[c];
+                            if constexpr ((CF & 1) != 0 && CF < NC) prow[w][CF] = ar[CF];
+                            lu_for<0, (NC - EV) / 2>([&](auto jc) {
+                                constexpr int j = EV + 2 * decltype(jc)::value;
                                 double2 v;
-                                v.x = a[j];
-                                v.y = a[j + 1];
-                                *(double2*)&prow[ch][j] = v;
+                                v.x = ar[j];
+                                v.y = ar[j + 1];
+                                *(double2*)&prow[w][j] = v;
                             });
-                            if (solve && ch == 0) yk_s = bb;
+                            if constexpr (((NC - EV) & 1) != 0) prow[w][NC - 1] = ar[NC - 1];
+                        };
+                        if (rs == 0) park(a0); else park(a1);
+                    }
+                    if (solve) {                                 // forward substitution rides along (replicated)
+                        const double yk = lu_readlane(rs ? bb1 : bb0, lp);
+                        bb0 = __builtin_fma(-l0, yk, bb0);
+                        bb1 = __builtin_fma(-l1, yk, bb1);
+                    }
+                    // the owner of column k + 1 brings that column up to date first, finds its pivot and publishes step k + 1
+                    constexpr int qn = (q + 1) & 3, cn = q == 3 ? c + 1 : c;
+                    if constexpr (cn < NC) {
+                        if (w == qn && k + 1 < nsp) {
+                            const double u = prow[w][cn];
+                            a0[cn] = __builtin_fma(-l0, u, a0[cn]);
+                            a1[cn] = __builtin_fma(-l1, u, a1[cn]);
+                            search_publish(a0[cn], a1[cn], open0, open1, buf ^ 1);
                         }
                     }
-                    const bool below = __builtin_amdgcn_inverse_ballot_w64(openmask);   // rows not chosen yet
-                    double l = 0.0;
-                    if (ch == h) {
-                        l = below ? a[c] * inv : 0.0;
-                        if (below) a[c] = l;
-                        lcol[rh * 64 + lane] = l;
+                    // the other columns right of k
+                    if (w > q && !(cn == c && w == qn)) {
+                        const double u = prow[w][c];
+                        a0[c] = __builtin_fma(-l0, u, a0[c]);
+                        a1[c] = __builtin_fma(-l1, u, a1[c]);
                     }
-                    __syncthreads();
-                    // ---- 3. update of the columns right of k
-                    if (ch != h) l = lcol[rh * 64 + lane];
-                    if (ch > h) a[c] = __builtin_fma(-l, prow[ch][c], a[c]);
-                    {
-                        constexpr int ST = c + 1, EV = ST + (ST & 1);
-                        if constexpr ((ST & 1) != 0 && ST < NC) a[ST] = __builtin_fma(-l, prow[ch][ST], a[ST]);
-                        lu_for<0, (NC - EV) / 2>([&](auto qc) {
-                            constexpr int j = EV + 2 * decltype(qc)::value;
-                            const double2 u = *(const double2*)&prow[ch][j];
-                            a[j] = __builtin_fma(-l, u.x, a[j]);
-                            a[j + 1] = __builtin_fma(-l, u.y, a[j + 1]);
-                        });
+                    if constexpr ((CF & 1) != 0 && CF < NC) {
+                        if (!(cn == CF && w == qn)) {
+                            const double u = prow[w][CF];
+                            a0[CF] = __builtin_fma(-l0, u, a0[CF]);
+                            a1[CF] = __builtin_fma(-l1, u, a1[CF]);
+                        }
                     }
-                    if (solve && ch == 0) bb = __builtin_fma(-l, yk_s, bb);      // forward substitution rides along
+                    lu_for<0, (NC - EV) / 2>([&](auto jc) {
+                        constexpr int j = EV + 2 * decltype(jc)::value;
+                        const double2 u = *(const double2*)&prow[w][j];
+                        if (!(cn == j && w == qn)) {
+                            a0[j] = __builtin_fma(-l0, u.x, a0[j]);
+                            a1[j] = __builtin_fma(-l1, u.x, a1[j]);
+                        }
+                        if (!(cn == j + 1 && w == qn)) {
+                            a0[j + 1] = __builtin_fma(-l0, u.y, a0[j + 1]);
+                            a1[j + 1] = __builtin_fma(-l1, u.y, a1[j + 1]);
+                        }
+                    });
+                    if constexpr (((NC - EV) & 1) != 0) {
+                        if (!(cn == NC - 1 && w == qn)) {
+                            const double u = prow[w][NC - 1];
+                            a0[NC - 1] = __builtin_fma(-l0, u, a0[NC - 1]);
+                            a1[NC - 1] = __builtin_fma(-l1, u, a1[NC - 1]);
+                        }
+                    }
                 }
             });
         });
         asm volatile("" : "+s"(nsp), "+v"(lane));
-        if (lu != nullptr && act) {
+        if (lu != nullptr) {
             double* Ls = lu + s * ne;
             lu_for<0, NC>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                const int g = 2 * c + ch;
-                if (g < nsp) Ls[pos + (long)nsp * g] = a[c];
+                const int g = 4 * c + w;
+                if (g < nsp) {
+                    if (act0) Ls[pos0 + (long)nsp * g] = a0[c];
+                    if (act1) Ls[pos1 + (long)nsp * g] = a1[c];
+                }
             });
-            if (perm != nullptr && ch == 0) perm[s * nsp + pos] = row;
+            if (perm != nullptr && w == 0) {
+                if (act0) perm[s * nsp + pos0] = row0;
+                if (act1) perm[s * nsp + pos1] = row1;
+            }
         }
         if (solve) {
-            // U x = y, last column first, on an LDS copy of y by position: the lane at position k divides, the column's
-            // owners (parity ch == k & 1) update the positions above
-            if (ch == 0 && act) ys[pos] = bb;
-            __syncthreads();
+            // U x = y, last column first.  Every wavefront holds y and the positions; the products a[r][k'] x_k' of the columns it
+            // owns accumulate in acc (per row).  Step k: the four partial sums of the row at position k meet in LDS (one
+            // barrier), every wavefront forms x_k, the owner of column k adds its products.
+            double acc0 = 0.0, acc1 = 0.0, xs0 = 0.0, xs1 = 0.0;
             lu_for<0, NC>([&](auto cr) {
                 constexpr int c = NC - 1 - decltype(cr)::value;
-                lu_for<0, 2>([&](auto hr) {
-                    constexpr int h = 1 - decltype(hr)::value, k = 2 * c + h;
+                lu_for<0, 4>([&](auto qr) {
+                    constexpr int q = 3 - decltype(qr)::value, k = 4 * c + q, buf = k & 1;
                     if (k < nsp) {
-                        if (ch == h && pos == k) ys[k] = lu_div(ys[k], a[c], lu_rcp(a[c]));
+                        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(pos0 == k), m1 = __builtin_amdgcn_ballot_w64(pos1 == k);
+                        const int rs = m0 ? 0 : 1;
+                        const int lp = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll((m0 ? m0 : m1) | (1ull << 63)));
+                        const double accr = lu_readlane(rs ? acc1 : acc0, lp);
+                        if (lane == 0) part[buf][w] = accr;
                         __syncthreads();
-                        if (ch == h && pos >= 0 && pos < k) ys[pos] = __builtin_fma(-a[c], ys[k], ys[pos]);
-                        __syncthreads();
+                        const double sum = (part[buf][0] + part[buf][1]) + (part[buf][2] + part[buf][3]);
+                        const double yk = lu_readlane(rs ? bb1 : bb0, lp), ik = lu_readlane(rs ? inv1 : inv0, lp);
+                        const double xk = (yk - sum) * ik;
+                        if (w == q) {
+                            if (pos0 >= 0 && pos0 < k) acc0 = __builtin_fma(a0[c], xk, acc0);
+                            if (pos1 >= 0 && pos1 < k) acc1 = __builtin_fma(a1[c], xk, acc1);
+                        }
+                        xs0 = pos0 == k ? xk : xs0;
+                        xs1 = pos1 == k ? xk : xs1;
                     }
                 });
             });
-            if (ch == 0 && act) x[pos * Y.v_si + s * Y.v_ss] = ys[pos];
+            if (w == 0) {
+                if (act0) x[pos0 * Y.v_si + s * Y.v_ss] = xs0;
+                if (act1) x[pos1 * Y.v_si + s * Y.v_ss] = xs1;
+            }
         }
         __syncthreads();
     }
@@ -1004,10 +1069,10 @@ inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, do
         auto go = [&](auto ncc) {
             hipLaunchKernelGGL((k_lu4<decltype(ncc)::value>), dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
         };
-        if (nsp <= 80) go(std::integral_constant<int, 40>{});
-        else if (nsp <= 96) go(std::integral_constant<int, 48>{});
-        else if (nsp <= 112) go(std::integral_constant<int, 56>{});
-        else go(std::integral_constant<int, 64>{});
+        if (nsp <= 80) go(std::integral_constant<int, 80>{});
+        else if (nsp <= 96) go(std::integral_constant<int, 96>{});
+        else if (nsp <= 112) go(std::integral_constant<int, 112>{});
+        else go(std::integral_constant<int, 128>{});
         return 0;
     }
     if (nsp > 64) {

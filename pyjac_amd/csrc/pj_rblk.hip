@@ -141,7 +141,7 @@ using namespace pj;
 #ifndef PJQ_NT_STORE
 #define PJQ_NT_STORE 1
 #endif
-#if defined(PJQ_NO_STORE)
+#if defined(PJQ_NO_STORE) && PJQ_PART == 2
 // experiment: the arithmetic without the Jacobian stores (values folded into one sink per lane)
 #define PJQ_STORE(ptr, val) (pjq_sink += (val))
 #define PJQ_STORE2(ptr, val) (pjq_sink += (val).x + (val).y)
@@ -575,7 +575,8 @@ __global__ void __launch_bounds__(NTHR) k_pre(PjqArgs A)
                 constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
                 double Hr;
                 if constexpr ((fl & F_REV) != 0) {
-                    Hr = (RU_ * T) * (TdlnKc + net_sum(i));
+                    constexpr double nsum = net_sum(i);
+                    Hr = (RU_ * T) * (TdlnKc + nsum);
                 } else {
                     Hr = 0.0;
                     static_for<ncnt>([&](auto qc) PJR_INL {
@@ -601,7 +602,10 @@ __global__ void __launch_bounds__(NTHR) k_pre(PjqArgs A)
                     if constexpr (sp < LAST) {
                         if constexpr (!in_net(i, sp)) {
                             static_assert(BCOL.b[sp], "energy row: column not marked");
-                            ecl[ecl_index(sp)] += Hr * gv;
+                            // (a constexpr variable: called in place, ecl_index() is a RUN-TIME loop over BCOL, the index
+                            // a variable, and the whole array lives in scratch memory)
+                            constexpr int ci = ecl_index(sp);
+                            ecl[ci] += Hr * gv;
                         }
                     }
                 };
@@ -1181,8 +1185,15 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     // one-kernel builds with several lane groups, in an LDS column set that the groups fill together (53 doubles next
     // to everything else spill, and every row block would reload them from scratch memory: 85 KB per state through
     // the vector memory path, 9.8 ms per 1e6 products)
+    // What is kept is the SCALED vector vs_0 = v_0, vs_c = v_c / W_{c-1}: row k of the species block is
+    //   J(k, c) = (1 / W_{c-1}) (W_k (P_k + S_k,c-1)) - W_k Q_k / W_N   (the output phase's form), so
+    //   w_k = W_k JT_k v_0 + W_k P_k SV1 - (W_k Q_k / W_N) SV0 + W_k sum_{c-1 in nz(k)} S_k,c-1 vs_c
+    // with the per-state sums SV0 = sum_{c>=1} v_c, SV1 = sum_{c>=1} vs_c: a row costs one LDS read and one FMA per
+    // STRUCTURAL NON-ZERO instead of a read and three FMAs per column (round 4: 7.4 ms per 1e6 GRI-shaped products,
+    // slower than writing the Jacobians).
     double V[JV_LDS ? 1 : NSP];
     double WE = 0.0;        // JV_LDS: sum_j E^A_j v_{j+1} / W_j, the finished column sums' share of w_0
+    double SV0 = 0.0, SV1 = 0.0;
     {
         const double* vp = A.v + s * A.v_ss;
         if constexpr (JV_LDS) {
@@ -1190,14 +1201,30 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 constexpr int g = decltype(gc)::value;
                 if (grp == g)
                     static_range<group_first_species(g), group_first_species(g + 1)>([&](auto cc) PJR_INL {
-                        SM[SM_EJ + decltype(cc)::value * PJQ_BLOCK + tid] = vp[decltype(cc)::value * A.v_si];
+                        constexpr int c = decltype(cc)::value;
+                        const double vc = vp[c * A.v_si];
+                        double vsc = vc;
+                        if constexpr (c > 0) vsc = vc * pjs::SP[c - 1][0];
+                        SM[SM_EJ + c * PJQ_BLOCK + tid] = vsc;
                     });
             });
             __syncthreads();
+            // every lane group needs the whole sums: each takes them from the columns (NSP - 1 reads: once per state)
+            static_range<1, NSP>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value;
+                const double vsc = SM[SM_EJ + c * PJQ_BLOCK + tid];
+                SV1 += vsc;
+                SV0 += vsc * pjs::SP[c - 1][1];
+            });
         } else {
-            static_for<NSP>([&](auto cc) PJR_INL { V[decltype(cc)::value] = vp[decltype(cc)::value * A.v_si]; });
+            static_for<NSP>([&](auto cc) PJR_INL {
+                constexpr int c = decltype(cc)::value;
+                const double vc = vp[c * A.v_si];
+                if constexpr (c > 0) { V[c] = vc * pjs::SP[c - 1][0]; SV0 += vc; SV1 += V[c]; } else V[c] = vc;
+            });
         }
     }
+    // vs_c
     auto vv = [&](auto cc) PJR_INL {
         if constexpr (JV_LDS) return SM[SM_EJ + decltype(cc)::value * PJQ_BLOCK + tid];
         else return V[decltype(cc)::value];
@@ -1214,7 +1241,8 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 iw = grp == g ? pjs::SP[j < LAST ? j : 0][0] : iw;
             });
             const int jv_ = jfirst + p + 1 < NSP ? jfirst + p + 1 : 0;
-            WE += ECLV[p] * iw * SM[SM_EJ + jv_ * PJQ_BLOCK + tid];
+            (void)iw;
+            WE += ECLV[p] * SM[SM_EJ + jv_ * PJQ_BLOCK + tid];          // (the column holds v_{j+1} / W_j)
         });
     }
     double* const wp = A.w + s * A.w_ss;
@@ -1345,7 +1373,15 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         // (with several lane groups also at a group's first block: k_f of a reaction that two groups visit is
         // otherwise computed once, in front of the group branches, and kept)
         if constexpr ((b - LO_) % PJQ_LAUNDER_EVERY == 0 && (b != LO_ || G_ > 1))
-            asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT), "+v"(T2), "+v"(T3), "+v"(T4), "+v"(T2d), "+v"(T3d), "+v"(T4d));
+        {
+            // (the powers of T are REBUILT from the opaque copy, six multiplications per block: as opaque copies of their own
+            // they are six more per-state values that live through the whole kernel, and in the kernels that are short of
+            // registers exactly those are kept in scratch memory and reloaded at every visit -- each reload behind every
+            // Jacobian store issued before it: 2 900 reloads in the first kernel of a 64-state / four-group USC-shaped build)
+            asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT));
+            T2 = T * T; T3 = T2 * T; T4 = T2 * T2;
+            T2d = 2.0 * T2; T3d = 3.0 * T3; T4d = 4.0 * T4;
+        }
 #endif
         double om[nrows], P[nrows], Q[nrows], JT[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
         double EA[nrows];           // energy row, column of each row of the block: sum_i Hr_i G_ij over the block's visits
@@ -1590,7 +1626,8 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     hrt += pjs::NET_NU[np0 + decltype(qc)::value][0] * xtb[k / XGRP][(k % XGRP) * PJQ_BLOCK].y;
                 });
             }
-            const double Hr = (RU_ * T) * (hrt + net_sum(i));
+            constexpr double nsum = net_sum(i);
+            const double Hr = (RU_ * T) * (hrt + nsum);
 #else
             double Hr;
             if constexpr ((fl & F_REV) != 0) {
@@ -1598,7 +1635,8 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     const double* a = ka[decltype(cc)::value];
                     hrt += a[1] + a[2] * T + a[3] * T2d + a[4] * T3d + a[5] * T4d + a[6] * invT;
                 });
-                Hr = (RU_ * T) * (hrt + net_sum(i));
+                constexpr double nsum = net_sum(i);
+                Hr = (RU_ * T) * (hrt + nsum);
             } else {
                 // an irreversible reaction has no K_c polynomial: the species' enthalpies from their NASA coefficients
                 Hr = 0.0;
@@ -1763,9 +1801,13 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             constexpr int k = pjs::BLK_ROWS[r0 + r][0];
             if constexpr (k < LAST) {
 #if PJQ_JV
-                double wk = 0.0;
-                static_for<NSP>([&](auto cc) PJR_INL { wk += col_val(rc, cc) * vv(cc); });
-                wp[(k + 1) * A.w_si] = wk;
+                double sk = 0.0;
+                static_for<LAST>([&](auto jc) PJR_INL {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int si = pjs::SLOC[k][j];
+                    if constexpr (si >= 0) sk += S[si] * vv(std::integral_constant<int, j + 1>{});
+                });
+                wp[(k + 1) * A.w_si] = pjs::SP[k][1] * (JT[r] * vv(std::integral_constant<int, 0>{}) + sk) + WP[r] * SV1 - WQN[r] * SV0;
 #else
                 if constexpr (DEFER && b + 1 < HI_) {
                     // (stored during the next block's visits)
@@ -1793,7 +1835,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             if constexpr (k < LAST) {
                 if constexpr (G_ == 1) e_add(std::integral_constant<int, k>{}, EA[r]);
 #if PJQ_JV
-                else if constexpr (JV_LDS) WE += EA[r] * pjs::SP[k][0] * vv(std::integral_constant<int, k + 1>{});
+                else if constexpr (JV_LDS) WE += EA[r] * vv(std::integral_constant<int, k + 1>{});       // (v_{k+1} / W_k)
 #endif
                 else if constexpr (EJ_LDS && PJQ_ECL && BCOL.b[k < LAST ? k : 0]) SM[SM_EJ + k * PJQ_BLOCK + tid] += EA[r];
                 else if constexpr (EJ_LDS) SM[SM_EJ + k * PJQ_BLOCK + tid] = EA[r];
@@ -1878,14 +1920,19 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             // reads them any more) and the scalar sums to everybody; then each finishes its share of the energy row.
             double (*const EX)[G_ > 1 ? G_ - 1 : 1][PJQ_BLOCK] = (double (*)[G_ > 1 ? G_ - 1 : 1][PJQ_BLOCK])(SM + SM_EX);
             double (*const RED)[G_][PJQ_BLOCK] = (double (*)[G_][PJQ_BLOCK])(SM + SM_RED);
-            if constexpr (!EJ_LDS) __threadfence();     // (column sums this kernel's other lane groups left in the hand-over array)
+            // (column sums this kernel's other lane groups left in the hand-over array: a WORKGROUP-scope release -- the
+            // groups sit on one CU and share its L1.  __threadfence() is a device-scope fence: on this chip an L2 write-back,
+            // with the L2 full of Jacobian lines -- the last 111-species kernel spent 116 k of its 400 k cycles per
+            // wavefront in this epilogue, profiles/r05_phase_ecl.txt)
+            if constexpr (!EJ_LDS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __syncthreads();
             static_for<G_>([&](auto gc) PJR_INL {
                 constexpr int g = decltype(gc)::value;
                 if (grp == g)
                     static_for<LAST>([&](auto jc) PJR_INL {
                         constexpr int j = decltype(jc)::value, o = col_owner(j);
-                        if constexpr (o != g && ELM.slot[j] < 0 && e_live_col(j)) EX[ex_index(j)][g < o ? g : g - 1][tid] = E[j];
+                        constexpr int xi = ex_index(j);
+                        if constexpr (o != g && ELM.slot[j] < 0 && e_live_col(j)) EX[xi][g < o ? g : g - 1][tid] = E[j];
                     });
             });
             RED[0][grp][tid] = H; RED[1][grp][tid] = SCP; RED[2][grp][tid] = SJT; RED[3][grp][tid] = HP; RED[4][grp][tid] = HQ;
@@ -1905,7 +1952,8 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
                 constexpr int g = decltype(gc)::value;
                 static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
-                    ECOL[decltype(jc)::value - group_first_col(g)] = PJQ_LOAD_NT(&scr[(long)(E_COL0 + decltype(jc)::value) * PJQ_TILE]);
+                    constexpr int jl = decltype(jc)::value - group_first_col(g);
+                    ECOL[jl] = PJQ_LOAD_NT(&scr[(long)(E_COL0 + decltype(jc)::value) * PJQ_TILE]);
                 });
             });
             PJQ_SCHED_BARRIER();
@@ -1915,6 +1963,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         // used: gathered in front of the energy row, the sums of 55 columns spill)
         auto ecol = [&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
+            constexpr int jloc = j - group_first_col(col_owner(j));      // (constexpr variables: see ecl_index in k_pre)
             double e = 0.0;
             if constexpr (G_ == 1) {
                 if constexpr (ELM.slot[j] >= 0) e = el[ELM.slot[j] * PJQ_BLOCK]; else e = E[j];
@@ -1927,14 +1976,15 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     });
                 } else if constexpr (e_live_col(j)) {
                     e = E[j];
-                    static_for<G_ - 1>([&](auto qc) PJR_INL { e += EX[ex_index(j)][decltype(qc)::value][tid]; });
+                    constexpr int xi = ex_index(j);
+                    static_for<G_ - 1>([&](auto qc) PJR_INL { e += EX[xi][decltype(qc)::value][tid]; });
                 }
                 // + the column sum that the block of row j finished (w = J v with v in LDS: already in WE)
                 if constexpr (JV_LDS) {}
                 else if constexpr (EJ_LDS) e += SM[SM_EJ + j * PJQ_BLOCK + tid];
-                else e += ECOL[j - group_first_col(col_owner(j))];
+                else e += ECOL[jloc];
             }
-            if constexpr (PJQ_ECL && !ECL_PRO && BCOL.b[j]) e += ECLV[j - group_first_col(col_owner(j))];
+            if constexpr (PJQ_ECL && !ECL_PRO && BCOL.b[j]) e += ECLV[jloc];
             return e;
         };
         // column j + 1 of the energy row (create_jacobian.py:2940-3120)
@@ -1957,7 +2007,8 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             constexpr int g = decltype(gc)::value;
             if (G_ == 1 || grp == g)
                 static_range<group_first_col(g), group_first_col(g + 1)>([&](auto jc) PJR_INL {
-                    w0 += erow(jc) * vv(std::integral_constant<int, decltype(jc)::value + 1>{});
+                    // (erow carries the factor 1 / W_j itself: the plain v_{j+1} = W_j vs_{j+1})
+                    w0 += erow(jc) * (pjs::SP[decltype(jc)::value][1] * vv(std::integral_constant<int, decltype(jc)::value + 1>{}));
                 });
         });
         w0 -= icp * WE;         // (0 unless JV_LDS: erow's term -E_j / (W_j c_p) v_{j+1} of the finished column sums)

@@ -237,9 +237,11 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     check(L.pj_mech_emit_rblk_spec(handle, hdr.encode(), budget, fuse, block, halves, single, r_block, r_clds,
                                    int(rates_per_part or os.environ.get('PJ_RBLK_RATE_GROUPS', 0)), cv, ce, counts))
     nker, nrate, npre = counts[0], counts[1], counts[2]
-    # several lane groups: what a row block cannot see of its column of the energy row is summed once per state by the
-    # pre-pass (PJQ_ECL), so the row kernels carry no long-lived sums
-    ecl = int(os.environ.get('PJ_RBLK_ECL', 1 if halves > 1 else 0))
+    # several lane groups, polynomial K_c (the register-starved 111-species geometry): what a row block cannot see of its
+    # column of the energy row is summed once per state by the pre-pass (PJQ_ECL), so the row kernels carry no long-lived
+    # sums (USC-shaped -3 .. -7 %).  The one-kernel factor-column builds keep their 32 long-lived sums: with the
+    # pre-pass's extra visits they are 6 % SLOWER (GRI-shaped 6.23 -> 6.62 ms, profiles/r05_gri_variants_d.txt)
+    ecl = int(os.environ.get('PJ_RBLK_ECL', 1 if (halves > 1 and not kcf) else 0))
     common = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr, '-I', CSRC,
               '-DPJQ_SUMSETS=%d' % (0 if nker == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1), '-DPJQ_ECL=%d' % ecl] + \
         (['-DPJQ_ECOLS=1'] if (ecols and nker == 1) else [])

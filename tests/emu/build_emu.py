@@ -20,7 +20,7 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     (each one OS thread in the emulation); kcf: equilibrium constants from the per-species factor columns (the header
     must carry the rows: pj_mech_set_kc_factors before it was emitted); single: one row kernel for every block;
     ecl: the energy-row terms a row block cannot see summed by the pre-pass (PJQ_ECL; default as specbuild: with several
-    lane groups); pre_halves: lane groups of the pre-pass (2 needs c_lds)."""
+    lane groups and polynomial K_c); pre_halves: lane groups of the pre-pass (2 needs c_lds)."""
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
     t = open(hdr).read()
@@ -33,7 +33,7 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
         blocks_per_part = nblk
     starts = list(range(0, nblk, blocks_per_part))
     if ecl is None:
-        ecl = 1 if halves > 1 else 0
+        ecl = 1 if (halves > 1 and not kcf) else 0
     common += ['-DPJQ_SUMSETS=%d' % (0 if len(starts) == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(len(starts) == 1),
                '-DPJQ_ECL=%d' % ecl]
     base = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % c_lds, os.path.join(CSRC, 'pj_rblk.hip')]

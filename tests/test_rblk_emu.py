@@ -86,6 +86,9 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6, halves=2)),
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, ecl=0)),
+    # ... and PJQ_ECL with the factor columns: one kernel (the sums land in the EJ columns behind the prologue) and several
+    ('synth_mid24', 40, dict(rates_per_part=40, kcf=1, halves=4, single=1, ecl=1)),
+    ('h2o2_n2', 12, dict(blocks_per_part=2, rates_per_part=5, kcf=1, halves=2, ecl=1)),
     # ONE row kernel with polynomial K_c rows (the 111-species geometry: no LDS room for the finished column sums, which
     # travel through the hand-over array -- PJQ_ECOLS), four lane groups with a cooperative prologue (PJQ_COOP)
     ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
@@ -181,6 +184,8 @@ def test_rblk_kernels_vs_reference_golden(tmp_path_factory, golden):
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1)),
     # two lane groups over several kernels: v in registers, column sums through the hand-over array
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
+    # ... with the pre-pass's column sums (PJQ_ECL) folded into w_0's share behind the prologue
+    ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1, ecl=1)),
     # one kernel, four lane groups, polynomial K_c rows, column sums through the hand-over array
     ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
 ])

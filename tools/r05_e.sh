@@ -1,0 +1,8 @@
+#!/bin/bash
+export TMPDIR=/tmp PJ_VAR_RATES=0
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 900 python tools/rblk_variants.py time pyjac_amd/data/usc2_shaped.inp 200000 rblk ecl $@ > $O/r05_usc_variants_e.txt 2>&1
+cat $O/r05_usc_variants_e.txt
+timeout 600 python tools/jv_time.py pyjac_amd/data/gri30_shaped.inp 1000000 rblk jv2 rblk jv2 > $O/r05_gri_jv.txt 2>&1
+cat $O/r05_gri_jv.txt
