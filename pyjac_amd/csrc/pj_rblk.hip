@@ -112,6 +112,11 @@ using namespace pj;
                             // groups exchange partial sums and each writes its species' concentration columns (the
                             // factor-column builds always; the polynomial K_c builds on request: 4 KB of LDS per 64 states)
 #endif
+#ifndef PJQ_FIN
+#define PJQ_FIN 0           // 1: the energy row is finished by a kernel of its own (k_fin) behind the row kernels instead of in the
+                            // last row kernel's epilogue, whose loads sit behind that kernel's last Jacobian stores (needs the
+                            // column sums in the hand-over array: PJQ_ECOLS, and PJQ_ECL; every translation unit gets the same value)
+#endif
 #ifndef PJQ_DEFER
 #define PJQ_DEFER 0         // 1: the Jacobian rows of block b are stored DURING the visits of block b + 1, a slice behind every
                             // visit, instead of in one burst behind the block's own visits (k_rblk; not the w = J v builds)
@@ -699,9 +704,10 @@ struct Reg { Reg() { pjq_register(0, 1, launch_pre); } } reg_;
 #define PJQ_PLAN 0
 #endif
 constexpr int B0_ = PJQ_B0, B1_ = PJQ_B1;
-constexpr bool FIRST_ = PJQ_FIRST != 0, LASTK_ = PJQ_LAST != 0;
+constexpr bool FIRST_ = PJQ_FIRST != 0, LASTK_ = PJQ_LAST != 0 && !PJQ_FIN;
+static_assert(!PJQ_FIN || (PJQ_ECOLS && PJQ_ECL && PJQ_HALVES > 1), "PJQ_FIN: column sums and the pre-pass's sums in the hand-over array");
 static_assert(!PJQ_KCF || pjs::KCF_OK, "PJQ_KCF needs the per-species factor rows (pj_mech_set_kc_factors)");
-static_assert(!PJQ_SINGLE || (FIRST_ && LASTK_), "PJQ_SINGLE: one row kernel");
+static_assert(!PJQ_SINGLE || (FIRST_ && (LASTK_ || PJQ_FIN)), "PJQ_SINGLE: one row kernel");
 constexpr KcMap make_kcmap()
 {
     KcMap m{};
@@ -2060,6 +2066,108 @@ struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_JV ? 6 : PJQ_PAIR ? 2 : 4, launch_
 struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_JV ? 6 : PJQ_PAIR ? 2 : 4, launch_part); } } reg_;   // 2: pair stores, 4: general, 6: w = J v
 #endif
 #endif  // PJQ_PART == 2
+
+#if PJQ_PART == 4
+// ------------------------------------------------------------------------------------------
+// k_fin: the energy row (row 0 of the Jacobian) from what the row kernels and k_pre left in the hand-over array
+// ------------------------------------------------------------------------------------------
+// In the last row kernel's epilogue the loads of the column sums sit behind that kernel's last Jacobian stores (one
+// in-order vmcnt queue), its workgroups keep their CU until the store queue has drained, and the lane groups wait for
+// the slowest: 95 .. 110 k of the 280 k cycles of the last 111-species kernel.  As a kernel of its own -- one state per
+// lane, 2.4 KB read and 888 bytes written per 111-species state -- it costs a fraction of that, and every row kernel ends
+// right behind its last store.  create_jacobian.py:2940-3120 (energy row), 1853-1905 (jac[0]).
+#ifndef PJQ_NKER        // row kernels of the library: from the kernel plan unless given (tests)
+#define PJQ_NKER pjs::NKER
+#endif
+constexpr int G_ = PJQ_HALVES;
+constexpr int NKER_ = PJQ_NKER;
+constexpr int SUM_FIN = pjs::NSCQ + (NKER_ % 2) * NSUM;      // the slot set the last row kernel wrote
+#ifdef PJR_HOST_EMU
+constexpr int FINB = 1;         // (the emulation runs a one-thread workgroup inline)
+#else
+constexpr int FINB = 256;
+#endif
+__global__ void __launch_bounds__(FINB) k_fin(PjqArgs A)
+{
+    long s = (long)blockIdx.x * FINB + (long)threadIdx.x;
+    const bool valid = s < A.n;
+    if (!valid) s = A.n - 1;
+    const double* const scr = scr_of(A, s);
+    State L;
+    load_state(A, s, L);
+    double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
+    static_for<G_>([&](auto gc) PJR_INL {
+        const long hset = (long)decltype(gc)::value * (2 * NSUM) * PJQ_TILE;
+        H += scr[hset + (long)SUM_FIN * PJQ_TILE];
+        SCP += scr[hset + (long)(SUM_FIN + 1) * PJQ_TILE];
+        SJT += scr[hset + (long)(SUM_FIN + 2) * PJQ_TILE];
+        HP += scr[hset + (long)(SUM_FIN + 3) * PJQ_TILE];
+        HQ += scr[hset + (long)(SUM_FIN + 4) * PJQ_TILE];
+    });
+    to_conc(L);
+    const double T = L.T, invrho = L.invrho;
+    auto cp_of = [&](auto kc, double& cpm, double& dcpm) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        const bool lo = T <= pjs::SP[k][2];
+        double a[5];
+        static_for<5>([&](auto cc) PJR_INL {
+            constexpr int c = decltype(cc)::value;
+            a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
+        });
+        cpm = a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T)));
+        dcpm = a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T));
+    };
+    // rate_subs.py:2171-2335 / create_jacobian.py:2940-3120: mass-fraction weighted c_p sums from the concentrations
+    double cpa = 0.0, dcpa = 0.0, cpN = 0.0;
+    static_for<NSP>([&](auto kc) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        double cpm, dcpm;
+        cp_of(kc, cpm, dcpm);
+        cpa += L.C[k] * cpm;
+        dcpa += L.C[k] * dcpm;
+        if constexpr (k == LAST) cpN = (RU_ * pjs::SP[k][0]) * cpm;
+    });
+    const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
+    const double icp = 1.0 / cpavg;
+    const double rho_e = 1.0 / invrho;
+    const double e0 = -(SCP - (dcpavg * icp) * H + rho_e * SJT) / (rho_e * cpavg);
+    auto erow = [&](auto jc) PJR_INL {
+        constexpr int j = decltype(jc)::value;
+        double e = scr[(long)(E_COL0 + j) * PJQ_TILE];
+        if constexpr (BCOL.b[j]) {
+            constexpr int ci = ecl_index(j);
+            e += scr[(long)(ECL0 + ci) * PJQ_TILE];
+        }
+        double cpm, dcpm;
+        cp_of(jc, cpm, dcpm);
+        const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
+        return -((HP + e) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
+    };
+#if PJQ_JV
+    const double* vp = A.v + s * A.v_ss;
+    double w0 = e0 * vp[0];
+    static_for<LAST>([&](auto jc) PJR_INL { w0 += erow(jc) * vp[(decltype(jc)::value + 1) * A.v_si]; });
+    if (valid) (A.w + s * A.w_ss)[0] = w0;
+#else
+    double* const J = A.jac + s * A.j_ss;
+    if (valid) PJQ_STORE(&J[0], e0);
+    static_for<LAST>([&](auto jc) PJR_INL {
+        const double v = erow(jc);
+        if (valid) PJQ_STORE(&J[(long)(NSP * (decltype(jc)::value + 1)) * A.j_si], v);
+    });
+#endif
+}
+void launch_fin(const PjqArgs& A, void* stream)
+{
+    hipLaunchKernelGGL(k_fin, dim3((unsigned)((A.n + FINB - 1) / FINB)), dim3(FINB), 0, (hipStream_t)stream, A);
+}
+// behind the row kernels of its kind (2: pair stores, 4: general -- the same kernel --, 6: w = J v)
+#if PJQ_JV
+struct Reg { Reg() { pjq_register(NKER_, 6, launch_fin); } } reg_;
+#else
+struct Reg { Reg() { pjq_register(NKER_, 2, launch_fin); pjq_register(NKER_, 4, launch_fin); } } reg_;
+#endif
+#endif  // PJQ_PART == 4
 
 #if PJQ_PART == 3
 // ------------------------------------------------------------------------------------------

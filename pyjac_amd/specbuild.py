@@ -23,7 +23,7 @@ SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rblk': ('pj_rblk.hip', 'pj_mat
 # environment overrides that shape a binary (experiments): part of the digest
 ENV = ('PJ_LANE_FLAGS', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE', 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES',
        'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST', 'PJ_RBLK_RATE_GROUPS', 'PJ_RBLK_RATE_DEFINES',
-       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV', 'PJ_RBLK_ECL', 'PJ_RBLK_WIDE')
+       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV', 'PJ_RBLK_ECL', 'PJ_RBLK_WIDE', 'PJ_RBLK_FIN')
 
 # reciprocal instead of IEEE division sequences, contraction, no -0 special-casing; NO reassociation (it keeps
 # every product of an accumulation chain live: +40 AGPRs, -5 %); measured on MI355X against -ffast-math and
@@ -242,9 +242,12 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     # sums (USC-shaped -3 .. -7 %).  The one-kernel factor-column builds keep their 32 long-lived sums: with the
     # pre-pass's extra visits they are 6 % SLOWER (GRI-shaped 6.23 -> 6.62 ms, profiles/r05_gri_variants_d.txt)
     ecl = int(os.environ.get('PJ_RBLK_ECL', 1 if (halves > 1 and not kcf) else 0))
+    # ... and the energy row is finished by a kernel of its own (PJQ_FIN: k_fin) when its column sums travel through the
+    # hand-over array anyway (several row kernels, or one without LDS room for them)
+    fin = int(os.environ.get('PJ_RBLK_FIN', 1 if (ecl and halves > 1 and (nker > 1 or ecols)) else 0))
     common = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr, '-I', CSRC,
-              '-DPJQ_SUMSETS=%d' % (0 if nker == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1), '-DPJQ_ECL=%d' % ecl] + \
-        (['-DPJQ_ECOLS=1'] if (ecols and nker == 1) else [])
+              '-DPJQ_SUMSETS=%d' % (0 if (nker == 1 and not fin) else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1), '-DPJQ_ECL=%d' % ecl,
+              '-DPJQ_FIN=%d' % fin] + (['-DPJQ_ECOLS=1'] if (ecols and nker == 1) else [])
     flags = os.environ.get('PJ_RBLK_FLAGS', RBLK_FLAGS).split()
     src = os.path.join(CSRC, 'pj_rblk.hip')
     # (the 111-species kernels are short of registers: without the one-visit look-ahead of the K_c rows and
@@ -272,6 +275,10 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
             jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=%d' % pair], 'rblk%d_%d.o' % (i, pair)))
         if not os.environ.get('PJ_RBLK_NO_JV'):     # (experiments: skip the w = J v build)
             jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % i))
+    if fin:
+        jobs.append((rblk + ['-DPJQ_PART=4'], 'fin.o'))
+        if not os.environ.get('PJ_RBLK_NO_JV'):
+            jobs.append((rblk + ['-DPJQ_PART=4', '-DPJQ_JV=1'], 'fin_jv.o'))
     for i in range(nrate):
         for full in (0, 1):
             jobs.append((rate + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % i, '-DPJQ_FULL=%d' % full], 'rate%d_%d.o' % (i, full)))

@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
 
 def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int = 128, c_lds: int = 0,
                opt: str = '-O1', defines=(), halves: int = 1, kcf: int = 0, single: int = 0, ecl: int = None,
-               pre_halves: int = 1) -> str:
+               pre_halves: int = 1, fin: int = None) -> str:
     """csrc/pj_rblk.hip for the host: row blocks that rebuild their rates + falloff / PLOG pre-pass (k_pre,
     k_rblk, also as w = J v) and the rate-output kernels (k_rate, one per `rates_per_part` reactions, with and
     without the per-reaction outputs), the way specbuild.build_rblk links them.  halves: lane groups of the row kernels
@@ -34,8 +34,11 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     starts = list(range(0, nblk, blocks_per_part))
     if ecl is None:
         ecl = 1 if (halves > 1 and not kcf) else 0
-    common += ['-DPJQ_SUMSETS=%d' % (0 if len(starts) == 1 else 2 * halves), '-DPJQ_SINGLE=%d' % int(len(starts) == 1),
-               '-DPJQ_ECL=%d' % ecl]
+    ecols = any('PJQ_ECOLS=1' in d for d in defines)
+    if fin is None:         # (as specbuild: a kernel of its own for the energy row when its column sums are in the hand-over array)
+        fin = int(bool(ecl) and halves > 1 and (len(starts) > 1 or ecols))
+    common += ['-DPJQ_SUMSETS=%d' % (0 if (len(starts) == 1 and not fin) else 2 * halves), '-DPJQ_SINGLE=%d' % int(len(starts) == 1),
+               '-DPJQ_ECL=%d' % ecl, '-DPJQ_FIN=%d' % fin]
     base = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % c_lds, os.path.join(CSRC, 'pj_rblk.hip')]
     rblk = base + ['-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf]
     jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
@@ -48,6 +51,9 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
         jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % n, '-DPJQ_B0=%d' % b0,
                              '-DPJQ_B1=%d' % min(nblk, b0 + blocks_per_part), '-DPJQ_FIRST=%d' % (n == 0),
                              '-DPJQ_LAST=%d' % (n == len(starts) - 1), '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % n))
+    if fin:
+        jobs.append((rblk + ['-DPJQ_PART=4', '-DPJQ_NKER=%d' % len(starts)], 'fin.o'))
+        jobs.append((rblk + ['-DPJQ_PART=4', '-DPJQ_NKER=%d' % len(starts), '-DPJQ_JV=1'], 'fin_jv.o'))
     rstarts = list(range(0, nrxn, rates_per_part))
     for n, r0 in enumerate(rstarts):
         for full in (0, 1):
