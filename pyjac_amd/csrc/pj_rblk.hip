@@ -2093,8 +2093,6 @@ __global__ void __launch_bounds__(FINB) k_fin(PjqArgs A)
     const bool valid = s < A.n;
     if (!valid) s = A.n - 1;
     const double* const scr = scr_of(A, s);
-    State L;
-    load_state(A, s, L);
     double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
     static_for<G_>([&](auto gc) PJR_INL {
         const long hset = (long)decltype(gc)::value * (2 * NSUM) * PJQ_TILE;
@@ -2104,33 +2102,61 @@ __global__ void __launch_bounds__(FINB) k_fin(PjqArgs A)
         HP += scr[hset + (long)(SUM_FIN + 3) * PJQ_TILE];
         HQ += scr[hset + (long)(SUM_FIN + 4) * PJQ_TILE];
     });
-    to_conc(L);
-    const double T = L.T, invrho = L.invrho;
-    auto cp_of = [&](auto kc, double& cpm, double& dcpm) PJR_INL {
+    const double* const y = A.y + s * A.y_ss;
+    const double T = y[0], p = A.pres[s];
+    // (Tc: the temperature, or an opaque copy of it -- the range-selected coefficients of a species are wanted twice, in the
+    // c_p sums and in the species' column; as common subexpressions they are kept from the first use to the second,
+    // 5 NSP doubles: 4.3 KB of scratch memory per lane)
+    auto cp_of = [&](auto kc, const double Tc, double& cpm, double& dcpm) PJR_INL {
         constexpr int k = decltype(kc)::value;
-        const bool lo = T <= pjs::SP[k][2];
+        const bool lo = Tc <= pjs::SP[k][2];
         double a[5];
         static_for<5>([&](auto cc) PJR_INL {
             constexpr int c = decltype(cc)::value;
             a[c] = lo ? pjs::SP[k][4 + c] : pjs::SP[k][11 + c];
         });
-        cpm = a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T)));
-        dcpm = a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T));
+        cpm = a[0] + Tc * (a[1] + Tc * (a[2] + Tc * (a[3] + a[4] * Tc)));
+        dcpm = a[1] + Tc * (2.0 * a[2] + Tc * (3.0 * a[3] + 4.0 * a[4] * Tc));
     };
-    // rate_subs.py:2171-2335 / create_jacobian.py:2940-3120: mass-fraction weighted c_p sums from the concentrations
-    double cpa = 0.0, dcpa = 0.0, cpN = 0.0;
-    static_for<NSP>([&](auto kc) PJR_INL {
+    // eval_conc (rate_subs.py:1625-1710) and the mass-fraction weighted c_p sums (rate_subs.py:2171-2335,
+    // create_jacobian.py:2940-3120) in one pass over the mass fractions -- sum_k C_k c_p,k = rho sum_k (Y_k / W_k) c_p,k:
+    // nothing per species is kept
+    double sumY = 0.0, sumYW = 0.0, cps = 0.0, dcps = 0.0;
+    static_for<LAST>([&](auto kc) PJR_INL {
         constexpr int k = decltype(kc)::value;
+        const double yk = y[(k + 1) * A.y_si];
         double cpm, dcpm;
-        cp_of(kc, cpm, dcpm);
-        cpa += L.C[k] * cpm;
-        dcpa += L.C[k] * dcpm;
-        if constexpr (k == LAST) cpN = (RU_ * pjs::SP[k][0]) * cpm;
+        cp_of(kc, T, cpm, dcpm);
+        const double yw = yk * pjs::SP[k][0];
+        sumY += yk;
+        sumYW += yw;
+        cps += yw * cpm;
+        dcps += yw * dcpm;
+        if constexpr (k % 8 == 7) PJQ_SCHED_BARRIER();
     });
+    double cpN;
+    {
+        double cpm, dcpm;
+        cp_of(std::integral_constant<int, LAST>{}, T, cpm, dcpm);
+        const double yw = (1.0 - sumY) * pjs::SP[LAST][0];
+        sumYW += yw;
+        cps += yw * cpm;
+        dcps += yw * dcpm;
+        cpN = (RU_ * pjs::SP[LAST][0]) * cpm;
+    }
+    const double Wbar = 1.0 / sumYW;
+    const double rho = p * Wbar / (RU_ * T);
+    const double invrho = 1.0 / rho;
+    const double cpa = rho * cps, dcpa = rho * dcps;
     const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
     const double icp = 1.0 / cpavg;
     const double rho_e = 1.0 / invrho;
     const double e0 = -(SCP - (dcpavg * icp) * H + rho_e * SJT) / (rho_e * cpavg);
+    PJQ_SCHED_BARRIER();        // (the concentrations are dead from here on)
+    double Te = T;
+#ifndef PJR_HOST_EMU
+    asm volatile("" : "+v"(Te));
+#endif
     auto erow = [&](auto jc) PJR_INL {
         constexpr int j = decltype(jc)::value;
         double e = scr[(long)(E_COL0 + j) * PJQ_TILE];
@@ -2139,14 +2165,17 @@ __global__ void __launch_bounds__(FINB) k_fin(PjqArgs A)
             e += scr[(long)(ECL0 + ci) * PJQ_TILE];
         }
         double cpm, dcpm;
-        cp_of(jc, cpm, dcpm);
+        cp_of(jc, Te, cpm, dcpm);
         const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
         return -((HP + e) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
     };
 #if PJQ_JV
     const double* vp = A.v + s * A.v_ss;
     double w0 = e0 * vp[0];
-    static_for<LAST>([&](auto jc) PJR_INL { w0 += erow(jc) * vp[(decltype(jc)::value + 1) * A.v_si]; });
+    static_for<LAST>([&](auto jc) PJR_INL {
+        w0 += erow(jc) * vp[(decltype(jc)::value + 1) * A.v_si];
+        if constexpr (decltype(jc)::value % 8 == 7) PJQ_SCHED_BARRIER();
+    });
     if (valid) (A.w + s * A.w_ss)[0] = w0;
 #else
     double* const J = A.jac + s * A.j_ss;
@@ -2154,6 +2183,9 @@ __global__ void __launch_bounds__(FINB) k_fin(PjqArgs A)
     static_for<LAST>([&](auto jc) PJR_INL {
         const double v = erow(jc);
         if (valid) PJQ_STORE(&J[(long)(NSP * (decltype(jc)::value + 1)) * A.j_si], v);
+        // (eight columns' loads in flight at a time: left alone the scheduler requests all 2 (NSP - 1) sums up front and
+        // keeps them, next to the NSP concentrations, in 4 KB of scratch memory per lane)
+        if constexpr (decltype(jc)::value % 8 == 7) PJQ_SCHED_BARRIER();
     });
 #endif
 }

@@ -244,7 +244,11 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     ecl = int(os.environ.get('PJ_RBLK_ECL', 1 if (halves > 1 and not kcf) else 0))
     # ... and the energy row is finished by a kernel of its own (PJQ_FIN: k_fin) when its column sums travel through the
     # hand-over array anyway (several row kernels, or one without LDS room for them)
-    fin = int(os.environ.get('PJ_RBLK_FIN', 1 if (ecl and halves > 1 and (nker > 1 or ecols)) else 0))
+    # (measured, round 5: NOT the default -- with the workgroup-scope fence the last kernel's epilogue is 95 k of 1 280 k cycles
+    # per wavefront and step, and k_fin as written keeps 2.5 KB of scratch memory per lane: USC-shaped 4.98 -> 6.08 ms)
+    fin = int(os.environ.get('PJ_RBLK_FIN', 0))
+    if fin and not (ecl and halves > 1 and (nker > 1 or ecols)):
+        raise ValueError('PJ_RBLK_FIN=1 needs PJQ_ECL, several lane groups and the column sums in the hand-over array')
     common = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-DPJS_HEADER="%s"' % hdr, '-I', CSRC,
               '-DPJQ_SUMSETS=%d' % (0 if (nker == 1 and not fin) else 2 * halves), '-DPJQ_SINGLE=%d' % int(nker == 1), '-DPJQ_ECL=%d' % ecl,
               '-DPJQ_FIN=%d' % fin] + (['-DPJQ_ECOLS=1'] if (ecols and nker == 1) else [])

@@ -86,9 +86,11 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6, halves=2)),
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, ecl=0)),
-    # (with PJQ_ECL and the column sums in the hand-over array the energy row is finished by k_fin, a kernel of its own --
-    # the default of the cases above; here: the last row kernel's epilogue instead)
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, fin=0)),
+    # PJQ_FIN: the energy row finished by k_fin, a kernel of its own behind the row kernels (several kernels; one kernel whose
+    # column sums travel through the hand-over array)
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, fin=1)),
+    ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, fin=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
+    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2, fin=1)),
     # ... and PJQ_ECL with the factor columns: one kernel (the sums land in the EJ columns behind the prologue) and several
     ('synth_mid24', 40, dict(rates_per_part=40, kcf=1, halves=4, single=1, ecl=1)),
     ('h2o2_n2', 12, dict(blocks_per_part=2, rates_per_part=5, kcf=1, halves=2, ecl=1)),
@@ -191,6 +193,8 @@ def test_rblk_kernels_vs_reference_golden(tmp_path_factory, golden):
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1, ecl=1)),
     # one kernel, four lane groups, polynomial K_c rows, column sums through the hand-over array
     ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
+    # ... and w_0 finished by k_fin
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, fin=1)),
 ])
 def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
     """N2 for the row-block family: w = J v per state with the Jacobian consumed in registers
