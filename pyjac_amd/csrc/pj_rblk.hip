@@ -186,6 +186,9 @@ struct PjqArgs {
     double *conc, *fwd, *rev, *pres_mod, *spec_rates, *dy; long o_ld;
     long fwd_ld, rev_ld, pm_ld;
     double* sr; long sr_ld;
+    // PJQ_TILE again, as a run-time value: slot offsets of the hand-over array formed with it are scalar arithmetic the
+    // optimiser cannot fold into the per-lane address (k_rblk: ScrRef)
+    long tile_rt;
 };
 typedef void (*pjq_launch_fn)(const PjqArgs&, void* stream);
 extern "C" void pjq_register(int id, int kind, pjq_launch_fn fn);
@@ -866,6 +869,17 @@ constexpr int SM_RED = SM_EX + NEX * (G_ - 1) * PJQ_BLOCK;
 constexpr int SM_EPI = SM_EPI_SIZE ? SM_EX + SM_EPI_SIZE : 0;
 constexpr int SM_DOUBLES = SM_MAIN > SM_EPI ? SM_MAIN : SM_EPI;
 static_assert(SM_DOUBLES * 8 <= 160 * 1024, "LDS: columns of PJQ_BLOCK states do not fit");
+// Per-state scalars that every visit of every block reads -- 1 / T, ln T, T, 1 / rho, Wbar / rho, p / (R T) -- are kernel-long
+// values, and in a kernel that is short of registers exactly those are what the allocator parks in scratch memory
+// (reloaded at every visit, each reload behind every Jacobian store issued before it).  Whatever LDS is left over holds a
+// column of each (in that order, as many as fit): they are re-read at every row block through an opaque offset, so no block
+// inherits them in registers.
+#ifndef PJQ_PARK
+#define PJQ_PARK 0           // (measured, round 5: no gain -- USC-shaped 4.99 -> 5.24 ms, GRI-shaped 5.93 -> 6.00 ms with it; kept as a build option)
+#endif
+constexpr int NPARK = (160 * 1024 / 8 - SM_DOUBLES) / PJQ_BLOCK < PJQ_PARK ? (160 * 1024 / 8 - SM_DOUBLES) / PJQ_BLOCK : PJQ_PARK;
+constexpr int SM_PS = SM_DOUBLES;
+constexpr int SM_TOTAL = SM_DOUBLES + NPARK * PJQ_BLOCK;
 // which columns' sums live in LDS: those with the most structural non-zeros (the most updates)
 constexpr int col_nnz(int j)
 {
@@ -902,7 +916,7 @@ constexpr int ex_index(int j)
 
 __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 {
-    __shared__ __attribute__((aligned(16))) double SM[SM_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double SM[SM_TOTAL];
     // Concentrations live in LDS, one column per lane (bank-conflict free)
     double (*const CL)[PJQ_BLOCK] = (double (*)[PJQ_BLOCK])(SM + SM_CL);
     // NASA row pairs of every K_c group (the low / high range select is per lane)
@@ -1142,21 +1156,34 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     // powers of T for the K_c polynomials (sum-of-products form: no dependent Horner chain)
     double T2 = T * T, T3 = T2 * T, T4 = T2 * T2;
     double T2d = 2.0 * T2, T3d = 3.0 * T3, T4d = 4.0 * T4;
-    const double WR = Wbar * invrho;
+    double WR = Wbar * invrho;
+    // (every lane group writes the same values: no barrier, a wavefront reads what it -- or a twin -- wrote)
+    if constexpr (NPARK > 0) SM[SM_PS + tid] = invT;
+    if constexpr (NPARK > 1) SM[SM_PS + PJQ_BLOCK + tid] = logT;
+    if constexpr (NPARK > 2) SM[SM_PS + 2 * PJQ_BLOCK + tid] = T;
+    if constexpr (NPARK > 3) SM[SM_PS + 3 * PJQ_BLOCK + tid] = invrho;
+    if constexpr (NPARK > 4) SM[SM_PS + 4 * PJQ_BLOCK + tid] = WR;
+    if constexpr (NPARK > 5) SM[SM_PS + 5 * PJQ_BLOCK + tid] = mconc;
     // A DS instruction reaches 64 KB from its address register; the columns of a 53-species mechanism
     // span 106 KB.  Left alone the compiler keeps one address VGPR per column beyond the first 64 KB;
     // an opaque zero offset per 32-column group gives it one base per group instead.
     constexpr int CGRP = 65536 / (8 * PJQ_BLOCK) > 0 ? 65536 / (8 * PJQ_BLOCK) : 1;
     constexpr int NCG = (NSP + CGRP - 1) / CGRP;
+    // (the bases are derived anew at every row block -- rebase() below: as kernel-long values they are what the register
+    // allocator parks in scratch memory first, reloaded at every visit: 2 900 reloads in the w = J v kernel of the 53-species
+    // mechanism, round 5)
     const double* clb[NCG];
-    static_for<NCG>([&](auto gc) PJR_INL {
-        constexpr int g = decltype(gc)::value;
-        unsigned zo = 0;
+    auto rebase_c = [&]() PJR_INL {
+        static_for<NCG>([&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            unsigned zo = 0;
 #ifndef PJR_HOST_EMU
-        if constexpr (g > 0) asm volatile("" : "+v"(zo));
+            if constexpr (g > 0) asm volatile("" : "+v"(zo));
 #endif
-        clb[g] = (const double*)((const char*)&CL[g * CGRP][tid] + zo);
-    });
+            clb[g] = (const double*)((const char*)&CL[g * CGRP][tid] + zo);
+        });
+    };
+    rebase_c();
     unsigned vzo = 0;      // opaque zero, renewed per visit (PJQ_CONC_OPAQUE): see the visit loop
     auto conc = [&](auto spc) PJR_INL {
         constexpr int sp = decltype(spc)::value;
@@ -1169,15 +1196,18 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     constexpr int NXG = (NSP + XGRP - 1) / XGRP;
     const d2* xtb[NXG];
     const d2* ixtb[NXG];
-    static_for<NXG>([&](auto gc) PJR_INL {
-        constexpr int g = decltype(gc)::value;
-        unsigned z0 = 0, z1 = 0;
+    auto rebase_x = [&]() PJR_INL {
+        static_for<NXG>([&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value;
+            unsigned z0 = 0, z1 = 0;
 #ifndef PJR_HOST_EMU
-        asm volatile("" : "+v"(z0), "+v"(z1));
+            asm volatile("" : "+v"(z0), "+v"(z1));
 #endif
-        xtb[g] = (const d2*)((const char*)&XT[g * XGRP][tid] + z0);
-        ixtb[g] = (const d2*)((const char*)&IXT[g * XGRP][tid] + z1);
-    });
+            xtb[g] = (const d2*)((const char*)&XT[g * XGRP][tid] + z0);
+            ixtb[g] = (const d2*)((const char*)&IXT[g * XGRP][tid] + z1);
+        });
+    };
+    rebase_x();
     // {X_k or 1 / X_k, t_k} of net species q of reaction i: a product (nu > 0) divides K_c's inverse
     auto factor = [&](auto ic, auto qc) PJR_INL {
         constexpr int i = decltype(ic)::value, q = pjs::RI[i][RI_NET_PTR] + decltype(qc)::value;
@@ -1256,7 +1286,37 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
     double E[LAST > 0 ? LAST : 1];
     double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
-    const double* const scr = scr_of(A, s);
+    // this lane's column of the hand-over array: a wavefront-uniform 64-bit base (the first lane's address: scalar
+    // registers, slot offsets by scalar arithmetic) + a 32-bit per-lane byte offset -- as a per-lane 64-bit pointer it is a
+    // kernel-long register pair that the allocator parks in scratch memory and reloads in front of every hand-over load
+    // (and two vector additions per access)
+    // (idx = slot * PJQ_TILE at every call site; the slot is multiplied by the RUN-TIME tile size -- with the constant the
+    // optimiser folds base + off into one per-lane 64-bit address again and adds the slot offsets with vector arithmetic)
+    struct ScrRef {
+        double* base;
+        unsigned off;
+        long tile;
+        __device__ __forceinline__ double& operator[](const long idx) const
+        {
+            return *(double*)((char*)(base + (idx / PJQ_TILE) * tile + (idx % PJQ_TILE)) + off);
+        }
+    };
+    ScrRef scr;
+    scr.tile = A.tile_rt;
+    {
+        double* const mine = scr_of(A, s);
+#ifdef PJR_HOST_EMU
+        scr.base = mine;
+        scr.off = 0u;
+#else
+        // (pointer arithmetic on the kernel argument with a SCALAR state index: the address space survives -- rebuilt from
+        // readfirstlane'd integer halves the pointer is a flat one, and flat loads count on lgkmcnt as well)
+        const long sw_ = ((long)__builtin_amdgcn_readfirstlane((int)((unsigned long)s >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s);
+        scr.base = scr_of(A, sw_);
+        scr.off = (unsigned)((mine - scr.base) * 8);
+#endif
+    }
     const long hset = (long)grp * (2 * NSUM) * PJQ_TILE;      // this group's pair of slot sets
     // (sums that live in LDS: this lane's slot of column j is el[ELM.slot[j] * PJQ_BLOCK])
     double* const el = SM + SM_EL + (long)grp * NEL_ * PJQ_BLOCK + tid;
@@ -1380,11 +1440,30 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         // otherwise computed once, in front of the group branches, and kept)
         if constexpr ((b - LO_) % PJQ_LAUNDER_EVERY == 0 && (b != LO_ || G_ > 1))
         {
+#ifndef PJQ_NO_REBASE
+            rebase_c();
+#if PJQ_KCF
+            rebase_x();
+#endif
+#endif
             // (the powers of T are REBUILT from the opaque copy, six multiplications per block: as opaque copies of their own
             // they are six more per-state values that live through the whole kernel, and in the kernels that are short of
             // registers exactly those are kept in scratch memory and reloaded at every visit -- each reload behind every
             // Jacobian store issued before it: 2 900 reloads in the first kernel of a 64-state / four-group USC-shaped build)
-            asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT));
+            if constexpr (NPARK > 0) {
+                unsigned pzo = 0;
+                asm volatile("" : "+v"(pzo));
+                const double* const ps = (const double*)((const char*)(SM + SM_PS + tid) + pzo);
+                invT = ps[0];
+                if constexpr (NPARK > 1) logT = ps[PJQ_BLOCK];
+                if constexpr (NPARK > 2) T = ps[2 * PJQ_BLOCK];
+                if constexpr (NPARK > 3) invrho = ps[3 * PJQ_BLOCK];
+                if constexpr (NPARK > 4) WR = ps[4 * PJQ_BLOCK];
+                if constexpr (NPARK > 5) mconc = ps[5 * PJQ_BLOCK];
+            }
+            if constexpr (NPARK == 0) asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT));
+            else if constexpr (NPARK == 1) asm volatile("" : "+v"(T), "+v"(logT));
+            else if constexpr (NPARK == 2) asm volatile("" : "+v"(T));
             T2 = T * T; T3 = T2 * T; T4 = T2 * T2;
             T2d = 2.0 * T2; T3d = 3.0 * T3; T4d = 4.0 * T4;
         }
@@ -1845,7 +1924,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #endif
                 else if constexpr (EJ_LDS && PJQ_ECL && BCOL.b[k < LAST ? k : 0]) SM[SM_EJ + k * PJQ_BLOCK + tid] += EA[r];
                 else if constexpr (EJ_LDS) SM[SM_EJ + k * PJQ_BLOCK + tid] = EA[r];
-                else PJQ_STORE(&scr_of(A, s)[(long)(E_COL0 + k) * PJQ_TILE], EA[r]);
+                else PJQ_STORE(&scr[(long)(E_COL0 + k) * PJQ_TILE], EA[r]);
             }
         });
 #endif
@@ -1863,18 +1942,17 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     // ---- energy row: partial sums travel from kernel to kernel through hand-over slots (stored here,
     //      loaded in the next kernel's prologue); the last kernel turns them into d(dT/dt)/d. ----
     if constexpr (!LASTK_) {
-        double* const sw = scr_of(A, s) + hset;
-        sw[(long)SUM_OUT * PJQ_TILE] = H;
-        sw[(long)(SUM_OUT + 1) * PJQ_TILE] = SCP;
-        sw[(long)(SUM_OUT + 2) * PJQ_TILE] = SJT;
-        sw[(long)(SUM_OUT + 3) * PJQ_TILE] = HP;
-        sw[(long)(SUM_OUT + 4) * PJQ_TILE] = HQ;
+        scr[hset + (long)SUM_OUT * PJQ_TILE] = H;
+        scr[hset + (long)(SUM_OUT + 1) * PJQ_TILE] = SCP;
+        scr[hset + (long)(SUM_OUT + 2) * PJQ_TILE] = SJT;
+        scr[hset + (long)(SUM_OUT + 3) * PJQ_TILE] = HP;
+        scr[hset + (long)(SUM_OUT + 4) * PJQ_TILE] = HQ;
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
             if constexpr (e_live_col(j)) {
-                if constexpr (ELM.slot[j] >= 0) sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = el[ELM.slot[j] * PJQ_BLOCK];
-                else sw[(long)(SUM_OUT + 5 + j) * PJQ_TILE] = E[j];
+                if constexpr (ELM.slot[j] >= 0) scr[hset + (long)(SUM_OUT + 5 + j) * PJQ_TILE] = el[ELM.slot[j] * PJQ_BLOCK];
+                else scr[hset + (long)(SUM_OUT + 5 + j) * PJQ_TILE] = E[j];
             }
 #endif
         });
@@ -2662,6 +2740,7 @@ static int run_batch(Ctx& C, long n, const double* pres, const double* y, long y
         void* st = S > 1 ? (void*)C.streams[b] : stream;
         PjqArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jv ? nullptr : jac + s0 * j_ss, j_si, j_ss, C.scr[b], sum_last,
                   jv ? v + s0 * v_ss : nullptr, v_si, v_ss, jv ? w + s0 * w_ss : nullptr, w_si, w_ss};
+        A.tile_rt = PJQ_TILE;
         const bool fast = fast_ok && m >= PJQ_BLOCK;
         if (!jv && !fast && !have_gen) return -5;
         if (g_pre) g_pre(A, st);
