@@ -100,9 +100,19 @@ def cpu_baseline(w, tables, target_seconds=16.0):
             dt = time.perf_counter() - t0
         return passes * nn / dt, passes, dt
     n1 = max(256, n // 16)
-    r1, p1, t1 = rate(1, target_seconds * 0.4, n1)
-    rN, pN, tN = rate(cores, target_seconds * 0.6, n)
+    r1, p1, t1 = rate(1, target_seconds * 0.3, n1)
+    rN, pN, tN = rate(cores, target_seconds * 0.45, n)
+    # the reference's CPU arm sweeps OpenMP thread counts 1, 2, 4 ... ncpu (performance_tester.py:276-283): the counts
+    # between 1 and all cores, on what is left of the time budget
+    mid, t = [], 2
+    while t < cores:
+        mid.append(t)
+        t *= 2
+    sweep = {1: r1, cores: rN}
+    for t in mid:
+        sweep[t] = rate(t, target_seconds * 0.25 / max(len(mid), 1), max(n1, min(n, n1 * t)))[0]
     return dict(value=rN, unit='Jacobians/s', cores=cores, kind=kind, one_thread=r1, cpu=cpu_model(),
+                thread_sweep={str(k): sweep[k] for k in sorted(sweep)},
                 sample='%d passes over %d states on %d threads (%.1f s) and %d passes over %d states on 1 thread '
                        '(%.1f s) of the same synthetic distribution, OpenMP parallel-for over states'
                        % (pN, n, cores, tN, p1, n1, t1))

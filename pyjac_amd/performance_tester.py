@@ -16,7 +16,8 @@ read_initial_conditions.cu:9-59).
   finite-difference Jacobian (``finite_diffs``, :280-296), appended as ``"N,milliseconds"`` lines to
   ``cuda_nco_nosmem_{ajac|fd}_-1_output.txt`` -- the file the reference's plotting scripts read (:388-397).
   The reference's CPU arm sweeps OpenMP thread counts 1, 2, 4 ... ncpu at the full batch (:276-283); its
-  counterpart here is bench.py's ``cpu_baseline`` (pyJac's generated C at 1 thread and at all cores).
+  counterpart here is bench.py's ``cpu_baseline`` (pyJac's generated C at 1, 2, 4 ... and all usable cores:
+  ``cpu_baseline.thread_sweep``).
 
     python -m pyjac_amd.performance_tester --mech mech.inp --data data.bin --num 1000000
     python -m pyjac_amd.performance_tester --mech mech.inp --data data.bin --num 1000000 --sweep [--fd]
