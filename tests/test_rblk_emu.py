@@ -73,7 +73,6 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('h2o2', 24, dict(blocks_per_part=3, rates_per_part=10)),
     ('h2o2_n2', 12, dict(blocks_per_part=100, rates_per_part=5)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, defines=('-DPJQ_DEPTH=1',))),
     # several lane groups per workgroup on the same states (each an OS thread in the emulation, a real barrier behind
     # __syncthreads): groups split the row blocks of a kernel, exchange the energy-row sums and share its columns
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
@@ -83,27 +82,22 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     # with a two-group pre-pass (the 111-species geometry), with one lane group, and the long-lived sums they replace
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, c_lds=1, pre_halves=2)),
     ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1, ecl=1)),
-    ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6, halves=2)),
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, ecl=0)),
     # PJQ_FIN: the energy row finished by k_fin, a kernel of its own behind the row kernels (several kernels; one kernel whose
     # column sums travel through the hand-over array)
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, fin=1)),
     ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, fin=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
-    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2, fin=1)),
     # ... and PJQ_ECL with the factor columns: one kernel (the sums land in the EJ columns behind the prologue) and several
     ('synth_mid24', 40, dict(rates_per_part=40, kcf=1, halves=4, single=1, ecl=1)),
-    ('h2o2_n2', 12, dict(blocks_per_part=2, rates_per_part=5, kcf=1, halves=2, ecl=1)),
     # ONE row kernel with polynomial K_c rows (the 111-species geometry: no LDS room for the finished column sums, which
     # travel through the hand-over array -- PJQ_ECOLS), four lane groups with a cooperative prologue (PJQ_COOP)
     ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
     ('synth_srichb', 16, dict(rates_per_part=5, halves=2, single=1, c_lds=1, pre_halves=2,
                               defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1', '-DPJQ_DEFER=1'))),
-    ('synth_mid24', 40, dict(blocks_per_part=6, rates_per_part=40, halves=4, defines=('-DPJQ_COOP=1',))),
     # PJQ_DEFER: the rows of a block are stored during the visits of the next one
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, defines=('-DPJQ_DEFER=1',))),
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1, defines=('-DPJQ_DEFER=1',))),
-    ('synth_srichb', 16, dict(blocks_per_part=3, rates_per_part=5, defines=('-DPJQ_DEFER=1',))),
     # equilibrium constants from per-species factor columns (PJQ_KCF: cooperative prologue, products instead of a
     # polynomial + exp per visit): one group and several kernels; four groups and ONE kernel (the 53-species shape)
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, kcf=1)),
