@@ -25,7 +25,7 @@
 //                  and those few columns travel between the kernels of one library through hand-over slots
 //                  that the next kernel loads with its state; the last kernel finishes the row and jac[0].
 //   lane groups    PJQ_HALVES = 2 / 4: the wavefronts of a workgroup work on the SAME states and split the row blocks;
-//   PJQ_KCF        up to 62 species: equilibrium constants as products of per-species factors kept in LDS columns,
+//   PJQ_KCF        up to 53 species: equilibrium constants as products of per-species factors kept in LDS columns,
 //                  64 states per workgroup, four lane groups, ONE row kernel (see k_rblk).
 //
 //   PJQ_JV         the same row kernels with the Jacobian stores replaced by w_k += J(k, c) v_c: the
@@ -162,7 +162,8 @@ using namespace pj;
 #endif
 
 // debug builds (-DPJQ_TIMING): shader cycles per phase and wavefront, summed over a kernel
-// (0 prologue, 1 Arrhenius visits, 2 hand-over visits, 3 output phase, 4 energy-row epilogue)
+// (0 prologue, 1 Arrhenius visits, 2 hand-over visits, 3 output phase, 4 energy-row epilogue: its last part -- 5: c_p sums,
+// 6: fence + barriers + exchange of the scalar sums, 7: loads of the column sums)
 #ifdef PJQ_TIMING
 #define PJQ_TICK(ph) { const long long tn_ = clock64(); tacc[ph] += tn_ - tprev; tprev = tn_; }
 #else
@@ -766,7 +767,7 @@ constexpr OwnerMap make_owner()
 }
 constexpr OwnerMap OWNER = make_owner();
 #ifdef PJQ_TIMING
-__device__ long long g_tim[5][1024][4];
+__device__ long long g_tim[8][1024][4];
 #endif
 
 // Lane groups (PJQ_HALVES = G: 1, 2 or 4).  The workgroup is G groups of PJQ_BLOCK lanes ON THE SAME PJQ_BLOCK
@@ -926,7 +927,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     d2 (*const IXT)[PJQ_BLOCK] = (d2 (*)[PJQ_BLOCK])(SM + SM_IXT);
 #endif
 #ifdef PJQ_TIMING
-    long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64();
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
 #endif
     // grp: wavefront-uniform -- and the compiler has to know (readfirstlane: a scalar), or the group branches below
     // become divergent regions that every wavefront walks through under an execution mask, with the registers of
@@ -1999,6 +2000,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #endif
         const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
         const double icp = 1.0 / cpavg;
+        PJQ_TICK(5)
         if constexpr (G_ > 1) {
             // Every group hands the sums of the columns it does not own to their owners through the columns (nobody
             // reads them any more) and the scalar sums to everybody; then each finishes its share of the energy row.
@@ -2027,6 +2029,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 H += RED[0][g][tid]; SCP += RED[1][g][tid]; SJT += RED[2][g][tid]; HP += RED[3][g][tid]; HQ += RED[4][g][tid];
             });
         }
+        PJQ_TICK(6)
         // Several kernels: the finished column sums of this group's columns come out of the hand-over array -- ALL requested
         // here, in one batch (a load per column next to its use is a memory round trip per column, each behind the store
         // of the column before: 170 k of the 500 k cycles of the 111-species mechanism's last kernel)
@@ -2043,6 +2046,10 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             PJQ_SCHED_BARRIER();
         }
         if constexpr (PJQ_ECL && !ECL_PRO) { ecl_fetch(); PJQ_SCHED_BARRIER(); }
+#ifdef PJQ_TIMING
+        if constexpr (ECOL_MEM) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        PJQ_TICK(7)
+#endif
         // the total of column j, for the lane group that owns it (called once per column, right where the value is
         // used: gathered in front of the energy row, the sums of 55 columns spill)
         auto ecol = [&](auto jc) PJR_INL {
@@ -2123,7 +2130,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #ifdef PJQ_TIMING
     PJQ_TICK(4)
     if ((tid & 63) == 0 && blockIdx.x < 1024)
-        for (int ph = 0; ph < 5; ++ph) g_tim[ph][blockIdx.x][(tid >> 6) + grp * (PJQ_BLOCK / 64)] = tacc[ph];
+        for (int ph = 0; ph < 8; ++ph) g_tim[ph][blockIdx.x][(tid >> 6) + grp * (PJQ_BLOCK / 64)] = tacc[ph];
 #endif
 #undef J_
 }

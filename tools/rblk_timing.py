@@ -17,10 +17,10 @@ ev.time_jacobian(d_p, d_y, jac, 2, L, L)
 ms = ev.time_jacobian(d_p, d_y, jac, 3, L, L)
 print('%.3f ms per step' % ms)
 lib = ctypes.CDLL(so)
-names = ['prologue', 'visits', 'pre-visits', 'output', 'epilogue']
-tot = np.zeros(5)
+names = ['prologue', 'visits', 'pre-visits', 'output', 'epilogue', 'ep:cp', 'ep:fence', 'ep:loads']
+tot = np.zeros(8)
 for part in range(64):
-    buf = np.zeros((5, 1024, 4), dtype=np.int64)
+    buf = np.zeros((8, 1024, 4), dtype=np.int64)
     if lib.pj_spec_debug_timing(part, buf.ctypes.data_as(ctypes.c_void_p)) != 0:
         break
     # per lane group (several groups per workgroup: index = group; one group: index = wavefront of the workgroup)
@@ -28,7 +28,7 @@ for part in range(64):
     for q in range(4):
         if g[:, q].sum() > 0:
             print('   group/wave %d: ' % q + '  '.join('%s %7.0f' % (nm, v) for nm, v in zip(names, g[:, q])) + '   sum %8.0f' % g[:, q].sum())
-    m = buf.reshape(5, -1).mean(axis=1)
+    m = buf.reshape(8, -1).mean(axis=1)
     tot += m
     print('kernel %2d: ' % part + '  '.join('%s %7.0f' % (nm, v) for nm, v in zip(names, m)) + '   sum %8.0f' % m.sum())
 print('all      : ' + '  '.join('%s %7.0f' % (nm, v) for nm, v in zip(names, tot)) + '   sum %8.0f' % tot.sum())
