@@ -163,10 +163,12 @@ int pj_eval_fd_jacobian_dev(pj_mech* m, long n, const double* d_pres, const doub
  * pj_eval_jacobian_dev leaves them: a_layout = PJ_LAYOUT_AOS: state-major, each block column-major
  * (a[s*NSP*NSP + r + NSP*c], pyJac's per-state C layout); PJ_LAYOUT_SOA: a[(r + NSP*c)*n + s], pyJac's batch layout
  * (the one the row-block kernels write at full speed).  Factors (d_lu, d_perm) are always per state.  NSP <= 16: four blocks per wavefront; NSP <= 64: one
- * wavefront per block -- a lane per row, the block in registers; 65 <= NSP <= 140: one workgroup per block, the block in LDS (PJ_EUNSUPPORTED beyond).  gamma != 0: the matrix factored is I - gamma * A (the Newton matrix of an implicit
+ * wavefront per block -- a lane per row, the block in registers; 65 <= NSP <= 128: four wavefronts per block, the block in
+ * their registers (factorisation and the fused solve; a solve from stored factors takes the LDS kernel); 129 <= NSP <= 140: one
+ * workgroup per block, the block in LDS (PJ_EUNSUPPORTED beyond).  gamma != 0: the matrix factored is I - gamma * A (the Newton matrix of an implicit
  * step); gamma == 0: A itself.  Partial pivoting: a row of maximum magnitude, as LAPACK dgetf2; on an EXACT tie the
- * LDS-resident kernel (NSP > 64, rows exchanged physically) takes dgetf2's row -- the first in the current order --, the
- * register-resident ones (rows never exchanged) the lowest original row, which differs only when the tie involves a row
+ * LDS-resident kernel (NSP > 128, rows exchanged physically) takes dgetf2's row -- the first in the current order --, the
+ * register-resident ones (NSP <= 128, rows never exchanged) the lowest original row, which differs only when the tie involves a row
  * that an earlier step displaced; the
  * result is P A = L U with L unit lower triangular below the diagonal of d_lu, U on and above it, and
  * d_perm[s*NSP + k] = the row of A that became row k.  A singular block yields non-finite factors (no info

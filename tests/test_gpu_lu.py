@@ -206,9 +206,9 @@ def test_newton_step_on_jacobians(name, n, torch_cuda):
 def test_pivot_ties(nsp, torch_cuda):
     """Exact ties of the column maximum (structured Newton matrices have them).  Every kernel picks A row of maximum
     magnitude (partial pivoting holds: |L| <= 1, P A = L U exactly on small-integer data).  Which one: the LDS-resident
-    kernel (65 .. 140 rows) exchanges rows physically and takes the first row of maximum magnitude in the current
+    kernel (129 .. 140 rows) exchanges rows physically and takes the first row of maximum magnitude in the current
     order -- LAPACK dgetf2's choice, pivot for pivot (a lane scans rows 32 apart there, so the lowest LANE is not the
-    lowest row: ADVICE round 3).  The register-resident kernels (<= 64 rows) never exchange rows: among tied rows
+    lowest row: ADVICE round 3).  The register-resident kernels (<= 128 rows) never exchange rows: among tied rows
     they take the lowest ORIGINAL row, which is dgetf2's choice unless the tie involves a row that an earlier step
     displaced (include/pyjac_amd.h says so)."""
     import scipy.linalg
