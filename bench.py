@@ -419,8 +419,9 @@ def main():
                     line['also']['fused_jacobian_vector_product'] = dict(
                         states=n, kernel_ms=ms, products_per_s=n / ms * 1e3, bytes_per_state=bjv,
                         achieved_GBps=n * bjv / ms / 1e6, finite=bool(torch.isfinite(d_w[:, ::997]).all()),
-                        note='same kernel with the stores replaced by w[row] += J(row,col) v[col]: %d instead of '
-                             '%d bytes per state' % (bjv, bj))
+                        kernel='k_lane with w = J v fused in' if ev.spec_kernel == 'pj_lane' else
+                               'k_jvd (every reaction once: its derivative row times v, scattered like its rate)',
+                        note='no Jacobian in memory: %d instead of %d bytes per state' % (bjv, bj))
                 except Exception as ex:
                     line['also']['fused_jacobian_vector_product'] = {'error': repr(ex)}
                 # the path a user without a compiler gets: the same batch through the table-driven kernels (no

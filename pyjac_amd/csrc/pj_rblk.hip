@@ -2542,10 +2542,513 @@ void launch_rate(const PjqArgs& A, void* stream)
 struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_FULL ? 8 : 7, launch_rate); } } reg_;   // 7: conc / spec_rates / dydt, 8: every rate output
 #endif  // PJQ_PART == 3
 
+#if PJQ_PART == 5
+// ------------------------------------------------------------------------------------------
+// k_jvd: w = J v per state as a DIRECTIONAL DERIVATIVE -- every reaction visited ONCE (pj_spec_jacvec)
+// ------------------------------------------------------------------------------------------
+// Every sum of the formulation is a sum over reactions of nu_ki times a per-reaction scalar:
+//   omega_k = sum nu q,  JT_k = sum nu theta,  P_k = sum nu rp,  Q_k = sum nu rq,  S_kj = sum nu G_ij,
+// and row k of the species block applied to v is  w_k = W_k D_k  with
+//   D_k = JT_k v_0 + P_k SV1 - Q_k SV0 / W_N + sum_j S_kj vs_j = sum_i nu_ki d_i,
+//   d_i = theta_i v_0 + rp_i SV1 - rq_i SV0 / W_N + sum_{slots of i} G_ij vs_j      (vs_j = v_{j+1} / W_j,
+//   SV0 = sum_j v_{j+1}, SV1 = sum_j vs_j: k_rblk's scaled vector)
+// -- ONE scalar d_i per reaction: the reaction's sparse derivative row times the vector, scattered to its net species
+// exactly like q_i into omega_k.  The row kernels visit a reaction once per row block that holds one of its net species
+// (3.6 times on average) because a Jacobian ROW needs all of its reactions in one place; the product does not.
+// The energy row needs no sums of its own:  sum_k h_kW_k (P_k SV1 - Q_k SV0/W_N + sum_j S_kj vs_j) = sum_k h_kW_k (D_k - JT_k v_0),
+// and with jac[0]'s term -(sum_k h_kW_k JT*_k / c_p) v_0  (JT*: the J_nplusone quirk's value for the last species)
+//   w_0 = -[SCP - (dc_p/c_p) H] / (rho c_p) v_0 - [sum_k h_kW_k D_k + h_NW_N (JTQ - JT_N) v_0] / c_p
+//         + (H / (rho c_p^2)) (sum_j c_p,j v_{j+1} - c_p,N SV0)
+// (k_rblk's epilogue, create_jacobian.py:2940-3120).  The rates enter only through H = sum_k h_kW_k omega_k and
+// SCP = sum_k omega_k W_k c_p,k, and those are sums over reactions too:  H = sum_i Hr_i q_i,  SCP = sum_i dCp_i q_i  with the
+// reaction enthalpy Hr_i = sum_k nu_ki h_kW_k = R T (T dlnK_c/dT + sum nu) -- the visit has it -- and its temperature
+// derivative dCp_i = sum_k nu_ki W_k c_p,k, four more multiply-adds on the K_c row the visit has read anyway (an irreversible
+// reaction has no row: its net species' NASA polynomials).  So a lane carries ONE array, D_k, and four scalars.
+// Geometry (pyjac_amd/specbuild.py): D_k in registers; concentrations and the scaled vector in registers too (256 states
+// per workgroup) or -- large mechanisms -- in LDS columns, 64 states and four lane groups that take every fourth reaction.
+// Reaction ranges as k_rate (RATE_R); between the kernels of a library D_k and the scalars travel through `sr`.
+#ifndef PJQ_V_LDS
+#define PJQ_V_LDS 0         // the scaled vector in LDS columns (large mechanisms) instead of registers
+#endif
+#ifndef PJQ_JVD_SB
+#define PJQ_JVD_SB 2        // visits between scheduling barriers
+#endif
+#ifndef PJQ_JVD_AHEAD
+#define PJQ_JVD_AHEAD (PJQ_C_LDS != 0)      // the K_c rows and concentrations of a lane group's NEXT reaction are read from LDS
+                            // while the current one is computed (k_rblk's PJQ_KC_AHEAD / PJQ_CONC_AHEAD: at one wavefront per
+                            // SIMD nothing else covers the LDS round trips at the top of every visit)
+#endif
+#define PJR_RECOMPUTE_KF 0
+#define PJR_RECOMPUTE_KR 1
+// which scalars of a falloff / PLOG / Chebyshev reaction pj_rate_pre.inc "hands over" (here: to local variables): the rule
+// of pj_tables.cpp's SCQ
+constexpr int jvd_slot(int fl, int c)
+{
+    return c == S_KR ? ((fl & F_CHEB) ? c : -1) : c == S_RP ? ((fl & (F_THD | F_PDEP)) ? c : -1) :
+           c == S_BM ? ((fl & F_EFFTYPE) ? c : -1) : c == S_BC ? ((fl & F_COLLIDER) ? c : -1) : c;
+}
+#define PJR_SLOT(i_, c_) jvd_slot(pjs::RI[i_][RI_FLAGS], c_)
+constexpr bool kf_plain(int) { return false; }
+template <int i>
+constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
+constexpr int max_kc_cnt()
+{
+    int m = 1;
+    for (int i = 0; i < NRXN; ++i)
+        if ((pjs::RI[i][RI_FLAGS] & F_REV) && pjs::RI[i][RI_KC_CNT] > m) m = pjs::RI[i][RI_KC_CNT];
+    return m;
+}
+constexpr int MAXKC = max_kc_cnt();
+#ifndef PJQ_R0      // from the kernel plan
+#define PJQ_R0 pjs::RATE_R[PJQ_ID][0]
+#define PJQ_R1 pjs::RATE_R[PJQ_ID + 1][0]
+#define PJQ_FIRST (PJQ_ID == 0)
+#define PJQ_LAST (PJQ_ID == pjs::NRATE - 1)
+#endif
+constexpr int R0_ = PJQ_R0, R1_ = PJQ_R1;
+constexpr bool FIRST_ = PJQ_FIRST != 0, LASTK_ = PJQ_LAST != 0;
+constexpr KcMap make_kcmap()
+{
+    KcMap m{};
+    for (int g = 0; g < NKC_ALL; ++g) m.loc[g] = -1;
+    for (int i = R0_; i < R1_; ++i) kcmap_add(m, i);
+    return m;
+}
+constexpr KcMap KCM = make_kcmap();
+constexpr int NKC = KCM.n;
+struct KcList { int v[NKC > 0 ? NKC : 1]; };
+constexpr KcList make_list() { KcList l{}; for (int q = 0; q < NKC; ++q) l.v[q] = KCM.list[q]; return l; }
+__device__ const KcList KCL = make_list();
+constexpr int G_ = PJQ_HALVES;
+constexpr int NTHR = PJQ_BLOCK * G_;
+static_assert(G_ == 1 || PJQ_C_LDS, "k_jvd: several lane groups share the concentration columns (PJQ_C_LDS)");
+static_assert(!PJQ_V_LDS || PJQ_C_LDS, "k_jvd: the vector columns sit next to the concentration columns");
+constexpr long JVD_LDS = 8L * ((NKC > 0 ? NKC : 1) * 16 + (PJQ_C_LDS ? (long)NSP * PJQ_BLOCK : 0) + (PJQ_V_LDS ? (long)NSP * PJQ_BLOCK : 0) +
+                               (G_ > 1 ? 4L * PJQ_BLOCK : 0));
+#ifndef PJR_HOST_EMU
+static_assert(JVD_LDS <= 160L * 1024, "k_jvd: columns + K_c rows exceed the LDS (specbuild.py picks the geometry)");
+#endif
+// rows of `sr` between the kernels of a library: D_k, then four scalars
+constexpr int SR_D = 0, SR_SC = NSP;       // JT_N, JTQ, H, SCP
+
+__global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
+{
+    __shared__ __attribute__((aligned(16))) double LTK[(NKC > 0 ? NKC : 1) * 16];
+#if PJQ_C_LDS
+    __shared__ double CL[NSP][PJQ_BLOCK];
+#endif
+#if PJQ_V_LDS
+    __shared__ double VL[NSP][PJQ_BLOCK];
+#endif
+    __shared__ double RED[G_ > 1 ? 4 : 1][PJQ_BLOCK];
+    // lane groups (see k_rblk): all on the same PJQ_BLOCK states, reaction R0 + q to group q % G_
+    const int grp = G_ > 1 ? (int)threadIdx.x / PJQ_BLOCK : 0;
+    const int tid = (int)threadIdx.x - grp * PJQ_BLOCK;
+    // lanes past the end repeat the last state (same values to the same addresses): no divergence
+    long s = (long)blockIdx.x * PJQ_BLOCK + tid;
+    if (s >= A.n) s = A.n - 1;
+    double acc[NSP];                    // D_k
+    double JTN = 0.0, JTQ = 0.0, Hs = 0.0, SCP = 0.0;
+    double T, p, rho, invrho, Wbar, mconc;
+    PJQ_CONST_BASES()
+    // a lane's byte offset inside an LDS column (an opaque copy per pass and epilogue part: nothing read from the columns
+    // is kept from one part of the kernel to the next)
+    unsigned lo_ = (unsigned)tid * 8u;
+#if !PJQ_C_LDS
+    State L;
+#endif
+#if !PJQ_V_LDS
+    double VR[NSP];                     // vs_c: v_0, v_c / W_{c-1}
+#endif
+    double SV0 = 0.0, SV1 = 0.0;
+    {
+        constexpr int NQ = (NKC * 8 + NTHR - 1) / NTHR;
+        d2 lt[NQ > 0 ? NQ : 1];
+        kc_issue<NQ, NTHR>(KCL.v, NKC, lt);
+#if PJQ_C_LDS
+        State L;
+#endif
+        // the sums of the reactions before R0: requested with the state, before anything waits
+        if constexpr (!FIRST_) {
+            if (grp == 0) {
+                static_for<NSP>([&](auto kc) PJR_INL { acc[decltype(kc)::value] = A.sr[(SR_D + decltype(kc)::value) * A.sr_ld + s]; });
+                JTN = A.sr[(SR_SC + 0) * A.sr_ld + s]; JTQ = A.sr[(SR_SC + 1) * A.sr_ld + s];
+                Hs = A.sr[(SR_SC + 2) * A.sr_ld + s]; SCP = A.sr[(SR_SC + 3) * A.sr_ld + s];
+            }
+        }
+        const double* vp = A.v + s * A.v_ss;
+#if PJQ_V_LDS
+        // the groups fill the vector columns together: group g the components g, g + G_, ... (ONE branch per group with all
+        // of its loads in flight -- a test per component is a load, a wait and a store per component, NSP / G_ memory round
+        // trips in a row)
+        group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+            constexpr int g = decltype(gc)::value, cnt = (NSP - g + G_ - 1) / G_;
+            double vt[cnt > 0 ? cnt : 1];
+            static_for<cnt>([&](auto jc) PJR_INL { vt[decltype(jc)::value] = vp[(g + decltype(jc)::value * G_) * A.v_si]; });
+            static_for<cnt>([&](auto jc) PJR_INL {
+                constexpr int c = g + decltype(jc)::value * G_;
+                if constexpr (c > 0) VL[c][tid] = vt[decltype(jc)::value] * pjs::SP[c > 0 ? c - 1 : 0][0];
+                else VL[c][tid] = vt[decltype(jc)::value];
+            });
+        });
+#else
+        static_for<NSP>([&](auto cc) PJR_INL { VR[decltype(cc)::value] = vp[decltype(cc)::value * A.v_si]; });
+#endif
+        load_state(A, s, L);
+        kc_land<NQ, NTHR>(LTK, NKC, lt);
+        to_conc(L);
+        T = L.T; p = L.p; rho = L.rho; invrho = L.invrho; Wbar = L.Wbar; mconc = L.mconc;
+#if PJQ_C_LDS
+        if (grp == 0)
+            static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = L.C[decltype(kc)::value]; });
+#endif
+    }
+    if (FIRST_ || grp != 0) static_for<NSP>([&](auto kc) PJR_INL { acc[decltype(kc)::value] = 0.0; });
+    __syncthreads();
+#if PJQ_C_LDS
+#define CC(idx) ((idx) == ONE ? 1.0 : *(const double*)((const char*)&CL[(idx) == ONE ? 0 : (idx)][0] + lo_))
+#else
+#define CC(idx) L.C[idx]
+#endif
+#if PJQ_V_LDS
+#define VS(c_) (*(const double*)((const char*)&VL[c_][0] + lo_))
+    static_range<1, NSP>([&](auto cc) PJR_INL {
+        constexpr int c = decltype(cc)::value;
+        const double vsc = VL[c][tid];
+        SV1 += vsc;
+        SV0 += vsc * pjs::SP[c - 1][1];
+    });
+#else
+#define VS(c_) VR[c_]
+    static_range<1, NSP>([&](auto cc) PJR_INL {
+        constexpr int c = decltype(cc)::value;
+        SV0 += VR[c];
+        VR[c] *= pjs::SP[c - 1][0];
+        SV1 += VR[c];
+    });
+#endif
+    const double v0 = VS(0);
+    const double SV0N = SV0 * pjs::SP[LAST][0];
+    double logT = log(T), invT = 1.0 / T;
+    const double logp = log(p);
+    double T2, T3, T4, T2d, T3d, T4d, Tc1, Tc2, Tc3, Tc4;
+    // opaque copies of T and its functions: k_f, K_c, the NASA selects ... of one part of the kernel are not kept for the
+    // next one (two passes over the reactions: 2 NRXN values; three sweeps over the species: 6 NSP range-selected
+    // coefficients -- in scratch memory)
+    auto fresh = [&]() PJR_INL {
+#ifndef PJR_HOST_EMU
+        asm volatile("" : "+v"(T), "+v"(logT), "+v"(invT), "+v"(lo_));
+#endif
+        T2 = T * T; T3 = T2 * T; T4 = T2 * T2;
+        T2d = 2.0 * T2; T3d = 3.0 * T3; T4d = 4.0 * T4;
+        Tc1 = 2.0 * T; Tc2 = 6.0 * T2; Tc3 = 12.0 * T3; Tc4 = 20.0 * T4;
+    };
+    fresh();
+    const double WR = Wbar * invrho;
+    double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
+    double jtd[NSP], jtq = 0.0;         // pj_rate_pre.inc's d/dT sums: dead here
+    auto rate_out = [](auto, double, double, double) {};
+    double hv[6];                       // pj_rate_pre.inc's hand-over values of the reaction at hand
+#define SCR_ST(slot, val) (hv[slot] = (val))
+
+    // NASA properties of species k: h_kW_k and c_p,k W_k / R (rate_subs.py:2171-2335)
+    auto nasa = [&](auto kc, double& hW, double& cpm, double& dcpm) PJR_INL {
+        constexpr int k = decltype(kc)::value;
+        const bool lo = T <= pjs::SP[k][2];
+        double a[6];
+        static_for<6>([&](auto cc) PJR_INL { a[decltype(cc)::value] = lo ? pjs::SP[k][4 + decltype(cc)::value] : pjs::SP[k][11 + decltype(cc)::value]; });
+        hW = RU_ * (a[5] + T * (a[0] + T * (a[1] * (1.0 / 2.0) + T * (a[2] * (1.0 / 3.0) + T * (a[3] * (1.0 / 4.0) + a[4] * (1.0 / 5.0) * T)))));
+        cpm = a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T)));
+        dcpm = a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T));
+    };
+    // what an Arrhenius visit reads from LDS first: requested one visit ahead (PJQ_JVD_AHEAD), into the buffer of its parity
+    double cab[PJQ_JVD_AHEAD ? 2 : 1][6], kab[PJQ_JVD_AHEAD ? 2 : 1][MAXKC][7];
+    auto fetch = [&](auto ic) PJR_INL {
+        constexpr int i = decltype(ic)::value, par = PJQ_JVD_AHEAD ? ((i - R0_) / G_) & 1 : 0;
+        if constexpr (i < R1_) {
+            if constexpr (!is_pre(i < R1_ ? i : R0_)) {
+                constexpr int FL = pjs::RI[i][RI_FLAGS];
+                cab[par][0] = CC(pjs::RI[i][RI_R0]); cab[par][1] = CC(pjs::RI[i][RI_R1]); cab[par][2] = CC(pjs::RI[i][RI_R2]);
+                if constexpr ((FL & F_REV) != 0) {
+                    cab[par][3] = CC(pjs::RI[i][RI_P0]); cab[par][4] = CC(pjs::RI[i][RI_P1]); cab[par][5] = CC(pjs::RI[i][RI_P2]);
+                    static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJR_INL {
+                        constexpr int c = decltype(cc)::value, g = pjs::RI[i][RI_KC_PTR] + c;
+                        const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                        static_for<7>([&](auto ec) PJR_INL { kab[par][c][decltype(ec)::value] = a[decltype(ec)::value]; });
+                    });
+                }
+            }
+        }
+    };
+    // One reaction: q_i and d_i, the reaction's derivative row times the scaled vector
+    auto visit = [&](auto ic) PJR_INL {
+        constexpr int i = decltype(ic)::value;
+        constexpr int par = PJQ_JVD_AHEAD ? ((i - R0_) / G_) & 1 : 0;
+        constexpr int FL = pjs::RI[i][RI_FLAGS];
+        constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
+        constexpr int GP = pjs::RI[i][RI_GEN_PTR];
+        constexpr int GNR = (FL & F_GEN) ? pjs::RI[i][RI_GEN_NR] : 0;
+        constexpr int GNP = ((FL & F_GEN) && (FL & F_REV)) ? pjs::RI[i][RI_GEN_NP] : 0;
+        constexpr int KCNT = (FL & F_REV) ? pjs::RI[i][RI_KC_CNT] : 0;
+        constexpr double nsum = net_sum(i);
+        double q_ = 0.0, theta = 0.0, rp = 0.0, bM_ = 0.0, bcol_ = 0.0, gkf = 0.0, gkr = 0.0;
+        double a0 = 1.0, a1 = 1.0, a2 = 1.0, b0 = 1.0, b1 = 1.0, b2 = 1.0;     // the molecule slots' concentrations
+        double hrt = 0.0, dcr = 0.0;        // Hr_i / (R T) - sum nu and dCp_i / R - sum nu, from the K_c rows
+        if constexpr (is_pre(i)) {
+            // falloff / PLOG / Chebyshev: the shared body (rate_subs.py:254-2335, create_jacobian.py:2189-3298)
+            constexpr bool RATES_OUT = false;
+            double (&jt)[NSP] = jtd;
+#define PJR_RD(i_) pjs::RD[i_]
+#define PJR_KCROW(g_) (LTK + KCM.loc[g_] * 16)
+#define PJR_EFL(e_) pjs::EFF_AM1[e_][0]
+#define PJR_KC_FIRST(i_) true
+#define PJR_SCHED_BARRIER() ((void)0)
+#include "pj_rate_pre.inc"
+#undef PJR_RD
+#undef PJR_KCROW
+#undef PJR_EFL
+#undef PJR_KC_FIRST
+#undef PJR_SCHED_BARRIER
+            q_ = c * R;
+            theta = hv[S_TH];
+            bM_ = bM; bcol_ = bcol;
+            gkf = c * kf; gkr = c * kr;
+            if constexpr (PJR_SLOT(i, S_RP) >= 0) rp = hv[S_RP];
+            else rp = WR * ((1.0 - pjs::RD[i][RD_NR]) * (c * Rf) - ((FL & F_REV) ? (1.0 - pjs::RD[i][RD_NP]) * (c * Rr) : 0.0));
+            if constexpr ((FL & F_CHEB) != 0) {         // eval_jacob's own k_f in the dR/dY_j terms (pj_rate_pre.inc)
+                gkf = kfj_;
+                if constexpr ((FL & F_REV) != 0) gkr = kfj_ * ekc[pjs::KC_CLASS[i][0]];
+            }
+            a0 = cr0; a1 = cr1; a2 = cr2; b0 = cp0; b1 = cp1; b2 = cp2;
+            hrt = TdlnKc;
+            if constexpr (PJQ_JVD_AHEAD) fetch(std::integral_constant<int, i + G_>{});
+            static_for<KCNT>([&](auto cc) PJR_INL {
+                constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
+                const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                dcr += a[1] + a[2] * Tc1 + a[3] * Tc2 + a[4] * Tc3 + a[5] * Tc4;
+            });
+        } else {
+            // Arrhenius (+ optional third body): k_rblk's visit (rate_subs.py:113-147, 660-840, 1076-1134;
+            // create_jacobian.py:341-489)
+            constexpr double nr = pjs::RD[i][RD_NR], np_ = pjs::RD[i][RD_NP];
+            if constexpr (!PJQ_JVD_AHEAD) fetch(ic);
+            a0 = cab[par][0]; a1 = cab[par][1]; a2 = cab[par][2];
+            if constexpr ((FL & F_REV) != 0) { b0 = cab[par][3]; b1 = cab[par][4]; b2 = cab[par][5]; }
+            double ka[KCNT > 0 ? KCNT : 1][7];
+            static_for<KCNT>([&](auto cc) PJR_INL {
+                static_for<7>([&](auto ec) PJR_INL { ka[decltype(cc)::value][decltype(ec)::value] = kab[par][decltype(cc)::value][decltype(ec)::value]; });
+            });
+            if constexpr (PJQ_JVD_AHEAD) fetch(std::integral_constant<int, i + G_>{});
+            double pr_ = a0 * a1 * a2, pp_ = b0 * b1 * b2;
+            static_for<GNR + GNP>([&](auto fc) PJR_INL {
+                constexpr int f = decltype(fc)::value;
+                const double gp_ = gen_pow<GP + f>(CC(pjs::GEN_SP[GP + f][0]));
+                if constexpr (f < GNR) pr_ *= gp_; else pp_ *= gp_;
+            });
+            const double lnk = RDC(i, RD_LNA) + RDC(i, RD_B) * logT - RDC(i, RD_TA) * invT;
+            double kf, ekc_ = 0.0;
+            if constexpr ((FL & F_REV) != 0) {
+                double lnKc = RDC(i, RD_LNPREF);
+                static_for<KCNT>([&](auto cc) PJR_INL {
+                    const double* a = ka[decltype(cc)::value];
+                    lnKc += a[0] + a[1] * logT + a[2] * T + a[3] * T2 + a[4] * T3 + a[5] * T4 - a[6] * invT;
+                    hrt += a[1] + a[2] * T + a[3] * T2d + a[4] * T3d + a[5] * T4d + a[6] * invT;
+                    dcr += a[1] + a[2] * Tc1 + a[3] * Tc2 + a[4] * Tc3 + a[5] * Tc4;
+                });
+                exp_pair(lnk, -lnKc, kf, ekc_);
+            } else {
+                kf = exp_one(lnk);
+            }
+            if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
+            const double Rf = kf * pr_;
+            double Rr = 0.0;
+            if constexpr ((FL & F_REV) != 0) Rr = (kf * ekc_) * pp_;
+            const double R = Rf - Rr;
+            double c = 1.0, lead = 0.0;
+            if constexpr ((FL & F_THD) != 0) {
+                double Mc = mconc;
+                static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
+                    constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                    Mc += EFC(e) * CC(pjs::EFF_SP[e][0]);
+                });
+                c = Mc;
+                lead = -c * R * invT;
+                if constexpr ((FL & F_EFFTYPE) != 0) bM_ = R;
+            }
+            if constexpr ((FL & F_NO_DT) == 0) {
+                const double dlnk = RDC(i, RD_B) + RDC(i, RD_TA) * invT;
+                double el = R * dlnk + Rf * (1.0 - nr);
+                if constexpr ((FL & F_REV) != 0) el -= Rr * ((1.0 - np_) - hrt);
+                theta = (lead + c * invT * el) * invrho;
+            }
+            gkf = c * kf;
+            if constexpr ((FL & F_REV) != 0) gkr = gkf * ekc_;
+            if constexpr ((FL & F_THD) != 0) {
+                double a = c * (nr * Rf - ((FL & F_REV) ? np_ * Rr : 0.0));
+                if constexpr ((FL & F_EFFTYPE) != 0) a += c * R;
+                rp = WR * (c * R - a) + bM_;
+            } else {
+                rp = WR * ((1.0 - nr) * Rf - ((FL & F_REV) ? (1.0 - np_) * Rr : 0.0));
+            }
+            q_ = gkf * pr_ - gkr * pp_;
+        }
+        // H and SCP: the reaction's enthalpy and its temperature derivative times q_i
+        if constexpr ((FL & F_REV) != 0) {
+            Hs += ((RU_ * T) * (hrt + nsum)) * q_;
+            SCP += (RU_ * (dcr + nsum)) * q_;
+        } else {
+            // an irreversible reaction has no K_c row: its net species' NASA polynomials
+            double Hr = 0.0, dC = 0.0;
+            static_for<ncnt>([&](auto qc) PJR_INL {
+                constexpr int k = pjs::NET_SP[np0 + decltype(qc)::value][0];
+                double hW, cpm, dcpm;
+                nasa(std::integral_constant<int, k>{}, hW, cpm, dcpm);
+                Hr += pjs::NET_NU[np0 + decltype(qc)::value][0] * hW;
+                dC += pjs::NET_NU[np0 + decltype(qc)::value][0] * (RU_ * cpm);
+            });
+            Hs += Hr * q_;
+            SCP += dC * q_;
+        }
+        double gN = 0.0, dot = 0.0;
+        if constexpr (has_anm1<i>()) gN = bM_ * RDC(i, RD_ANM1);
+        auto slot = [&](auto spc, const double gv) PJR_INL {
+            constexpr int sp = decltype(spc)::value;
+            if constexpr (sp == LAST) gN += gv;
+            else if constexpr (sp != ONE) dot += gv * VS(sp + 1);
+        };
+        slot(std::integral_constant<int, pjs::RI[i][RI_R0]>{}, gkf * (a1 * a2));
+        slot(std::integral_constant<int, pjs::RI[i][RI_R1]>{}, gkf * (a0 * a2));
+        slot(std::integral_constant<int, pjs::RI[i][RI_R2]>{}, gkf * (a0 * a1));
+        if constexpr ((FL & F_REV) != 0) {
+            slot(std::integral_constant<int, pjs::RI[i][RI_P0]>{}, -gkr * (b1 * b2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_P1]>{}, -gkr * (b0 * b2));
+            slot(std::integral_constant<int, pjs::RI[i][RI_P2]>{}, -gkr * (b0 * b1));
+        }
+        if constexpr (GNR + GNP > 0) {
+            // one value per factor: c k nu C^(nu-1) prod_others (create_jacobian.py:400-448)
+            double gcf[GNR + GNP > 0 ? GNR + GNP : 1], gpw[GNR + GNP > 0 ? GNR + GNP : 1];
+            static_for<GNR + GNP>([&](auto fc) PJR_INL {
+                constexpr int f = decltype(fc)::value;
+                gcf[f] = CC(pjs::GEN_SP[GP + f][0]);
+                gpw[f] = gen_pow<GP + f>(gcf[f]);
+            });
+            static_for<GNR + GNP>([&](auto fc) PJR_INL {
+                constexpr int f = decltype(fc)::value;
+                constexpr int f0 = f < GNR ? 0 : GNR, f1 = f < GNR ? GNR : GNR + GNP;
+                double gv = (f < GNR ? gkf : -gkr) * gen_dpow<GP + f>(gcf[f]);
+                static_range<f0, f1>([&](auto hc) PJR_INL { if constexpr (decltype(hc)::value != f) gv *= gpw[decltype(hc)::value]; });
+                slot(std::integral_constant<int, pjs::GEN_SP[GP + f][0]>{}, gv);
+            });
+        }
+        if constexpr ((FL & F_COLLIDER) != 0)
+            slot(std::integral_constant<int, (pjs::RI[i][RI_COLLIDER] >= 0 ? pjs::RI[i][RI_COLLIDER] : ONE)>{}, bcol_);
+        if constexpr ((FL & F_EFFTYPE) != 0) {
+            static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
+                constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
+                constexpr int es = pjs::EFF_SP[e][0];
+                // the last species' enhanced efficiency is already in gN (RD_ANM1)
+                if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, EFC(e) * bM_);
+            });
+        }
+        const double rq = rp + gN;
+        const double del = theta * v0 + rp * SV1 - rq * SV0N + dot;
+        static_for<ncnt>([&](auto qc) PJR_INL {
+            constexpr int q = np0 + decltype(qc)::value;
+            constexpr int k = pjs::NET_SP[q][0];
+            constexpr double nu = pjs::NET_NU[q][0];
+            acc[k] += nu * del;
+            // reference quirk (create_jacobian.py:2786-2818): J_nplusone is assigned, not accumulated
+            if constexpr (k == LAST) JTN += nu * theta;
+            if constexpr (k == LAST && i == pjs::LASTQ) JTQ = nu * theta;
+        });
+        // (without a barrier nothing orders the reactions and the scheduler interleaves -- and keeps live -- far more of
+        // them than the register file holds; a pair at a time fills the fp64 pipeline's dependent-issue bubbles)
+        if constexpr (((i - R0_) / G_ + 1) % PJQ_JVD_SB == 0) PJQ_SCHED_BARRIER();
+    };
+    group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
+        if constexpr (PJQ_JVD_AHEAD) fetch(std::integral_constant<int, R0_ + decltype(gc)::value>{});
+        static_range<R0_, R1_>([&](auto ic) PJR_INL {
+            if constexpr ((decltype(ic)::value - R0_) % G_ == decltype(gc)::value) visit(ic);
+        });
+    });
+    (void)jtq; (void)logp; (void)p; (void)hv; (void)ekc; (void)tdk;
+
+    // mass-fraction weighted c_p sums from the concentrations (Y_k c_p,k = C_k R (a0 + ...) / rho) and the vector's share
+    // sum_j c_p,j v_{j+1}: taken before the groups reuse the concentration columns
+    double cpa = 0.0, dcpa = 0.0, cpN = 0.0, SCV = 0.0;
+    PJQ_SCHED_BARRIER();
+    fresh();
+    if constexpr (LASTK_) {
+        if (grp == 0)
+            static_for<NSP>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                double hW, cpm, dcpm;
+                nasa(kc, hW, cpm, dcpm);
+                const double Ck = CC(k);
+                cpa += Ck * cpm;
+                dcpa += Ck * dcpm;
+                const double cpk = (RU_ * pjs::SP[k][0]) * cpm;
+                if constexpr (k == LAST) cpN = cpk;
+                else SCV += cpk * (pjs::SP[k][1] * VS(k + 1));
+            });
+    }
+#if PJQ_HALVES > 1
+    // the groups' shares meet in group 0: D_k through the concentration columns (nobody reads them any more)
+    static_range<1, G_>([&](auto gc) PJR_INL {
+        constexpr int g = decltype(gc)::value;
+        __syncthreads();
+        if (grp == g) {
+            static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = acc[decltype(kc)::value]; });
+            RED[0][tid] = JTN; RED[1][tid] = JTQ; RED[2][tid] = Hs; RED[3][tid] = SCP;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            static_for<NSP>([&](auto kc) PJR_INL { acc[decltype(kc)::value] += CL[decltype(kc)::value][tid]; });
+            JTN += RED[0][tid]; JTQ += RED[1][tid]; Hs += RED[2][tid]; SCP += RED[3][tid];
+        }
+    });
+    if (grp != 0) return;
+#endif
+    if constexpr (!LASTK_) {
+        static_for<NSP>([&](auto kc) PJR_INL { A.sr[(SR_D + decltype(kc)::value) * A.sr_ld + s] = acc[decltype(kc)::value]; });
+        A.sr[(SR_SC + 0) * A.sr_ld + s] = JTN; A.sr[(SR_SC + 1) * A.sr_ld + s] = JTQ;
+        A.sr[(SR_SC + 2) * A.sr_ld + s] = Hs; A.sr[(SR_SC + 3) * A.sr_ld + s] = SCP;
+    } else {
+        double* wp = A.w + s * A.w_ss;
+        double HD = 0.0, hWN = 0.0;
+        PJQ_SCHED_BARRIER();
+        fresh();
+        static_for<NSP>([&](auto kc) PJR_INL {
+            constexpr int k = decltype(kc)::value;
+            double hW, cpm, dcpm;
+            nasa(kc, hW, cpm, dcpm);
+            HD += hW * acc[k];
+            if constexpr (k == LAST) hWN = hW;
+            else wp[(k + 1) * A.w_si] = pjs::SP[k][1] * acc[k];
+        });
+        const double cpavg = cpa * (RU_ * invrho), dcpavg = dcpa * (RU_ * invrho);
+        const double icp = 1.0 / cpavg;
+        const double quirk = A.sum_last ? 0.0 : hWN * (JTQ - JTN) * v0;
+        wp[0] = -((SCP - (dcpavg * icp) * Hs) / (rho * cpavg)) * v0 - icp * (HD + quirk) +
+                (SCV - cpN * SV0) * Hs * invrho * icp * icp;
+    }
+#undef CC
+#undef VS
+#undef SCR_ST
+}
+
+void launch_jvd(const PjqArgs& A, void* stream)
+{
+    const long blocks = (A.n + PJQ_BLOCK - 1) / PJQ_BLOCK;
+    hipLaunchKernelGGL(k_jvd, dim3((unsigned)blocks), dim3(NTHR), 0, (hipStream_t)stream, A);
+}
+struct Reg { Reg() { pjq_register(PJQ_ID, 9, launch_jvd); } } reg_;     // 9: w = J v, every reaction once
+#endif  // PJQ_PART == 5
+
 #if PJQ_PART == 0
 constexpr int MAXPARTS = 256;
 pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_rows_gen[MAXPARTS], g_rows_jv[MAXPARTS], g_timing[MAXPARTS];
-pjq_launch_fn g_rate_lean[MAXPARTS], g_rate_full[MAXPARTS];
+pjq_launch_fn g_rate_lean[MAXPARTS], g_rate_full[MAXPARTS], g_jvd[MAXPARTS];
 constexpr int MAXSTREAMS = 8;
 // Everything a batch needs beyond the caller's arrays belongs to a CONTEXT: hand-over arrays, internal streams and
 // events, the AoS staging block, the rate kernels' scratch, and the launch settings.  pj_api.hip creates one per
@@ -2571,6 +3074,9 @@ struct Ctx {
     long rate_scr_ld = 0;
     double* rate_dummy = nullptr;        // one row that takes the per-reaction outputs the caller does not want
     long rate_dummy_ld = 0;
+    double* jvd_scr[MAXSTREAMS] = {};    // D_k and four scalars between the k_jvd kernels of a library that has several
+    long jvd_scr_ld[MAXSTREAMS] = {};
+    int cfg_row_jv = 0;                  // w = J v through the row kernels' PJQ_JV builds (if the library has them)
     // launch settings: the environment is read ONCE, when the context is created (PJ_RBLK_STREAMS, PJ_RBLK_CHUNK,
     // PJ_RBLK_SPLIT, PJ_RBLK_AOS_DIRECT); pj_spec_ctx_config overrides them
     int cfg_streams = 0;                 // 0: the build's default (PJQ_STREAMS)
@@ -2583,6 +3089,7 @@ struct Ctx {
         if (const char* e = getenv("PJ_RBLK_CHUNK")) cfg_chunk = atol(e);
         if (const char* e = getenv("PJ_RBLK_SPLIT")) cfg_split = atoi(e) != 0;
         cfg_aos_direct = getenv("PJ_RBLK_AOS_DIRECT") != nullptr;
+        cfg_row_jv = getenv("PJ_RBLK_ROW_JV") != nullptr;
     }
     void release()
     {
@@ -2593,6 +3100,7 @@ struct Ctx {
             if (cur != device) (void)hipSetDevice(device);
             (void)hipDeviceSynchronize();
             for (auto& p : scr) if (p) { (void)hipFree(p); p = nullptr; }
+            for (auto& p : jvd_scr) if (p) { (void)hipFree(p); p = nullptr; }
             if (aos_tmp) (void)hipFree(aos_tmp);
             if (rate_scr) (void)hipFree(rate_scr);
             if (rate_dummy) (void)hipFree(rate_dummy);
@@ -2622,7 +3130,7 @@ void pjq_register(int id, int kind, pjq_launch_fn fn)
 {
     if (kind == 1) g_pre = fn;
     else if (id >= 0 && id < MAXPARTS)
-        (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : kind == 6 ? g_rows_jv : kind == 7 ? g_rate_lean : kind == 8 ? g_rate_full : g_rows)[id] = fn;
+        (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : kind == 6 ? g_rows_jv : kind == 7 ? g_rate_lean : kind == 8 ? g_rate_full : kind == 9 ? g_jvd : g_rows)[id] = fn;
 }
 
 // debug builds (-DPJQ_TIMING): cycles per phase of row kernel `part`, [5][1024 workgroups][4 wavefronts]
@@ -2691,7 +3199,11 @@ static int run_batch(Ctx& C, long n, const double* pres, const double* y, long y
 {
     if (n <= 0) return 0;
     const bool jv = w != nullptr;
-    if (jv && !g_rows_jv[0]) return -5;
+    // w = J v: k_jvd (every reaction once) unless the library has only the row kernels' PJQ_JV builds or those are asked for
+    const bool jvd = jv && g_jvd[0] && !(C.cfg_row_jv && g_rows_jv[0]);
+    if (jv && !jvd && !g_rows_jv[0]) return -5;
+    int njvd = 0;
+    while (jvd && njvd < MAXPARTS && g_jvd[njvd]) ++njvd;
     std::lock_guard<std::mutex> lock(C.batch_mutex);
     if (const int rc = enter_batch(C, stream)) return rc;
     int nstreams = C.cfg_streams > 0 ? C.cfg_streams : PJQ_STREAMS;
@@ -2722,8 +3234,10 @@ static int run_batch(Ctx& C, long n, const double* pres, const double* y, long y
     if (chunk > n) chunk = (n + PJQ_TILE - 1) / PJQ_TILE * PJQ_TILE;
     const long nchunks = (n + chunk - 1) / chunk;
     const int S = (int)(nchunks < nstreams ? nchunks : nstreams);
-    for (int b = 0; b < S; ++b)
-        if (const int rc = grow(C.scr[b], C.scr_ld[b], chunk, (size_t)NSLOTS)) return rc;
+    for (int b = 0; b < S; ++b) {
+        if (jvd) { if (njvd > 1) if (const int rc = grow(C.jvd_scr[b], C.jvd_scr_ld[b], chunk, (size_t)NSP + 4)) return rc; }
+        else if (const int rc = grow(C.scr[b], C.scr_ld[b], chunk, (size_t)NSLOTS)) return rc;
+    }
     hipStream_t user = (hipStream_t)stream;
     if (S > 1) {
         if (!C.have_streams) {
@@ -2750,6 +3264,11 @@ static int run_batch(Ctx& C, long n, const double* pres, const double* y, long y
         A.tile_rt = PJQ_TILE;
         const bool fast = fast_ok && m >= PJQ_BLOCK;
         if (!jv && !fast && !have_gen) return -5;
+        if (jvd) {
+            A.sr = C.jvd_scr[b]; A.sr_ld = C.jvd_scr_ld[b];
+            for (int i = 0; i < njvd; ++i) g_jvd[i](A, st);
+            continue;
+        }
         if (g_pre) g_pre(A, st);
         pjq_launch_fn* rows = jv ? g_rows_jv : fast ? g_rows : g_rows_gen;
         for (int i = 0; i < MAXPARTS; ++i) if (rows[i]) rows[i](A, st);
@@ -2812,6 +3331,16 @@ int pj_spec_ctx_config(void* ctx, int streams, long chunk, int split, int aos_di
     if (split >= 0) C.cfg_split = split != 0;
     if (aos_direct >= 0) C.cfg_aos_direct = aos_direct != 0;
     return 0;
+}
+
+// w = J v through the row kernels' PJQ_JV builds (on = 1; a library that has them) or through k_jvd (on = 0, the default);
+// returns what is in force afterwards (also the environment: PJ_RBLK_ROW_JV)
+int pj_spec_ctx_row_jv(void* ctx, int on)
+{
+    Ctx& C = ctx ? *(Ctx*)ctx : default_ctx();
+    std::lock_guard<std::mutex> lock(C.batch_mutex);
+    if (on >= 0) C.cfg_row_jv = on != 0;
+    return (C.cfg_row_jv && g_rows_jv[0]) || !g_jvd[0] ? 1 : 0;
 }
 
 int pj_spec_jacobian_ctx(void* ctx, long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,

@@ -199,6 +199,28 @@ def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0):
     return block, halves, kcf, single, ecols, coop
 
 
+def jvd_geometry(nsp: int, nkc: int, rate_block_clds: int = 0):
+    """(states per workgroup, lane groups, concentrations in LDS, vector in LDS) of k_jvd, or None if nothing fits.
+    nkc: K_c groups of the mechanism (128 bytes each; a kernel stages those of its reaction range: at most what the
+    rate-kernel plan of pj_tables.cpp leaves room for, rate_block_clds = the states per workgroup that plan reserves
+    concentration columns for).  A lane holds D_k (NSP doubles); concentrations and scaled vector sit in LDS columns that
+    four lane groups share, each taking every fourth reaction: 128 states per workgroup (512 threads, two wavefronts per
+    SIMD, 256 registers per lane) up to 64 species if the columns fit, 64 states otherwise.  Measured, 1e6 GRI-shaped
+    products (profiles/r05_jvd_variants.txt): 128 x 4 2.20 ms; 256 states, one group, vector in registers 2.45; everything in
+    registers 2.54 (a third of the lane's values then live in AGPRs: 4.7 k v_accvgpr moves)."""
+    env = os.environ.get('PJ_RBLK_JVD_GEOMETRY')        # "block,groups,conc_in_lds,vector_in_lds"
+    if env:
+        return tuple(int(x) for x in env.split(','))
+    plan_rows = (LDS_BYTES - nsp * rate_block_clds * 8 - 2048) // 128       # (pj_tables.cpp: rlimit)
+    rows = min(nkc, plan_rows) if nkc else plan_rows
+    fits = lambda block, groups, cols: 8 * (max(rows, 1) * 16 + cols * nsp * block + (4 * block if groups > 1 else 0)) <= LDS_BYTES
+    cands = ([(128, 4, 1, 1)] if nsp <= 64 else []) + [(64, 4, 1, 1)]
+    for block, groups, c_lds, v_lds in cands:
+        if fits(block, groups, c_lds + v_lds):
+            return block, groups, c_lds, v_lds
+    return None
+
+
 def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=(),
                kcf_rows=None, nkc: int = 0):
     """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the falloff / PLOG
@@ -268,21 +290,34 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
         list(defines) + os.environ.get('PJ_RBLK_DEFINES', '').split() + [src]
     rate = common + flags + ['-DPJQ_BLOCK=%d' % r_block, '-DPJQ_C_LDS=%d' % r_clds, '-DPJQ_HALVES=%d' % r_halves] + \
         list(defines) + os.environ.get('PJ_RBLK_RATE_DEFINES', '').split() + [src]
+    # w = J v (k_jvd: every reaction once, pj_rblk.hip): D_k in registers; concentrations and vector in registers too, or in
+    # LDS columns (jvd_geometry)
+    jvd_geo = jvd_geometry(nsp, nkc, r_block if r_clds else 0)
+    jvd = None if jvd_geo is None else common + flags + \
+        ['-DPJQ_BLOCK=%d' % jvd_geo[0], '-DPJQ_HALVES=%d' % jvd_geo[1], '-DPJQ_C_LDS=%d' % jvd_geo[2], '-DPJQ_V_LDS=%d' % jvd_geo[3]] + \
+        list(defines) + os.environ.get('PJ_RBLK_JVD_DEFINES', '').split() + [src]
     jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
     if npre or ecl:
         jobs.append((pre + ['-DPJQ_PART=1'], 'pre.o'))
     # each row kernel three times: with pair stores (SoA output, whole workgroups: the fast path), general,
     # and as w = J v (the Jacobian consumed in registers)
-    pair_modes = [int(x) for x in os.environ.get('PJ_RBLK_PAIR_MODES', '1,0').split(',')]
+    pair_modes = [int(x) for x in os.environ.get('PJ_RBLK_PAIR_MODES', '1,0').split(',') if x.strip()]
+    # ... and, on request (PJ_RBLK_ROW_JV=1) or when k_jvd's columns do not fit the LDS, as w = J v with the Jacobian consumed
+    # in registers (rounds 2 - 4's fused product: 3.6 visits per reaction; k_jvd visits each once)
+    no_jv = bool(os.environ.get('PJ_RBLK_NO_JV'))       # (experiments: no w = J v kernels at all)
+    row_jv = not no_jv and (bool(os.environ.get('PJ_RBLK_ROW_JV')) or jvd is None)
     for i in range(nker):
         for pair in pair_modes:
             jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=%d' % pair], 'rblk%d_%d.o' % (i, pair)))
-        if not os.environ.get('PJ_RBLK_NO_JV'):     # (experiments: skip the w = J v build)
+        if row_jv:
             jobs.append((rblk + ['-DPJQ_PART=2', '-DPJQ_ID=%d' % i, '-DPJQ_PAIR=0', '-DPJQ_JV=1'], 'rblk%d_jv.o' % i))
     if fin:
         jobs.append((rblk + ['-DPJQ_PART=4'], 'fin.o'))
-        if not os.environ.get('PJ_RBLK_NO_JV'):
+        if row_jv:
             jobs.append((rblk + ['-DPJQ_PART=4', '-DPJQ_JV=1'], 'fin_jv.o'))
+    if jvd is not None and not no_jv:
+        for i in range(nrate):
+            jobs.append((jvd + ['-DPJQ_PART=5', '-DPJQ_ID=%d' % i], 'jvd%d.o' % i))
     for i in range(nrate):
         for full in (0, 1):
             jobs.append((rate + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % i, '-DPJQ_FULL=%d' % full], 'rate%d_%d.o' % (i, full)))

@@ -13,14 +13,15 @@ CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
 
 def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int = 128, c_lds: int = 0,
                opt: str = '-O1', defines=(), halves: int = 1, kcf: int = 0, single: int = 0, ecl: int = None,
-               pre_halves: int = 1, fin: int = None) -> str:
+               pre_halves: int = 1, fin: int = None, jvd=(1, None, 0), only_jvd: bool = False) -> str:
     """csrc/pj_rblk.hip for the host: row blocks that rebuild their rates + falloff / PLOG pre-pass (k_pre,
     k_rblk, also as w = J v) and the rate-output kernels (k_rate, one per `rates_per_part` reactions, with and
     without the per-reaction outputs), the way specbuild.build_rblk links them.  halves: lane groups of the row kernels
     (each one OS thread in the emulation); kcf: equilibrium constants from the per-species factor columns (the header
     must carry the rows: pj_mech_set_kc_factors before it was emitted); single: one row kernel for every block;
     ecl: the energy-row terms a row block cannot see summed by the pre-pass (PJQ_ECL; default as specbuild: with several
-    lane groups and polynomial K_c); pre_halves: lane groups of the pre-pass (2 needs c_lds)."""
+    lane groups and polynomial K_c); pre_halves: lane groups of the pre-pass (2 needs c_lds); jvd: (lane groups,
+    concentrations in LDS, vector in LDS) of k_jvd (w = J v, every reaction once); only_jvd: no other kernels."""
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
     t = open(hdr).read()
@@ -61,6 +62,15 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
             jobs.append((base + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % n, '-DPJQ_R0=%d' % r0, '-DPJQ_R1=%d' % min(nrxn, r0 + rates_per_part),
                                  '-DPJQ_FIRST=%d' % (n == 0), '-DPJQ_LAST=%d' % (n == len(rstarts) - 1),
                                  '-DPJQ_FULL=%d' % full], 'rate%d_%d.o' % (n, full)))
+
+    if only_jvd:
+        jobs = jobs[:1]
+    jg, jc, jvl = jvd
+    jc = int(jg > 1 or jvl) if jc is None else jc
+    jflags = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % jc, '-DPJQ_HALVES=%d' % jg, '-DPJQ_V_LDS=%d' % jvl] + [os.path.join(CSRC, 'pj_rblk.hip')]
+    for n, r0 in enumerate(rstarts):
+        jobs.append((jflags + ['-DPJQ_PART=5', '-DPJQ_ID=%d' % n, '-DPJQ_R0=%d' % r0, '-DPJQ_R1=%d' % min(nrxn, r0 + rates_per_part),
+                               '-DPJQ_FIRST=%d' % (n == 0), '-DPJQ_LAST=%d' % (n == len(rstarts) - 1)], 'jvd%d.o' % n))
 
     def run(j):
         subprocess.check_call(j[0] + ['-o', os.path.join(work, j[1])])

@@ -87,12 +87,12 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     # PJQ_FIN: the energy row finished by k_fin, a kernel of its own behind the row kernels (several kernels; one kernel whose
     # column sums travel through the hand-over array)
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, fin=1)),
-    ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, fin=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
+    ('synth_alltypes', 16, dict(rates_per_part=7, halves=4, single=1, fin=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
     # ... and PJQ_ECL with the factor columns: one kernel (the sums land in the EJ columns behind the prologue) and several
-    ('synth_mid24', 40, dict(rates_per_part=40, kcf=1, halves=4, single=1, ecl=1)),
+    ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1, ecl=1)),
     # ONE row kernel with polynomial K_c rows (the 111-species geometry: no LDS room for the finished column sums, which
     # travel through the hand-over array -- PJQ_ECOLS), four lane groups with a cooperative prologue (PJQ_COOP)
-    ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
+    ('synth_alltypes', 16, dict(rates_per_part=7, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
     ('synth_srichb', 16, dict(rates_per_part=5, halves=2, single=1, c_lds=1, pre_halves=2,
                               defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1', '-DPJQ_DEFER=1'))),
     # PJQ_DEFER: the rows of a block are stored during the visits of the next one
@@ -124,7 +124,7 @@ def test_rblk_kernels_vs_oracle(name, budget, kw, tmp_path, tables):
     from oracle.oracle import Oracle
     ev, L = _rblk_emu_lib(name, budget, str(tmp_path), **kw)
     orc = Oracle(tables(name))
-    n = 300                               # crosses a 256-state hand-over tile
+    n = 262                               # crosses a 256-state hand-over tile
     # (T from 300 K: every range of every species' NASA polynomials and K_c group is visited)
     pres, y = synth.dist_b(n, ev.nsp) if name != 'fe_septherm' else synth.dist_b(n, ev.nsp, seed=3, Tlo=300, Thi=2600)
     ref = orc.batch_jacob(pres, np.ascontiguousarray(y.T))
@@ -192,9 +192,12 @@ def test_rblk_kernels_vs_reference_golden(tmp_path_factory, golden):
 ])
 def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
     """N2 for the row-block family: w = J v per state with the Jacobian consumed in registers
-    (pj_spec_jacvec, PJQ_JV kernels) against the oracle's Jacobian times the same vectors, both layouts."""
+    (pj_spec_jacvec through the row kernels' PJQ_JV builds: pj_spec_ctx_row_jv) against the oracle's Jacobian times the
+    same vectors, both layouts."""
     from oracle.oracle import Oracle
     ev, L = _rblk_emu_lib(name, budget, str(tmp_path), **kw)
+    L.pj_spec_ctx_row_jv.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert L.pj_spec_ctx_row_jv(None, 1) == 1
     L.pj_spec_jacvec.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp, ctypes.c_long, ctypes.c_long,
                                  _dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
     n, nsp = 300, ev.nsp
@@ -210,4 +213,49 @@ def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
     assert (np.abs(ws.T - ref) / scale).max() < 1e-9
     ya, va, wa = np.ascontiguousarray(y.T), np.ascontiguousarray(v.T), np.full((n, nsp), np.nan)
     assert L.pj_spec_jacvec(n, P(pres), P(ya), 1, nsp, P(va), 1, nsp, P(wa), 1, nsp, 0, None) == 0
+    assert (np.abs(wa - ref) / scale).max() < 1e-9
+
+
+@pytest.mark.parametrize('name,budget,kw', [
+    # everything in registers; reaction ranges over several kernels (D_k and the scalars through `sr`)
+    ('synth_alltypes', 16, dict(rates_per_part=7)),
+    ('synth_srichb', 16, dict(rates_per_part=5)),
+    ('synth_fracnu', 16, dict(rates_per_part=6)),
+    ('synth_irrev72', 40, dict(rates_per_part=1000)),
+    ('synth_mid24', 40, dict(rates_per_part=1000, jvd=(1, 1, 0))),
+    # two lane groups on the same states (every other reaction each), concentrations in LDS
+    ('synth_mid24', 40, dict(rates_per_part=40, jvd=(2, 1, 0))),
+    # the large-mechanism geometry: four lane groups, concentrations and vector in LDS columns
+    ('synth_alltypes', 16, dict(rates_per_part=7, jvd=(4, 1, 1))),
+    ('synth_mid24', 40, dict(rates_per_part=1000, jvd=(4, 1, 1))),
+])
+@pytest.mark.parametrize('sum_last', [0, 1])
+def test_jvd_directional_derivative_vs_oracle(name, budget, kw, sum_last, tmp_path, tables):
+    """k_jvd (pj_spec_jacvec's default): w = J v with every reaction visited once -- d_i = the reaction's derivative row
+    times the vector, scattered like q_i -- against the oracle's Jacobian times the same vectors, with and without the
+    J_nplusone quirk (sum_last), both layouts, a batch that ends inside a workgroup."""
+    from oracle.oracle import Oracle
+    ev, L = _rblk_emu_lib(name, budget, str(tmp_path), only_jvd=True, **kw)
+    L.pj_spec_jacvec.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp, ctypes.c_long, ctypes.c_long,
+                                 _dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    L.pj_spec_ctx_row_jv.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert L.pj_spec_ctx_row_jv(None, 0) == 0
+    n, nsp = 131, ev.nsp
+    pres, y = synth.dist_b(n, nsp, seed=12, Tlo=400, Thi=2500)
+    v = np.random.default_rng(3).standard_normal((nsp, n))
+    v[0] *= 100.0
+    orc = Oracle(tables(name))
+    orc.lib.pjo_set_sum_last_species(sum_last)
+    try:
+        J = orc.batch_jacob(pres, np.ascontiguousarray(y.T)).reshape(n, nsp, nsp)   # [s][col][row]
+    finally:
+        orc.lib.pjo_set_sum_last_species(0)
+    ref = np.einsum('scr,cs->sr', J, v)
+    scale = np.einsum('scr,cs->sr', np.abs(J), np.abs(v)) + 1e-300
+    P = lambda a: a.ctypes.data_as(_dp)
+    ys, vs, ws = np.ascontiguousarray(y), np.ascontiguousarray(v), np.full((nsp, n), np.nan)
+    assert L.pj_spec_jacvec(n, P(pres), P(ys), n, 1, P(vs), n, 1, P(ws), n, 1, sum_last, None) == 0
+    assert (np.abs(ws.T - ref) / scale).max() < 1e-9
+    ya, va, wa = np.ascontiguousarray(y.T), np.ascontiguousarray(v.T), np.full((n, nsp), np.nan)
+    assert L.pj_spec_jacvec(n, P(pres), P(ya), 1, nsp, P(va), 1, nsp, P(wa), 1, nsp, sum_last, None) == 0
     assert (np.abs(wa - ref) / scale).max() < 1e-9

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5: w = J v as a directional derivative (k_jvd) against the row kernels' fused product (shipped library)
+mkdir -p gpurun_out
+{
+python tools/jv_time.py pyjac_amd/data/gri30_shaped.inp 1000000 rblk jvdw0 jvdw jvdl
+python tools/jv_time.py pyjac_amd/data/usc2_shaped.inp 200000 rblk jvd0 jvd
+} 2>&1 | grep -v "Warning\|amdgpu.ids" | tee gpurun_out/r05_jvd.txt
