@@ -323,3 +323,29 @@ def test_rblk_geometry_fits_the_lds(tmp_path):
                                '-DPJQ_C_LDS=0', '-DPJQ_HALVES=%d' % halves, '-DPJQ_KCF=%d' % kcf, '-DPJQ_COOP=%d' % coop,
                                '-DPJQ_PART=2', '-DPJQ_ID=%d' % (nker - 1), '-DPJQ_PAIR=0', '-DPJQ_JV=%d' % jv,
                                os.path.join(specbuild.CSRC, 'pj_rblk.hip')])
+    # k_jvd (w = J v, every reaction once): the geometry picked for this mechanism against the kernel's own static_assert
+    geo = specbuild.jvd_geometry(ev.nsp, int(ev.tables.I[10]), 0)
+    assert geo == (128, 4, 1, 1)
+    subprocess.check_call([specbuild._hipcc(), '--offload-arch=gfx950', '-O1', '-std=c++17', '-fPIC', '-c', '-fsyntax-only',
+                           '-DPJS_HEADER="%s"' % hdr, '-I', specbuild.CSRC, '-DPJQ_SUMSETS=0', '-DPJQ_SINGLE=1', '-DPJQ_ECL=0',
+                           '-DPJQ_BLOCK=%d' % geo[0], '-DPJQ_HALVES=%d' % geo[1], '-DPJQ_C_LDS=%d' % geo[2], '-DPJQ_V_LDS=%d' % geo[3],
+                           '-DPJQ_PART=5', '-DPJQ_ID=0', os.path.join(specbuild.CSRC, 'pj_rblk.hip')])
+
+
+def test_jvd_geometry_model():
+    """specbuild.jvd_geometry: columns + the K_c rows a kernel may have to stage (at most what the rate-kernel plan leaves
+    room for) fit the LDS, for every size the row-block family serves."""
+    from pyjac_amd import specbuild
+    for nsp in range(8, 141):
+        rate_block = 128 if nsp > 64 else 0          # (build_rblk: r_block if r_clds else 0)
+        for nkc in (0, 50, 300, 800, 2000):
+            geo = specbuild.jvd_geometry(nsp, nkc, rate_block)
+            if geo is None:
+                continue
+            block, groups, c_lds, v_lds = geo
+            plan_rows = (specbuild.LDS_BYTES - nsp * rate_block * 8 - 2048) // 128
+            rows = min(nkc, plan_rows) if nkc else plan_rows
+            lds = 8 * (max(rows, 1) * 16 + (c_lds + v_lds) * nsp * block + (4 * block if groups > 1 else 0))
+            assert lds <= specbuild.LDS_BYTES, (nsp, nkc, geo)
+            assert block * groups <= 512 and (block * groups < 512 or nsp <= 64)      # 256 registers per lane at 512 threads
+    assert specbuild.jvd_geometry(53, 313, 0) == (128, 4, 1, 1) and specbuild.jvd_geometry(111, 749, 128) == (64, 4, 1, 1)
