@@ -26,7 +26,6 @@ def _rblk_emu_lib(name, budget, tmp, **kw):
 @pytest.mark.parametrize('name,budget,kw', [
     ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1)),
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=1000)),
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
     # N1: fractional stoichiometric coefficients, more than three molecules / species per side
     ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6)),
@@ -76,17 +75,14 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     # several lane groups per workgroup on the same states (each an OS thread in the emulation, a real barrier behind
     # __syncthreads): groups split the row blocks of a kernel, exchange the energy-row sums and share its columns
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
-    ('synth_mid24', 40, dict(blocks_per_part=6, rates_per_part=40, halves=4)),
     # the energy-row terms a row block cannot see (enhanced colliders, a falloff collider, a species on both sides): summed
     # once per state by the pre-pass (PJQ_ECL, the default with several lane groups -- the cases above and below) -- here
-    # with a two-group pre-pass (the 111-species geometry), with one lane group, and the long-lived sums they replace
+    # with a two-group pre-pass (the 111-species geometry) and with one lane group
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, c_lds=1, pre_halves=2)),
     ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, c_lds=1, ecl=1)),
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2)),
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, ecl=0)),
-    # PJQ_FIN: the energy row finished by k_fin, a kernel of its own behind the row kernels (several kernels; one kernel whose
+    # PJQ_FIN: the energy row finished by k_fin, a kernel of its own behind the row kernels (here: one row kernel whose
     # column sums travel through the hand-over array)
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, fin=1)),
     ('synth_alltypes', 16, dict(rates_per_part=7, halves=4, single=1, fin=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
     # ... and PJQ_ECL with the factor columns: one kernel (the sums land in the EJ columns behind the prologue) and several
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1, ecl=1)),
@@ -96,12 +92,10 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('synth_srichb', 16, dict(rates_per_part=5, halves=2, single=1, c_lds=1, pre_halves=2,
                               defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1', '-DPJQ_DEFER=1'))),
     # PJQ_DEFER: the rows of a block are stored during the visits of the next one
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, defines=('-DPJQ_DEFER=1',))),
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1, defines=('-DPJQ_DEFER=1',))),
     # equilibrium constants from per-species factor columns (PJQ_KCF: cooperative prologue, products instead of a
     # polynomial + exp per visit): one group and several kernels; four groups and ONE kernel (the 53-species shape)
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, kcf=1)),
-    ('synth_mid24', 40, dict(rates_per_part=40, kcf=1, halves=4, single=1)),
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1)),
     ('h2o2_n2', 12, dict(blocks_per_part=2, rates_per_part=5, kcf=1, halves=2)),
     # ... with species of three different T_mid (range select per species instead of per K_c group)
@@ -174,21 +168,29 @@ def test_rblk_kernels_vs_reference_golden(tmp_path_factory, golden):
     for k, cols in (('conc', nsp), ('fwd', ev.n_fwd), ('rev', ev.n_rev), ('pres_mod', ev.n_pres_mod)):
         mx, _ = thresholded_rel_err(bufs[k].T[:, :cols], g[k][:, :cols])
         assert mx < 1e-9, (k, mx)
+    # ... and w = J v (k_jvd: every reaction once) against pyJac's own Jacobians times the same vectors
+    L.pj_spec_jacvec.argtypes = [ctypes.c_long, _dp, _dp, ctypes.c_long, ctypes.c_long, _dp, ctypes.c_long, ctypes.c_long,
+                                 _dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    L.pj_spec_ctx_row_jv.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert L.pj_spec_ctx_row_jv(None, 0) == 0
+    v = np.random.default_rng(4).standard_normal((nsp, n))
+    v[0] *= 100.0
+    J = g['jac'].reshape(n, nsp, nsp)           # [s][col][row]
+    ref = np.einsum('scr,cs->sr', J, v)
+    scale = np.einsum('scr,cs->sr', np.abs(J), np.abs(v)) + 1e-300
+    w = np.full((nsp, n), np.nan)
+    assert L.pj_spec_jacvec(n, P(pres), P(y), n, 1, P(np.ascontiguousarray(v)), n, 1, P(w), n, 1, 0, None) == 0
+    assert (np.abs(w.T - ref) / scale).max() < 1e-9
 
 
 @pytest.mark.parametrize('name,budget,kw', [
     ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7)),
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40)),
     # one kernel, four lane groups, factor columns: v lives in an LDS column set, finished column sums fold into w_0
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1)),
     # two lane groups over several kernels: v in registers, column sums through the hand-over array
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
+    ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5, halves=2, c_lds=1, pre_halves=2)),
     # ... with the pre-pass's column sums (PJQ_ECL) folded into w_0's share behind the prologue
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1, ecl=1)),
-    # one kernel, four lane groups, polynomial K_c rows, column sums through the hand-over array
-    ('synth_mid24', 40, dict(rates_per_part=40, halves=4, single=1, defines=('-DPJQ_ECOLS=1', '-DPJQ_COOP=1'))),
-    # ... and w_0 finished by k_fin
-    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2, fin=1)),
 ])
 def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
     """N2 for the row-block family: w = J v per state with the Jacobian consumed in registers
@@ -221,7 +223,6 @@ def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
     ('synth_alltypes', 16, dict(rates_per_part=7)),
     ('synth_srichb', 16, dict(rates_per_part=5)),
     ('synth_fracnu', 16, dict(rates_per_part=6)),
-    ('synth_irrev72', 40, dict(rates_per_part=1000)),
     ('synth_mid24', 40, dict(rates_per_part=1000, jvd=(1, 1, 0))),
     # two lane groups on the same states (every other reaction each), concentrations in LDS
     ('synth_mid24', 40, dict(rates_per_part=40, jvd=(2, 1, 0))),
