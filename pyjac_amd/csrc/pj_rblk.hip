@@ -2573,10 +2573,16 @@ struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_FULL ? 8 : 7, launch_rate); } } re
 #ifndef PJQ_JVD_SB
 #define PJQ_JVD_SB 2        // visits between scheduling barriers
 #endif
+#ifndef PJQ_JVD_KC_GLOBAL
+#define PJQ_JVD_KC_GLOBAL 0 // 1: the K_c rows are read from the mechanism table in global memory (L1 / L2 resident, a 16-byte load per
+                            // lane at one of two addresses) instead of from a copy in LDS: the vector memory path idles in this
+                            // kernel while the LDS is what bounds the large-mechanism geometry; and without the copy a kernel's
+                            // reaction range is not limited by the LDS (one kernel for the mechanism)
+#endif
 #ifndef PJQ_JVD_AHEAD
-#define PJQ_JVD_AHEAD (PJQ_C_LDS != 0)      // the K_c rows and concentrations of a lane group's NEXT reaction are read from LDS
-                            // while the current one is computed (k_rblk's PJQ_KC_AHEAD / PJQ_CONC_AHEAD: at one wavefront per
-                            // SIMD nothing else covers the LDS round trips at the top of every visit)
+#define PJQ_JVD_AHEAD (PJQ_C_LDS != 0)      // 1 / 2: the K_c rows and concentrations of a lane group's next / next but one reaction
+                            // are requested while the current one is computed (k_rblk's PJQ_KC_AHEAD / PJQ_CONC_AHEAD: at one
+                            // wavefront per SIMD nothing else covers the round trips at the top of every visit)
 #endif
 #define PJR_RECOMPUTE_KF 0
 #define PJR_RECOMPUTE_KR 1
@@ -2615,7 +2621,7 @@ constexpr KcMap make_kcmap()
     return m;
 }
 constexpr KcMap KCM = make_kcmap();
-constexpr int NKC = KCM.n;
+constexpr int NKC = PJQ_JVD_KC_GLOBAL ? 0 : KCM.n;
 struct KcList { int v[NKC > 0 ? NKC : 1]; };
 constexpr KcList make_list() { KcList l{}; for (int q = 0; q < NKC; ++q) l.v[q] = KCM.list[q]; return l; }
 __device__ const KcList KCL = make_list();
@@ -2745,6 +2751,11 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
     };
     fresh();
     const double WR = Wbar * invrho;
+    // NASA row pair of K_c group g
+    auto kcrow = [&](auto gc) PJR_INL -> const double* {
+        if constexpr (PJQ_JVD_KC_GLOBAL) return pjs::LTAB + pjs::LT_KC + (long)decltype(gc)::value * 16;
+        else return LTK + KCM.loc[decltype(gc)::value] * 16;
+    };
     double ekc[pjs::NKCCLS], tdk[pjs::NKCCLS];
     double jtd[NSP], jtq = 0.0;         // pj_rate_pre.inc's d/dT sums: dead here
     auto rate_out = [](auto, double, double, double) {};
@@ -2762,9 +2773,10 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
         dcpm = a[1] + T * (2.0 * a[2] + T * (3.0 * a[3] + 4.0 * a[4] * T));
     };
     // what an Arrhenius visit reads from LDS first: requested one visit ahead (PJQ_JVD_AHEAD), into the buffer of its parity
-    double cab[PJQ_JVD_AHEAD ? 2 : 1][6], kab[PJQ_JVD_AHEAD ? 2 : 1][MAXKC][7];
+    constexpr int NBUF = PJQ_JVD_AHEAD + 1;
+    double cab[NBUF][6], kab[NBUF][MAXKC][7];
     auto fetch = [&](auto ic) PJR_INL {
-        constexpr int i = decltype(ic)::value, par = PJQ_JVD_AHEAD ? ((i - R0_) / G_) & 1 : 0;
+        constexpr int i = decltype(ic)::value, par = ((i - R0_) / G_) % NBUF;
         if constexpr (i < R1_) {
             if constexpr (!is_pre(i < R1_ ? i : R0_)) {
                 constexpr int FL = pjs::RI[i][RI_FLAGS];
@@ -2773,7 +2785,7 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
                     cab[par][3] = CC(pjs::RI[i][RI_P0]); cab[par][4] = CC(pjs::RI[i][RI_P1]); cab[par][5] = CC(pjs::RI[i][RI_P2]);
                     static_for<pjs::RI[i][RI_KC_CNT]>([&](auto cc) PJR_INL {
                         constexpr int c = decltype(cc)::value, g = pjs::RI[i][RI_KC_PTR] + c;
-                        const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                        const double* a = kcrow(std::integral_constant<int, g>{}) + ((T <= pjs::KCG[g][0]) ? 0 : 8);
                         static_for<7>([&](auto ec) PJR_INL { kab[par][c][decltype(ec)::value] = a[decltype(ec)::value]; });
                     });
                 }
@@ -2783,7 +2795,7 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
     // One reaction: q_i and d_i, the reaction's derivative row times the scaled vector
     auto visit = [&](auto ic) PJR_INL {
         constexpr int i = decltype(ic)::value;
-        constexpr int par = PJQ_JVD_AHEAD ? ((i - R0_) / G_) & 1 : 0;
+        constexpr int par = ((i - R0_) / G_) % (PJQ_JVD_AHEAD + 1);
         constexpr int FL = pjs::RI[i][RI_FLAGS];
         constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
         constexpr int GP = pjs::RI[i][RI_GEN_PTR];
@@ -2799,7 +2811,7 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
             constexpr bool RATES_OUT = false;
             double (&jt)[NSP] = jtd;
 #define PJR_RD(i_) pjs::RD[i_]
-#define PJR_KCROW(g_) (LTK + KCM.loc[g_] * 16)
+#define PJR_KCROW(g_) kcrow(std::integral_constant<int, g_>{})
 #define PJR_EFL(e_) pjs::EFF_AM1[e_][0]
 #define PJR_KC_FIRST(i_) true
 #define PJR_SCHED_BARRIER() ((void)0)
@@ -2821,10 +2833,10 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
             }
             a0 = cr0; a1 = cr1; a2 = cr2; b0 = cp0; b1 = cp1; b2 = cp2;
             hrt = TdlnKc;
-            if constexpr (PJQ_JVD_AHEAD) fetch(std::integral_constant<int, i + G_>{});
+            if constexpr (PJQ_JVD_AHEAD) fetch(std::integral_constant<int, i + PJQ_JVD_AHEAD * G_>{});
             static_for<KCNT>([&](auto cc) PJR_INL {
                 constexpr int g = pjs::RI[i][RI_KC_PTR] + decltype(cc)::value;
-                const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
+                const double* a = kcrow(std::integral_constant<int, g>{}) + ((T <= pjs::KCG[g][0]) ? 0 : 8);
                 dcr += a[1] + a[2] * Tc1 + a[3] * Tc2 + a[4] * Tc3 + a[5] * Tc4;
             });
         } else {
@@ -2838,7 +2850,7 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
             static_for<KCNT>([&](auto cc) PJR_INL {
                 static_for<7>([&](auto ec) PJR_INL { ka[decltype(cc)::value][decltype(ec)::value] = kab[par][decltype(cc)::value][decltype(ec)::value]; });
             });
-            if constexpr (PJQ_JVD_AHEAD) fetch(std::integral_constant<int, i + G_>{});
+            if constexpr (PJQ_JVD_AHEAD) fetch(std::integral_constant<int, i + PJQ_JVD_AHEAD * G_>{});
             double pr_ = a0 * a1 * a2, pp_ = b0 * b1 * b2;
             static_for<GNR + GNP>([&](auto fc) PJR_INL {
                 constexpr int f = decltype(fc)::value;
@@ -2966,7 +2978,7 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
         if constexpr (((i - R0_) / G_ + 1) % PJQ_JVD_SB == 0) PJQ_SCHED_BARRIER();
     };
     group_dispatch<0, G_>(grp, [&](auto gc) PJR_INL {
-        if constexpr (PJQ_JVD_AHEAD) fetch(std::integral_constant<int, R0_ + decltype(gc)::value>{});
+        static_for<PJQ_JVD_AHEAD>([&](auto ac) PJR_INL { fetch(std::integral_constant<int, R0_ + decltype(gc)::value + decltype(ac)::value * G_>{}); });
         static_range<R0_, R1_>([&](auto ic) PJR_INL {
             if constexpr ((decltype(ic)::value - R0_) % G_ == decltype(gc)::value) visit(ic);
         });
@@ -3077,6 +3089,7 @@ struct Ctx {
     double* jvd_scr[MAXSTREAMS] = {};    // D_k and four scalars between the k_jvd kernels of a library that has several
     long jvd_scr_ld[MAXSTREAMS] = {};
     int cfg_row_jv = 0;                  // w = J v through the row kernels' PJQ_JV builds (if the library has them)
+    long cfg_aos_chunk = 0;              // states per SoA staging block of the AoS path (0: 65536; PJ_RBLK_AOS_CHUNK)
     // launch settings: the environment is read ONCE, when the context is created (PJ_RBLK_STREAMS, PJ_RBLK_CHUNK,
     // PJ_RBLK_SPLIT, PJ_RBLK_AOS_DIRECT); pj_spec_ctx_config overrides them
     int cfg_streams = 0;                 // 0: the build's default (PJQ_STREAMS)
@@ -3090,6 +3103,7 @@ struct Ctx {
         if (const char* e = getenv("PJ_RBLK_SPLIT")) cfg_split = atoi(e) != 0;
         cfg_aos_direct = getenv("PJ_RBLK_AOS_DIRECT") != nullptr;
         cfg_row_jv = getenv("PJ_RBLK_ROW_JV") != nullptr;
+        if (const char* e = getenv("PJ_RBLK_AOS_CHUNK")) cfg_aos_chunk = atol(e);
     }
     void release()
     {
@@ -3353,6 +3367,7 @@ int pj_spec_jacobian_ctx(void* ctx, long n, const double* pres, const double* y,
         std::lock_guard<std::mutex> lock(C.aos_mutex);
         // chunks that fill the device (one workgroup per CU, 256 CUs) a whole number of times: 65536 states
         long chunk = 256L * PJQ_BLOCK < 65536 ? 65536 : 256L * PJQ_BLOCK;
+        if (C.cfg_aos_chunk >= PJQ_BLOCK) chunk = C.cfg_aos_chunk / PJQ_BLOCK * PJQ_BLOCK;
         if (chunk > n) chunk = n;
         if (const int rc = grow(C.aos_tmp, C.aos_tmp_states, chunk, (size_t)NE)) return rc;
         for (long s0 = 0; s0 < n; s0 += chunk) {

@@ -199,6 +199,14 @@ def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0):
     return block, halves, kcf, single, ecols, coop
 
 
+def JVD_KC_GLOBAL_DEFAULT(nsp: int) -> int:
+    """k_jvd's K_c rows from the mechanism table in global memory instead of LDS copies: the 64-state / four-group geometry of
+    the large mechanisms is bound by its LDS traffic (a third of it those rows) while its vector memory path idles, and
+    without the copies one kernel covers the mechanism: 2e5 USC-shaped products 2.34 -> 1.72 ms; the 128-state geometry
+    (two wavefronts per SIMD) is not: 1e6 GRI-shaped products 2.20 -> 2.26 ms (profiles/r05_jvd_variants.txt)."""
+    return int(nsp > 64)
+
+
 def jvd_geometry(nsp: int, nkc: int, rate_block_clds: int = 0):
     """(states per workgroup, lane groups, concentrations in LDS, vector in LDS) of k_jvd, or None if nothing fits.
     nkc: K_c groups of the mechanism (128 bytes each; a kernel stages those of its reaction range: at most what the
@@ -292,9 +300,12 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
         list(defines) + os.environ.get('PJ_RBLK_RATE_DEFINES', '').split() + [src]
     # w = J v (k_jvd: every reaction once, pj_rblk.hip): D_k in registers; concentrations and vector in registers too, or in
     # LDS columns (jvd_geometry)
-    jvd_geo = jvd_geometry(nsp, nkc, r_block if r_clds else 0)
+    # (K_c rows from the mechanism table in global memory instead of LDS copies: no limit on a kernel's reaction range)
+    jvd_kcg = int(os.environ.get('PJ_RBLK_JVD_KC_GLOBAL', JVD_KC_GLOBAL_DEFAULT(nsp)))
+    jvd_geo = jvd_geometry(nsp, 1 if jvd_kcg else nkc, r_block if r_clds else 0)
     jvd = None if jvd_geo is None else common + flags + \
         ['-DPJQ_BLOCK=%d' % jvd_geo[0], '-DPJQ_HALVES=%d' % jvd_geo[1], '-DPJQ_C_LDS=%d' % jvd_geo[2], '-DPJQ_V_LDS=%d' % jvd_geo[3]] + \
+        (['-DPJQ_JVD_KC_GLOBAL=1', '-DPJQ_JVD_SB=4', '-DPJQ_R0=0', '-DPJQ_R1=pjs::NRXN', '-DPJQ_FIRST=1', '-DPJQ_LAST=1'] if jvd_kcg else []) + \
         list(defines) + os.environ.get('PJ_RBLK_JVD_DEFINES', '').split() + [src]
     jobs = [(rblk + ['-DPJQ_PART=0'], 'qhost.o')]
     if npre or ecl:
@@ -316,7 +327,7 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
         if row_jv:
             jobs.append((rblk + ['-DPJQ_PART=4', '-DPJQ_JV=1'], 'fin_jv.o'))
     if jvd is not None and not no_jv:
-        for i in range(nrate):
+        for i in range(1 if jvd_kcg else nrate):
             jobs.append((jvd + ['-DPJQ_PART=5', '-DPJQ_ID=%d' % i], 'jvd%d.o' % i))
     for i in range(nrate):
         for full in (0, 1):

@@ -21,7 +21,7 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     must carry the rows: pj_mech_set_kc_factors before it was emitted); single: one row kernel for every block;
     ecl: the energy-row terms a row block cannot see summed by the pre-pass (PJQ_ECL; default as specbuild: with several
     lane groups and polynomial K_c); pre_halves: lane groups of the pre-pass (2 needs c_lds); jvd: (lane groups,
-    concentrations in LDS, vector in LDS) of k_jvd (w = J v, every reaction once); only_jvd: no other kernels."""
+    concentrations in LDS, vector in LDS[, K_c rows from global memory[, look-ahead depth]]) of k_jvd (w = J v, every reaction once); only_jvd: no other kernels."""
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
     t = open(hdr).read()
@@ -65,9 +65,11 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
 
     if only_jvd:
         jobs = jobs[:1]
-    jg, jc, jvl = jvd
+    jg, jc, jvl = jvd[:3]
+    jkg = int(len(jvd) > 3 and jvd[3])
+    jah = ['-DPJQ_JVD_AHEAD=%d' % jvd[4]] if len(jvd) > 4 else []
     jc = int(jg > 1 or jvl) if jc is None else jc
-    jflags = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % jc, '-DPJQ_HALVES=%d' % jg, '-DPJQ_V_LDS=%d' % jvl] + [os.path.join(CSRC, 'pj_rblk.hip')]
+    jflags = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % jc, '-DPJQ_HALVES=%d' % jg, '-DPJQ_V_LDS=%d' % jvl, '-DPJQ_JVD_KC_GLOBAL=%d' % jkg] + jah + [os.path.join(CSRC, 'pj_rblk.hip')]
     for n, r0 in enumerate(rstarts):
         jobs.append((jflags + ['-DPJQ_PART=5', '-DPJQ_ID=%d' % n, '-DPJQ_R0=%d' % r0, '-DPJQ_R1=%d' % min(nrxn, r0 + rates_per_part),
                                '-DPJQ_FIRST=%d' % (n == 0), '-DPJQ_LAST=%d' % (n == len(rstarts) - 1)], 'jvd%d.o' % n))

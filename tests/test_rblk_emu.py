@@ -229,6 +229,10 @@ def test_rblk_fused_jacobian_vector_product(name, budget, kw, tmp_path, tables):
     # the large-mechanism geometry: four lane groups, concentrations and vector in LDS columns
     ('synth_alltypes', 16, dict(rates_per_part=7, jvd=(4, 1, 1))),
     ('synth_mid24', 40, dict(rates_per_part=1000, jvd=(4, 1, 1))),
+    # ... with the K_c rows read from the mechanism table instead of LDS copies
+    ('synth_srichb', 16, dict(rates_per_part=1000, jvd=(4, 1, 1, 1))),
+    ('synth_alltypes', 16, dict(rates_per_part=1000, jvd=(4, 1, 1, 1, 2))),
+    ('synth_alltypes', 16, dict(rates_per_part=7, jvd=(1, 0, 0, 0, 2))),
 ])
 @pytest.mark.parametrize('sum_last', [0, 1])
 def test_jvd_directional_derivative_vs_oracle(name, budget, kw, sum_last, tmp_path, tables):
