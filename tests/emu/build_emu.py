@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
 
 def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int = 128, c_lds: int = 0,
                opt: str = '-O1', defines=(), halves: int = 1, kcf: int = 0, single: int = 0, ecl: int = None,
-               pre_halves: int = 1, fin: int = None, jvd=(1, None, 0), only_jvd: bool = False) -> str:
+               pre_halves: int = 1, fin: int = None, jvd=(1, None, 0), only_jvd: bool = False, only_rows: bool = False) -> str:
     """csrc/pj_rblk.hip for the host: row blocks that rebuild their rates + falloff / PLOG pre-pass (k_pre,
     k_rblk, also as w = J v) and the rate-output kernels (k_rate, one per `rates_per_part` reactions, with and
     without the per-reaction outputs), the way specbuild.build_rblk links them.  halves: lane groups of the row kernels
@@ -21,7 +21,8 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     must carry the rows: pj_mech_set_kc_factors before it was emitted); single: one row kernel for every block;
     ecl: the energy-row terms a row block cannot see summed by the pre-pass (PJQ_ECL; default as specbuild: with several
     lane groups and polynomial K_c); pre_halves: lane groups of the pre-pass (2 needs c_lds); jvd: (lane groups,
-    concentrations in LDS, vector in LDS[, K_c rows from global memory[, look-ahead depth]]) of k_jvd (w = J v, every reaction once); only_jvd: no other kernels."""
+    concentrations in LDS, vector in LDS[, K_c rows from global memory[, look-ahead depth]]) of k_jvd (w = J v, every reaction once); only_jvd: no other kernels; only_rows: the Jacobian path
+    alone (pre-pass + row kernels: no w = J v, no rate kernels)."""
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
     t = open(hdr).read()
@@ -73,6 +74,9 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     for n, r0 in enumerate(rstarts):
         jobs.append((jflags + ['-DPJQ_PART=5', '-DPJQ_ID=%d' % n, '-DPJQ_R0=%d' % r0, '-DPJQ_R1=%d' % min(nrxn, r0 + rates_per_part),
                                '-DPJQ_FIRST=%d' % (n == 0), '-DPJQ_LAST=%d' % (n == len(rstarts) - 1)], 'jvd%d.o' % n))
+
+    if only_rows:
+        jobs = [j for j in jobs if j[1] in ('qhost.o', 'pre.o', 'fin.o') or (j[1].startswith('rblk') and not j[1].endswith('_jv.o'))]
 
     def run(j):
         subprocess.check_call(j[0] + ['-o', os.path.join(work, j[1])])

@@ -52,9 +52,9 @@ def test_factor_form_of_the_equilibrium_constants_against_the_truth(tables, gold
     name = 'gri30_shaped'
     tab = tables(name)
     nsp = tab.nsp
-    L = rblk_emu_lib(name, 48, tmp_path_factory, kcf=1, halves=4, single=1, c_lds=0)[1]
+    L = rblk_emu_lib(name, 48, tmp_path_factory, kcf=1, halves=4, single=1, c_lds=0, only_rows=True)[1]
     g = golden(name)
-    pres, y = synth.dist_b(200, nsp, seed=11, Tlo=300, Thi=3000)
+    pres, y = synth.dist_b(120, nsp, seed=11, Tlo=300, Thi=3000)
     pres = np.concatenate([g['pres'], pres])
     y = np.concatenate([g['y'].T, y], axis=1)
     y_aos = np.ascontiguousarray(y.T)
