@@ -461,6 +461,29 @@ def main():
                     del rhs, dx
                 except Exception as ex:
                     line['also']['newton_step'] = {'error': repr(ex)}
+                # the reference's own comparison arm (performance_tester/fd_jacob.c: NSP + 1 dydt evaluations per
+                # state) on a bounded sample of the same batch -- the "analytical vs finite difference" ratio of the pyJac
+                # paper, reported, never part of `value`
+                try:
+                    nf = min(n, 131072)
+                    fdj = jac[:, :nf] if L == pyjac_amd.LAYOUT_SOA else None
+                    fd_p, fd_y = d_p[:nf].contiguous(), d_y[:, :nf].contiguous()
+                    fd_out = torch.empty((ev.nsp * ev.nsp, nf), dtype=torch.float64, device=d_p.device)
+                    ev.fd_jacobian(fd_p, fd_y, out=fd_out)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        ev.fd_jacobian(fd_p, fd_y, out=fd_out)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms_fd = e0.elapsed_time(e1) / 3
+                    line['also']['finite_difference_arm'] = dict(
+                        states=nf, kernel_ms=ms_fd, jacobians_per_s=nf / ms_fd * 1e3,
+                        analytical_over_fd=(n / ms_kernel) / (nf / ms_fd),
+                        note='first-order differences of the GPU dydt with fd_jacob.c\'s increment: %d rate passes per state' % (ev.nsp + 1))
+                    del fd_out, fd_p, fd_y, fdj
+                except Exception as ex:
+                    line['also']['finite_difference_arm'] = {'error': repr(ex)}
                 # configs[1] "spec_rates + Jacobian": the rate pass (pyjacob.cu k_dydt) on the same batch,
                 # with every intermediate array written (conc, fwd, rev, pres_mod, spec_rates, dy) and
                 # with dy only
