@@ -485,6 +485,39 @@ def test_jacobian_vector_product(name, fused, layout, tables, torch_cuda):
     assert (np.abs(w - ref) / scale).max() < 1e-9, (name, fused, layout)
 
 
+@pytest.mark.parametrize('name', ['gri30_shaped', 'usc2_shaped', 'synth_irrev72'])
+def test_directional_derivative_product_without_the_quirk(name, tables, torch_cuda):
+    """k_jvd (w = J v, every reaction once; csrc/pj_rblk.hip PJQ_PART == 5) with the J_nplusone quirk switched off
+    (set_sum_last_species: the last species' d/dT terms summed like every other species') against the oracle in the same
+    mode, a batch that ends inside a workgroup, and against J v formed from the Jacobians of the row kernels."""
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev(name)
+    assert ev.spec_kernel == 'pj_rblk'
+    n = 777 if ev.nsp <= 64 else 333
+    pres, y = synth.dist_b(n, ev.nsp, seed=14, Tlo=600, Thi=2600)
+    v = np.random.default_rng(5).standard_normal((ev.nsp, n))
+    v[0] *= 100.0
+    d_p, d_y, d_v = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(v).cuda()
+    orc = Oracle(tables(name))
+    for on in (True, False):
+        ev.set_sum_last_species(on)
+        orc.lib.pjo_set_sum_last_species(int(on))
+        try:
+            J = orc.batch_jacob(pres, np.ascontiguousarray(y.T)).reshape(n, ev.nsp, ev.nsp)      # [s][col][row]
+        finally:
+            orc.lib.pjo_set_sum_last_species(0)
+        w = ev.jacobian_vec(d_p, d_y, d_v).cpu().numpy().T
+        ref = np.einsum('scr,cs->sr', J, v)
+        scale = np.einsum('scr,cs->sr', np.abs(J), np.abs(v)) + 1e-300
+        assert np.isfinite(w).all() and (np.abs(w - ref) / scale).max() < 1e-9, (name, on)
+        Jg = ev.jacobian(d_p, d_y).cpu().numpy().T.reshape(n, ev.nsp, ev.nsp)
+        assert (np.abs(w - np.einsum('scr,cs->sr', Jg, v)) / scale).max() < 1e-9, (name, on)
+    ev.set_sum_last_species(False)
+
+
 @pytest.mark.parametrize('name,n,tol', [('h2o2_n2', 300, 1e-5), ('gri30_shaped', 48, 1e-4), ('usc2_shaped', 16, 1e-4)])
 def test_finite_difference_arm(name, n, tol, tables, torch_cuda):
     """N3: the reference's FD Jacobian (fd_jacob.c / fd_jacob.cu:23-96) on the GPU dydt -- k_lane<2> for the H2
