@@ -168,3 +168,28 @@ def truth_report(test, ref, truth, nsp, label=''):
              'scale median %.3g max %.3g' % (rep['bad_test_vs_truth'], rep['bad_ref_vs_truth_median'],
                                               rep['bad_size_median'], rep['bad_size_max'])))
     return rep
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_collection_modifyitems(config, items):
+    """The two CPU emulation builds of the 53-species row kernels (single g++ translation units of 1 - 2 minutes) start as
+    soon as a test that needs them is known to run -- in the background, next to the tests in front of it."""
+    ids = [i.nodeid for i in items]
+    want_a = any('test_conditioning.py' in x or 'test_rblk_kernels_vs_reference_golden' in x for x in ids)
+    want_b = any('test_factor_form_of_the_equilibrium_constants' in x for x in ids)
+    if not (want_a or want_b) or config.option.collectonly:
+        return
+    import atexit
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    try:
+        import emu_libs
+        d = tempfile.mkdtemp(prefix='pj_emu_prefetch_')
+        atexit.register(shutil.rmtree, d, True)
+        if want_b:
+            emu_libs.prefetch('gri30_shaped', 48, d, kcf=1, halves=4, single=1, c_lds=0, only_rows=True)
+        if want_a:
+            emu_libs.prefetch('gri30_shaped', 56, d, blocks_per_part=13, c_lds=0)
+    except Exception as ex:         # (the tests build what they need themselves)
+        sys.stderr.write('emulation prefetch not started: %r\n' % (ex,))
