@@ -36,10 +36,8 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     starts = list(range(0, nblk, blocks_per_part))
     if ecl is None:
         ecl = 1 if (halves > 1 and not kcf) else 0
-    ecols = any('PJQ_ECOLS=1' in d for d in defines)
     if fin is None:         # (as specbuild: off unless asked for)
         fin = 0
-    (void_ := ecols)
     common += ['-DPJQ_SUMSETS=%d' % (0 if (len(starts) == 1 and not fin) else 2 * halves), '-DPJQ_SINGLE=%d' % int(len(starts) == 1),
                '-DPJQ_ECL=%d' % ecl, '-DPJQ_FIN=%d' % fin]
     base = common + ['-DPJQ_BLOCK=1', '-DPJQ_C_LDS=%d' % c_lds, os.path.join(CSRC, 'pj_rblk.hip')]
