@@ -446,6 +446,18 @@ def test_row_block_kernels_chunked_launch(torch_cuda, monkeypatch):
     parts = ev.jacobian(d_p[:n2].contiguous(), d_y[:, :n2].contiguous())
     torch.cuda.synchronize()
     assert torch.equal(whole, other) and torch.equal(whole[:, :n2], parts)
+    # ... and so does w = J v (k_jvd): chunked over internal streams / interleaved with the other handle's Jacobians,
+    # bit-identical to the product of one launch
+    d_v = torch.randn_like(d_y)
+    ev.set_spec_launch(streams=1, chunk_states=1 << 20)
+    w_whole = ev.jacobian_vec(d_p, d_y, d_v).clone()
+    ev.set_spec_launch(streams=3, chunk_states=512)
+    with torch.cuda.stream(s2):
+        other = ev2.jacobian(d_p, d_y)
+    w_parts = ev.jacobian_vec(d_p[:n2].contiguous(), d_y[:, :n2].contiguous(), d_v[:, :n2].contiguous())
+    w_other = ev2.jacobian_vec(d_p, d_y, d_v)
+    torch.cuda.synchronize()
+    assert torch.equal(w_whole[:, :n2], w_parts) and torch.equal(w_whole, w_other) and torch.equal(whole, other)
     ev2.close()
 
 
