@@ -1,14 +1,43 @@
 """Compile csrc/pj_rblk.hip with g++ through tests/emu/hip_shim.h (one "thread" per workgroup)
 so the CPU suite can run the state-per-lane row-block kernels against the oracle.
 Test infrastructure only."""
+import hashlib
 import os
 import re
+import shutil
 import subprocess
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
+
+
+def cache_path(files, extra: bytes):
+    """Path of a library in the build cache (test infrastructure, like ccache), keyed by the CONTENT of `files` and of
+    `extra` (options, generated header text) and the compiler version; None if the cache is off (PJ_EMU_CACHE=off)."""
+    cache_dir = os.environ.get('PJ_EMU_CACHE', os.path.join(tempfile.gettempdir(), 'pj_emu_cache'))
+    if cache_dir == 'off':
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(f, 'rb').read())
+    h.update(extra)
+    h.update(subprocess.run(['g++', '--version'], capture_output=True).stdout)
+    return os.path.join(cache_dir, h.hexdigest()[:32] + '.so')
+
+
+def cache_store(cached, out):
+    if not cached:
+        return
+    try:
+        os.makedirs(os.path.dirname(cached), exist_ok=True)
+        tmp = cached + '.%d.tmp' % os.getpid()
+        shutil.copyfile(out, tmp)
+        os.replace(tmp, cached)
+    except OSError:
+        pass
 
 
 def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int = 128, c_lds: int = 0,
@@ -23,9 +52,18 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     lane groups and polynomial K_c); pre_halves: lane groups of the pre-pass (2 needs c_lds); jvd: (lane groups,
     concentrations in LDS, vector in LDS[, K_c rows from global memory[, look-ahead depth]]) of k_jvd (w = J v, every reaction once); only_jvd: no other kernels; only_rows: the Jacobian path
     alone (pre-pass + row kernels: no w = J v, no rate kernels)."""
+    t = open(hdr).read()
+    # build cache: kernel sources, shim, this recipe, the mechanism header, every option -- a warm container re-runs the suite
+    # without g++
+    cached = cache_path([os.path.join(CSRC, f) for f in ('pj_rblk.hip', 'pj_math.h', 'pj_rate_pre.inc', 'pj_tables.h')] +
+                        [os.path.join(HERE, 'hip_shim.h'), os.path.abspath(__file__)],
+                        t.encode() + repr((blocks_per_part, rates_per_part, c_lds, opt, tuple(defines), halves, kcf, single, ecl,
+                                           pre_halves, fin, tuple(jvd), only_jvd, only_rows)).encode())
+    if cached and os.path.exists(cached):
+        shutil.copyfile(cached, out)
+        return out
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
-    t = open(hdr).read()
     nblk = int(re.search(r'NBLK = (\d+)', t).group(1))
     nrxn = int(re.search(r'NRXN = (\d+)', t).group(1))
     npre = int(re.search(r'NPRE = (\d+)', t).group(1))
@@ -81,4 +119,5 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(run, jobs))
     subprocess.check_call(['g++', '-shared', '-pthread', '-o', out] + [os.path.join(work, j[1]) for j in jobs])
+    cache_store(cached, out)
     return out

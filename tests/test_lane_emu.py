@@ -27,9 +27,18 @@ def _lane_emu(mech, tmp, tag, therm=None):
     hdr = os.path.join(tmp, tag + '.h')
     _lib.check(_lib.lib().pj_mech_emit_spec(ev._h, hdr.encode()))
     so = os.path.join(tmp, 'liblane_%s.so' % tag)
-    subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-x', 'c++', '-DPJL_HOST_EMU',
-                           '-DPJL_BLOCK=1', '-DPJS_HEADER="%s"' % hdr, '-I', build_emu.HERE,
-                           '-I', build_emu.CSRC, os.path.join(build_emu.CSRC, 'pj_lane.hip'), '-o', so])
+    import glob
+    import shutil
+    cached = build_emu.cache_path(sorted(glob.glob(os.path.join(build_emu.CSRC, '*.h'))) +
+                                  [os.path.join(build_emu.CSRC, 'pj_lane.hip'), os.path.join(build_emu.HERE, 'hip_shim.h'),
+                                   os.path.abspath(__file__)], open(hdr, 'rb').read())
+    if cached and os.path.exists(cached):
+        shutil.copyfile(cached, so)
+    else:
+        subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-x', 'c++', '-DPJL_HOST_EMU',
+                               '-DPJL_BLOCK=1', '-DPJS_HEADER="%s"' % hdr, '-I', build_emu.HERE,
+                               '-I', build_emu.CSRC, os.path.join(build_emu.CSRC, 'pj_lane.hip'), '-o', so])
+        build_emu.cache_store(cached, so)
     L = ctypes.CDLL(so)
     cl, ci, vp = ctypes.c_long, ctypes.c_int, ctypes.c_void_p
     L.pj_spec_jacobian.argtypes = [cl, _dp, _dp, cl, cl, _dp, cl, cl, ci, vp]
