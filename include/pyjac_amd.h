@@ -142,8 +142,10 @@ int pj_eval_jacobian_dev(pj_mech* m, long n, const double* d_pres, const double*
 /* Fused consumer: w_s = J(Phi_s) v_s for every state, v and w shaped like y (NSP rows, layout
  * vw_layout).  What an implicit / exponential integrator does with pyJac's output through
  * sparse_multiplier(A, Vm, w) (create_jacobian.py:3301-3404), without the NSP^2 doubles per state ever
- * reaching memory when a pj_lane.hip library is attached (reads 8(2 NSP + 1), writes 8 NSP bytes per
- * state); otherwise Jacobians are evaluated chunk-wise into a temporary block and multiplied there. */
+ * reaching memory when a mechanism-specific library is attached (reads 8(2 NSP + 1), writes 8 NSP bytes per
+ * state: pj_lane.hip consumes the Jacobian in registers, pj_rblk.hip evaluates the product as a directional
+ * derivative with every reaction visited once -- k_jvd); otherwise Jacobians are evaluated chunk-wise into a
+ * temporary block and multiplied there. */
 int pj_eval_jacobian_vec_dev(pj_mech* m, long n, const double* d_pres, const double* d_y, int y_layout,
                              const double* d_v, double* d_w, int vw_layout, void* stream);
 /* any output pointer may be NULL; outputs are SoA with leading dimension n:

@@ -28,9 +28,11 @@
 //   PJQ_KCF        up to 53 species: equilibrium constants as products of per-species factors kept in LDS columns,
 //                  64 states per workgroup, four lane groups, ONE row kernel (see k_rblk).
 //
-//   PJQ_JV         the same row kernels with the Jacobian stores replaced by w_k += J(k, c) v_c: the
-//                  consumer of pyJac's sparse_multiplier (create_jacobian.py:3301-3404) fused in, NSP
-//                  instead of NSP^2 doubles written per state; v sits in AGPRs next to the energy row.
+//   k_jvd          w = J v per state -- the consumer of pyJac's sparse_multiplier (create_jacobian.py:3301-3404) -- as a
+//                  directional derivative: every reaction visited ONCE, its derivative row times the vector scattered to
+//                  its net species like its rate (PJQ_PART == 5 below); NSP instead of NSP^2 doubles written per state.
+//   PJQ_JV         (rounds 2 - 4; built on request, PJ_RBLK_ROW_JV) the same product from the row kernels with their
+//                  Jacobian stores replaced by w_k += J(k, c) v_c: 3.6 visits per reaction, 3x the time of k_jvd.
 //
 // The mechanism is injected as constexpr tables (pj::emit_spec_header + pj::emit_rows_tables ->
 // PJS_HEADER); every loop is a compile-time loop.  One translation unit per kernel (PJQ_PART).
@@ -39,9 +41,10 @@
 // pyjac/core/rate_subs.py:254-2335, pyjac/core/create_jacobian.py:2189-3298.
 //
 // PJQ_PART = 0: host entry points;  1: k_pre;  2: k_rblk, row blocks [PJQ_B0, PJQ_B1) (PJQ_FIRST / PJQ_LAST: first /
-// last row kernel of the library);  3: k_rate, reactions [PJQ_R0, PJQ_R1).  PJQ_ID is the launch-order index of
-// a kernel; the ranges come from the kernel plan in the header (pj::emit_rows_tables: KER_B, KER_BM, RATE_R)
-// unless given explicitly (tests).
+// last row kernel of the library);  3: k_rate, reactions [PJQ_R0, PJQ_R1);  4: k_fin (option PJQ_FIN, off);  5: k_jvd,
+// reactions [PJQ_R0, PJQ_R1).  PJQ_ID is the launch-order index of a kernel; the ranges come from the kernel plan in the
+// header (pj::emit_rows_tables: KER_B, KER_BM, RATE_R) unless given explicitly (tests; k_jvd without LDS copies of the K_c
+// rows: the whole mechanism).
 #ifdef PJR_HOST_EMU
 #include "hip_shim.h"
 #else
@@ -2564,9 +2567,11 @@ struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_FULL ? 8 : 7, launch_rate); } } re
 // reaction enthalpy Hr_i = sum_k nu_ki h_kW_k = R T (T dlnK_c/dT + sum nu) -- the visit has it -- and its temperature
 // derivative dCp_i = sum_k nu_ki W_k c_p,k, four more multiply-adds on the K_c row the visit has read anyway (an irreversible
 // reaction has no row: its net species' NASA polynomials).  So a lane carries ONE array, D_k, and four scalars.
-// Geometry (pyjac_amd/specbuild.py): D_k in registers; concentrations and the scaled vector in registers too (256 states
-// per workgroup) or -- large mechanisms -- in LDS columns, 64 states and four lane groups that take every fourth reaction.
-// Reaction ranges as k_rate (RATE_R); between the kernels of a library D_k and the scalars travel through `sr`.
+// Geometry (pyjac_amd/specbuild.py: jvd_geometry): D_k in registers; concentrations and the scaled vector in LDS columns
+// shared by four lane groups that take every fourth reaction -- 128 states per workgroup up to 64 species (512 threads, two
+// wavefronts per SIMD), 64 states beyond (there with the K_c rows read from the mechanism table in global memory:
+// PJQ_JVD_KC_GLOBAL) -- or, small mechanisms / tests, everything in registers and one group.  Reaction ranges as k_rate
+// (RATE_R) where the K_c rows are staged in LDS; between the kernels of a library D_k and the scalars travel through `sr`.
 #ifndef PJQ_V_LDS
 #define PJQ_V_LDS 0         // the scaled vector in LDS columns (large mechanisms) instead of registers
 #endif

@@ -199,7 +199,7 @@ def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0):
     return block, halves, kcf, single, ecols, coop
 
 
-def JVD_KC_GLOBAL_DEFAULT(nsp: int) -> int:
+def jvd_kc_global_default(nsp: int) -> int:
     """k_jvd's K_c rows from the mechanism table in global memory instead of LDS copies: the 64-state / four-group geometry of
     the large mechanisms is bound by its LDS traffic (a third of it those rows) while its vector memory path idles, and
     without the copies one kernel covers the mechanism: 2e5 USC-shaped products 2.34 -> 1.72 ms; the 128-state geometry
@@ -301,7 +301,7 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     # w = J v (k_jvd: every reaction once, pj_rblk.hip): D_k in registers; concentrations and vector in registers too, or in
     # LDS columns (jvd_geometry)
     # (K_c rows from the mechanism table in global memory instead of LDS copies: no limit on a kernel's reaction range)
-    jvd_kcg = int(os.environ.get('PJ_RBLK_JVD_KC_GLOBAL', JVD_KC_GLOBAL_DEFAULT(nsp)))
+    jvd_kcg = int(os.environ.get('PJ_RBLK_JVD_KC_GLOBAL', jvd_kc_global_default(nsp)))
     jvd_geo = jvd_geometry(nsp, 1 if jvd_kcg else nkc, r_block if r_clds else 0)
     jvd = None if jvd_geo is None else common + flags + \
         ['-DPJQ_BLOCK=%d' % jvd_geo[0], '-DPJQ_HALVES=%d' % jvd_geo[1], '-DPJQ_C_LDS=%d' % jvd_geo[2], '-DPJQ_V_LDS=%d' % jvd_geo[3]] + \
