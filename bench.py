@@ -131,28 +131,59 @@ def end_to_end(ev, w, n_sample, np):
                      'reference harness copied back; caller buffers are pageable numpy arrays')
 
 
-def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0, build_rblk=False):
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def open_mechanism(pyjac_amd, mech, dist=None, local_rank=0, build_rblk=False, world=1, dev='cuda'):
     """Evaluator with its mechanism-specific kernels attached.  Prebuilt libraries
     (__graft_entry__.build()) are used as they are; a missing register-resident (pj_lane)
-    library is compiled here (seconds), by local rank 0 only.  The row-block (pj_rblk) library of a larger
-    mechanism takes minutes to build: only the HEADLINE workload compiles a missing one (build_rblk; said on
-    stderr), so that the metric is never quoted on the no-compile path by accident -- a library whose sources
-    changed since it was built is "missing".  Without a compiler the table-driven kernels run and the line's
-    `config.kernel` says so."""
+    library is compiled here (seconds).  The row-block (pj_rblk) library of a larger
+    mechanism takes minutes to build: only the HEADLINE workload of a ONE-process run compiles a missing one
+    (build_rblk; said on stderr), so that the metric is never quoted on the no-compile path by accident -- a
+    library whose sources changed since it was built is "missing".  Without a compiler the table-driven kernels
+    run and the line's `config.kernel` says so.
+
+    Several ranks (a scaling run): nothing is compiled.  Every rank looks for the library FIRST, before any
+    barrier, the ranks agree on the outcome (one MIN all-reduce of a flag), and if any of them has no up-to-date
+    library ALL of them stop with one message -- no rank sits in a barrier for the ten minutes another one
+    compiles (the collective watchdog's default time-out)."""
     ev = pyjac_amd.Evaluator(mech, specialize='auto')
+    if dist is not None and dist.is_initialized() and world > 1:
+        want = ev.spec_kind() == 'lane' or build_rblk
+        agree_on_library(dist, ev.has_spec or not want, dev, '%s (expected %s)' % (os.path.basename(mech), ev.spec_path()))
+        return ev
     if not ev.has_spec and (ev.spec_kind() == 'lane' or build_rblk):
-        if local_rank == 0:
-            try:
-                if ev.spec_kind() != 'lane':
-                    sys.stderr.write('bench: no up-to-date pj_rblk library for %s: compiling it (minutes)\n' % os.path.basename(mech))
-                ev.specialize(build=True)
-            except Exception as e:      # no compiler on this box: the table-driven kernels serve the mechanism
-                sys.stderr.write('bench: cannot build the mechanism-specific kernels (%s): table-driven path\n' % e)
-        if dist is not None and dist.is_initialized():
-            dist.barrier()
-        if not ev.has_spec:
-            ev.specialize(build=False)
+        try:
+            if ev.spec_kind() != 'lane':
+                sys.stderr.write('bench: no up-to-date pj_rblk library for %s: compiling it (minutes)\n' % os.path.basename(mech))
+            ev.specialize(build=True)
+        except Exception as e:      # no compiler on this box: the table-driven kernels serve the mechanism
+            sys.stderr.write('bench: cannot build the mechanism-specific kernels (%s): table-driven path\n' % e)
     return ev
+
+
+def agree_on_library(dist, have: bool, dev, what: str):
+    """One MIN all-reduce of "this rank has its library": raises LibraryMissing on EVERY rank if any rank has none."""
+    import torch
+    flag = torch.tensor([1 if have else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        raise LibraryMissing('no up-to-date mechanism-specific library for %s on at least one rank (this rank: %s): run '
+                             '`python -c "import __graft_entry__ as g; g.build()"` once before a multi-GPU run -- nothing is '
+                             'compiled inside one' % (what, 'present' if have else 'MISSING'))
+
+
+def profile_of(kind, wl, library):
+    """(json, matches) of a committed counter profile (profiles/traffic_<wl>.json, profiles/valu_<wl>.json): `matches` says
+    whether it was collected on the library that is attached NOW (tools/r06_prof.sh stores the library's file name, which
+    carries the digest of the kernel sources and build options, next to the counters) -- None if the profile does not say."""
+    path = os.path.join(ROOT, 'profiles', '%s_%s.json' % (kind, wl))
+    if not os.path.exists(path):
+        return None, None
+    j = json.load(open(path))
+    lib = j.get('library')
+    return j, (None if lib is None else bool(library) and lib == library)
 
 
 def kernel_label(ev, inject=None):
@@ -209,8 +240,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true',
                     help='skip the short extra measurements of the other workloads (N=1 only)')
-    ap.add_argument('--validate-states', type=int, default=4096,
-                    help='states per rank in the multi-GPU validation all-gather (outside the timed region)')
+    ap.add_argument('--validate-states', default='4096',
+                    help='states per rank in the multi-GPU validation all-gather (outside the timed region): a number, or '
+                         '"all" for the whole batch (GRI-shaped, 1e6 states per rank: 22.5 GB per rank, gathered a chunk at a time)')
     a = ap.parse_args()
 
     import numpy as np
@@ -238,7 +270,11 @@ def main():
     grouped = world > 1 or ('WORLD_SIZE' in os.environ and 'MASTER_PORT' in os.environ)
     if grouped:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import datetime
         kw = {} if inject else {'device_id': torch.device('cuda', local_rank)}
+        # (an explicit time-out: the default of the collective watchdog is ten minutes, less than one validation pass over
+        # 8 x 22.5 GB of Jacobians may take on a loaded node; PJ_DIST_TIMEOUT_S overrides)
+        kw['timeout'] = datetime.timedelta(seconds=int(os.environ.get('PJ_DIST_TIMEOUT_S', 1800)))
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     assert world == a.gpus, 'launch with --nproc-per-node equal to --gpus'
 
@@ -248,12 +284,21 @@ def main():
         # Jacobian); GRI-Mech 3.0 itself is not available offline: same-shape synthetic mechanism
         wl = 'gri'
     w = WORKLOADS[wl]
-    if inject:
-        import importlib
-        mod, fn = inject.split(':')
-        ev = getattr(importlib.import_module(mod), fn)(w['mech'])
-    else:
-        ev = open_mechanism(pyjac_amd, w['mech'], dist if grouped else None, local_rank, build_rblk=True)
+    try:
+        if inject:
+            import importlib
+            mod, fn = inject.split(':')
+            ev = getattr(importlib.import_module(mod), fn)(w['mech'])
+            if grouped and world > 1:
+                agree_on_library(dist, bool(ev.has_spec), dev, os.path.basename(w['mech']))
+        else:
+            ev = open_mechanism(pyjac_amd, w['mech'], dist if grouped else None, local_rank, build_rblk=True, world=world, dev=dev)
+    except LibraryMissing as ex:
+        # every rank is here (the ranks agreed): one message, one exit code, no rank left in a collective
+        if rank == 0:
+            sys.stderr.write('bench: %s\n' % ex)
+        dist.destroy_process_group()
+        sys.exit(3)
     n = a.states or w['n']
     # every rank owns n states (weak scaling); global batch = world * n
     pres, y = make_states(w, ev.nsp, n, seed=20240901 + rank)
@@ -307,7 +352,7 @@ def main():
         #  * a strided sample of the states of the NEXT rank (a remote one) is evaluated again HERE, from that
         #    rank's seeded inputs, and compared with the gathered columns: the bytes that crossed
         #    xGMI are the Jacobians of those states, not merely self-consistent.
-        nv = min(a.validate_states, n)
+        nv = n if str(a.validate_states).lower() == 'all' else min(int(a.validate_states), n)
         soa = L == pyjac_amd.LAYOUT_SOA
         shard = (jac[:, :nv] if soa else jac[:nv].T).contiguous()
         t0 = time.perf_counter()
@@ -355,27 +400,27 @@ def main():
         value = total / elapsed
         bj = ev.jacobian_bytes_per_state
         achieved = n * bj / (ms_kernel * 1e-3) / 1e9
+        library = os.path.basename(getattr(ev, 'attached_spec', None) or '') or None
         traffic = traffic_source = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % wl)   # rocprofv3 PMC passes of this round
-        if os.path.exists(tpath):
+        tj, traffic_matches = profile_of('traffic', wl, library)   # rocprofv3 PMC passes of this round
+        if tj:
             # PMC-measured HBM bytes of this kernel (profiles/README.md); a streaming map, so
             # a launch over n states moves n / states_per_launch times the profiled bytes
-            tj = json.load(open(tpath))
             traffic = tj['hbm_bytes_per_launch'] * n / tj.get('states_per_launch', n)
             # NOT measured in this run (PMC counters need rocprofv3 around the process): say where it comes from
-            traffic_source = ('committed profile profiles/traffic_%s.json (rocprofv3 --pmc passes of this command, %s), '
-                              'not measured in this run' % (wl, tj.get('collected', 'see profiles/README.md')))
+            traffic_source = ('committed profile profiles/traffic_%s.json (rocprofv3 --pmc passes over tools/one_step.py, %d states '
+                              'per launch, library %s), not measured in this run' % (wl, tj.get('states_per_launch', 0), tj.get('library')))
         # the instruction roof of the same step: VALU instructions per state and the share of wave-cycles that
         # issue, from the committed SQ-counter summary of this workload (profiles/valu_<wl>.json, tools/valu_roof.py)
         valu = None
-        vpath = os.path.join(ROOT, 'profiles', 'valu_%s.json' % wl)
-        if os.path.exists(vpath):
-            vj = json.load(open(vpath))
+        vj, valu_matches = profile_of('valu', wl, library)
+        if vj:
             wave_instr_per_s = vj['valu_instr_per_state'] * n / 64.0 / (ms_kernel * 1e-3)
             valu = {'instr_per_state': vj['valu_instr_per_state'], 'issue_frac': vj['issue_frac'],
                     'wait_frac': vj.get('wait_frac'), 'achieved_wave_instr_per_s': wave_instr_per_s,
                     'fp64_peak_wave_instr_per_s': VALU_PEAK_WAVE_INSTR_PER_S,
                     'frac': wave_instr_per_s / VALU_PEAK_WAVE_INSTR_PER_S, 'source': vj.get('source'),
+                    'profile_matches_library': valu_matches,
                     'source_kind': 'committed profile profiles/valu_%s.json (SQ counters of an earlier rocprofv3 run), '
                                    'not measured in this run; only achieved_wave_instr_per_s uses this run\'s kernel_ms' % wl}
         hbm_frac = achieved / HBM_PEAK_GBPS
@@ -392,6 +437,9 @@ def main():
             'roofline': {'bound': 'valu' if (valu and valu['frac'] > hbm_frac) else 'hbm', 'achieved': achieved,
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': hbm_frac, 'traffic': traffic,
                          'traffic_source': traffic_source,
+                         # do the committed counter profiles belong to the library that ran?  (its file name carries the digest
+                         # of kernel sources + build options; None: a profile that does not name its library)
+                         'library': library, 'profile_matches_library': traffic_matches,
                          'bytes_per_state': bj, 'kernel_ms': ms_kernel, 'valu': valu},
         }
         if validation:
@@ -465,9 +513,10 @@ def main():
                 # state) on a bounded sample of the same batch -- the "analytical vs finite difference" ratio of the pyJac
                 # paper, reported, never part of `value`
                 try:
-                    nf = min(n, 131072)
-                    fdj = jac[:, :nf] if L == pyjac_amd.LAYOUT_SOA else None
-                    fd_p, fd_y = d_p[:nf].contiguous(), d_y[:, :nf].contiguous()
+                    # (bounded by bytes: NSP^2 doubles per state next to the live Jacobian -- at most 2 GB; SoA inputs)
+                    nf = max(64, min(n, 131072, (2 << 30) // (8 * ev.nsp * ev.nsp)) // 64 * 64)
+                    fd_p = d_p[:nf].contiguous()
+                    fd_y = (d_y[:, :nf] if L == pyjac_amd.LAYOUT_SOA else d_y[:nf].T).contiguous()
                     fd_out = torch.empty((ev.nsp * ev.nsp, nf), dtype=torch.float64, device=d_p.device)
                     ev.fd_jacobian(fd_p, fd_y, out=fd_out)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -481,7 +530,7 @@ def main():
                         states=nf, kernel_ms=ms_fd, jacobians_per_s=nf / ms_fd * 1e3,
                         analytical_over_fd=(n / ms_kernel) / (nf / ms_fd),
                         note='first-order differences of the GPU dydt with fd_jacob.c\'s increment: %d rate passes per state' % (ev.nsp + 1))
-                    del fd_out, fd_p, fd_y, fdj
+                    del fd_out, fd_p, fd_y
                 except Exception as ex:
                     line['also']['finite_difference_arm'] = {'error': repr(ex)}
                 # configs[1] "spec_rates + Jacobian": the rate pass (pyjacob.cu k_dydt) on the same batch,

@@ -13,6 +13,7 @@
 #define PJ_DEV __device__ __forceinline__
 #include "pj_kernel.h"
 #include "pj_tab.h"
+#define PJ_LU_DECL_ONLY 1       // (the kernels: csrc/pj_lu.hip, translation units of their own)
 #include "pj_lu.h"
 #include "../../include/pyjac_amd.h"
 
@@ -1003,7 +1004,7 @@ static int lu_call(int nsp, long n, const double* a, int a_layout, double gamma,
     pj::LuLay Y;
     set_layout(n, nsp * nsp, a_layout, &Y.a_si, &Y.a_ss);
     set_layout(n, nsp, vec_layout, &Y.v_si, &Y.v_ss);
-    if (pj::lu_launch(nsp, n, a, Y, gamma, lu, perm, b, x, mode, lu_cus(), (hipStream_t)stream)) return fail(PJ_EHIP, "batched LU launch failed");
+    if (pj::lu_launch_x(nsp, n, a, Y, gamma, lu, perm, b, x, mode, lu_cus(), (hipStream_t)stream)) return fail(PJ_EHIP, "batched LU launch failed");
     return hipGetLastError() == hipSuccess ? PJ_OK : fail(PJ_EHIP, "batched LU launch failed");
 }
 int pj_lu_factor_dev(int nsp, long n, const double* d_a, int a_layout, double gamma, double* d_lu, int* d_perm, void* stream)

@@ -18,6 +18,28 @@
 
 #include <type_traits>
 
+// Translation units (csrc/pj_lu.hip; __graft_entry__.build compiles them in parallel -- k_lu4 alone is four instantiations of
+// two minutes each):
+//   PJ_LU_DECL_ONLY   declarations for callers (pj_api.hip): enum, LuLay, LU_MAX_LDS, lu_launch_x()
+//   PJ_LU4_SPLIT      lu_launch() reaches the k_lu4 instantiations through lu4_go_<NP>() defined elsewhere
+//   PJ_LU4_ONLY=NP    only the helpers, k_lu4 and lu4_go_<NP>()
+// None of them defined: everything inline in the including file (tools/micro/lu_bw.hip).
+namespace pj {
+enum { LU_FACTOR = 1, LU_SOLVE = 2, LU_PREFACTORED = 4 };
+// where the input blocks and the vectors live: entry (r, c) of block s at a[(r + NSP c) * a_si + s * a_ss], entry i of
+// vector s at v[i * v_si + s * v_ss] -- pyJac's per-state layout (a_si = 1, a_ss = NSP^2; v_si = 1, v_ss = NSP) or the
+// state-fastest batch layout the row kernels write (a_si = n, a_ss = 1; v_si = n, v_ss = 1).  Factors are always
+// written / read per state (P A = L U blocks are consumed by these kernels only).
+struct LuLay { long a_si, a_ss, v_si, v_ss; };
+constexpr int LU_MAX_LDS = 140;        // (140 | 1) * 140 + 3 * 140 doubles = 159 KB of the 160 KB
+int lu_launch_x(int nsp, long n, const double* A, LuLay Y, double gamma, double* lu, int* perm, const double* b, double* x,
+                int mode, int cus, hipStream_t st);
+#define PJ_LU4_GO_DECL(NP_) void lu4_go_##NP_(unsigned blocks, hipStream_t st, int nsp, long n, const double* A, LuLay Y, double gamma, \
+                                              double* lu, int* perm, const double* b, double* x, int mode);
+PJ_LU4_GO_DECL(80) PJ_LU4_GO_DECL(96) PJ_LU4_GO_DECL(112) PJ_LU4_GO_DECL(128)
+}
+#ifndef PJ_LU_DECL_ONLY
+
 namespace pj {
 
 template <int I, int N, class F>
@@ -127,13 +149,7 @@ __device__ __forceinline__ double lu_wave_max(double v)
     return lu_readlane(v, 63);
 }
 
-enum { LU_FACTOR = 1, LU_SOLVE = 2, LU_PREFACTORED = 4 };
-// where the input blocks and the vectors live: entry (r, c) of block s at a[(r + NSP c) * a_si + s * a_ss], entry i of
-// vector s at v[i * v_si + s * v_ss] -- pyJac's per-state layout (a_si = 1, a_ss = NSP^2; v_si = 1, v_ss = NSP) or the
-// state-fastest batch layout the row kernels write (a_si = n, a_ss = 1; v_si = n, v_ss = 1).  Factors are always
-// written / read per state (P A = L U blocks are consumed by these kernels only).
-struct LuLay { long a_si, a_ss, v_si, v_ss; };
-
+#ifndef PJ_LU4_ONLY
 // NP: NSP rounded up to a multiple of 8, or 54 for 53 / 54 rows (rows / columns beyond NSP are the identity's: they are never pivots of a
 // real column and contribute zeros -- for FINITE input: the padding is formed as 0 * (a clamped copy of the last row /
 // column) + delta_ij, so an Inf / NaN there puts NaN into the padding as well; a block with non-finite entries gives
@@ -426,7 +442,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PJ_LU_
 // column), pivot search by a wavefront argmax per 64 rows + a four-entry exchange, physical row exchange, 32 x 8
 // thread tiles over the trailing block with the multipliers of the thread's rows in registers.  Same results and
 // same (lu, perm) convention as k_lu; latency-bound by its ~4 barriers per column.
-constexpr int LU_MAX_LDS = 140;        // (140 | 1) * 140 + 3 * 140 doubles = 159 KB of the 160 KB
 
 __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, const double* A, const LuLay Y, const double gamma,
                                                 double* lu, int* __restrict__ perm, const double* __restrict__ b,
@@ -612,6 +627,8 @@ __global__ void __launch_bounds__(256) k_lu_lds(const int nsp, const long n, con
     }
 }
 
+#endif  // !PJ_LU4_ONLY
+
 // ---- blocks of 65 .. 128 rows: FOUR wavefronts per block, the matrix in registers ------------------------------------
 // k_lu_lds keeps the block in LDS and pays ~4 barriers and an LDS round trip per entry and column: 168 ms per 2e5
 // 111 x 111 blocks, 0.03 of the HBM roofline, 27x the time of the Jacobians it consumes.  Here the
@@ -771,6 +788,10 @@ k_lu4(const int nsp, const long n, const double* A, const LuLay Y, const double 
                         };
                         if (rs == 0) park(a0); else park(a1);
                     }
+                    // (the pivot lane's stores sit in a divergent region; every lane of the SAME wavefront reads the strip next:
+                    // a wavefront-scope release keeps the LDS accesses in program order whatever the compiler does with the branch)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                     if (solve) {                                 // forward substitution rides along (replicated)
                         const double yk = lu_readlane(rs ? bb1 : bb0, lp);
                         bb0 = __builtin_fma(-l0, yk, bb0);
@@ -874,6 +895,13 @@ k_lu4(const int nsp, const long n, const double* A, const LuLay Y, const double 
     }
 }
 
+#ifdef PJ_LU4_ONLY
+#define PJ_LU4_GO_DEF(NP_) void lu4_go_##NP_(unsigned blocks, hipStream_t st, int nsp, long n, const double* A, LuLay Y, double gamma, \
+                                             double* lu, int* perm, const double* b, double* x, int mode) \
+    { hipLaunchKernelGGL((k_lu4<NP_>), dim3(blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode); }
+#define PJ_LU4_GO_DEF_(NP_) PJ_LU4_GO_DEF(NP_)
+PJ_LU4_GO_DEF_(PJ_LU4_ONLY)
+#else
 // ---- blocks of up to 16 rows: four blocks per wavefront ---------------------------------------------------------
 // A 10 x 10 block (the H2-size mechanisms) leaves 54 of k_lu's 64 lanes idle.  k_lu16 gives every block one DPP row
 // of 16 lanes: lane = 16 g + i holds row i of block g, the pivot is a maximum over the row of lanes (four DPP
@@ -1066,6 +1094,12 @@ inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, do
     if (PJ_LU4 && nsp > 64 && nsp <= 128 && !(mode & LU_PREFACTORED)) {
         const long slots = (n + 127) / 128 * 128;
         const long blocks = slots < (long)cus * 8 ? slots : (long)cus * 8;
+#ifdef PJ_LU4_SPLIT
+        if (nsp <= 80) lu4_go_80((unsigned)blocks, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
+        else if (nsp <= 96) lu4_go_96((unsigned)blocks, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
+        else if (nsp <= 112) lu4_go_112((unsigned)blocks, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
+        else lu4_go_128((unsigned)blocks, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
+#else
         auto go = [&](auto ncc) {
             hipLaunchKernelGGL((k_lu4<decltype(ncc)::value>), dim3((unsigned)blocks), dim3(256), 0, st, nsp, n, A, Y, gamma, lu, perm, b, x, mode);
         };
@@ -1073,6 +1107,7 @@ inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, do
         else if (nsp <= 96) go(std::integral_constant<int, 96>{});
         else if (nsp <= 112) go(std::integral_constant<int, 112>{});
         else go(std::integral_constant<int, 128>{});
+#endif
         return 0;
     }
     if (nsp > 64) {
@@ -1110,5 +1145,7 @@ inline int lu_launch(int nsp, long n, const double* A, LuLay Y, double gamma, do
     }
     return 0;
 }
+#endif  // !PJ_LU4_ONLY
 
 }  // namespace pj
+#endif  // !PJ_LU_DECL_ONLY

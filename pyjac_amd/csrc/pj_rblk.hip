@@ -1362,12 +1362,22 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #endif
     double* const Jw = A.jac + s_wave * A.j_ss;
     const unsigned jvo = (unsigned)((s - s_wave) * A.j_ss) * 8u;
-#define J_(e) (*(double*)((char*)(Jw + (long)(e) * A.j_si) + jvo))
+    // The kernel argument block arrives as ONE 16-dword scalar load, and the register allocator treats its 16 SGPRs as one
+    // value: whoever needs a field in the steady state (the entry stride of every store address, sum_last) keeps all 16
+    // alive, they are spilled to VGPR lanes as a tuple and come back as a tuple -- 137 x 16 v_readlane_b32 per state in the
+    // 53-species kernel (round 6: 2 192 of its 3 861 v_readlane, each an issue slot at one wavefront per SIMD).  Opaque copies
+    // of the two fields the blocks read cut them loose.
+    long jsi = A.j_si;
+    int sum_last_ = A.sum_last;
+#ifndef PJR_HOST_EMU
+    asm volatile("" : "+s"(jsi), "+s"(sum_last_));
+#endif
+#define J_(e) (*(double*)((char*)(Jw + (long)(e) * jsi) + jvo))
 #if PJQ_PAIR
     // pair stores (SoA only, host-checked: j_ss == 1, 8 * NSP * j_si < 2^32): a lane of the lower half
     // addresses its own (even) state in column c, its partner in the upper half that state in column c + 1
     const bool upper = (tid & 32) != 0;
-    const unsigned jvo2 = upper ? jvo - 8u + (unsigned)(NSP * A.j_si) * 8u : jvo;
+    const unsigned jvo2 = upper ? jvo - 8u + (unsigned)(NSP * jsi) * 8u : jvo;
 #endif
 
     // hand-over values of the falloff / PLOG visits: those visits come last in a block
@@ -1416,7 +1426,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 d2s out;
                 out.x = v0;
                 out.y = v1;
-                PJQ_STORE2((d2s*)((char*)(Jw + (long)(k + 1 + NSP * c) * A.j_si) + jvo2), out);
+                PJQ_STORE2((d2s*)((char*)(Jw + (long)(k + 1 + NSP * c) * jsi) + jvo2), out);
             } else {
                 PJQ_STORE(&J_(k + 1 + NSP * c), cv(std::integral_constant<int, c>{}));
             }
@@ -1862,7 +1872,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             const double cpk = (RU_ * pjs::SP[k][0]) * (a[0] + T * (a[1] + T * (a[2] + T * (a[3] + a[4] * T))));
             H += hW[r] * om[r];
             SCP += om[r] * pjs::SP[k][1] * cpk;
-            if constexpr (k == LAST) SJT += hW[r] * (A.sum_last ? JT[r] : JTQ);
+            if constexpr (k == LAST) SJT += hW[r] * (sum_last_ ? JT[r] : JTQ);
             else SJT += hW[r] * JT[r];
             HP += hW[r] * P[r];
             HQ += hW[r] * Q[r];
@@ -3219,7 +3229,10 @@ static int run_batch(Ctx& C, long n, const double* pres, const double* y, long y
     if (n <= 0) return 0;
     const bool jv = w != nullptr;
     // w = J v: k_jvd (every reaction once) unless the library has only the row kernels' PJQ_JV builds or those are asked for
-    const bool jvd = jv && g_jvd[0] && !(C.cfg_row_jv && g_rows_jv[0]);
+    // (the row kernels' product asked for -- PJ_RBLK_ROW_JV, pj_spec_ctx_row_jv -- in a library built without it: an error, not
+    // a silent k_jvd; the build-time half of the switch is part of the library's digest, pyjac_amd/specbuild.py ENV)
+    if (jv && C.cfg_row_jv && !g_rows_jv[0]) return -5;
+    const bool jvd = jv && g_jvd[0] && !C.cfg_row_jv;
     if (jv && !jvd && !g_rows_jv[0]) return -5;
     int njvd = 0;
     while (jvd && njvd < MAXPARTS && g_jvd[njvd]) ++njvd;
@@ -3353,11 +3366,13 @@ int pj_spec_ctx_config(void* ctx, int streams, long chunk, int split, int aos_di
 }
 
 // w = J v through the row kernels' PJQ_JV builds (on = 1; a library that has them) or through k_jvd (on = 0, the default);
-// returns what is in force afterwards (also the environment: PJ_RBLK_ROW_JV)
+// returns what is in force afterwards (also the environment: PJ_RBLK_ROW_JV), -5 if the row kernels' product is asked for and
+// the library was built without it (specbuild: PJ_RBLK_ROW_JV at build time)
 int pj_spec_ctx_row_jv(void* ctx, int on)
 {
     Ctx& C = ctx ? *(Ctx*)ctx : default_ctx();
     std::lock_guard<std::mutex> lock(C.batch_mutex);
+    if (on > 0 && !g_rows_jv[0]) return -5;
     if (on >= 0) C.cfg_row_jv = on != 0;
     return (C.cfg_row_jv && g_rows_jv[0]) || !g_jvd[0] ? 1 : 0;
 }

@@ -95,7 +95,8 @@ class Evaluator:
                 specbuild.build_lane(L, self._h, so)
             else:
                 from .kcfactors import kc_factor_rows
-                specbuild.build_rblk(L, self._h, self.nsp, so, kcf_rows=kc_factor_rows(self.tables), nkc=int(self.tables.I[10]), **opts)
+                specbuild.build_rblk(L, self._h, self.nsp, so, kcf_rows=kc_factor_rows(self.tables), nkc=int(self.tables.I[10]),
+                                     nrxn=self.n_fwd, **opts)
         check(L.pj_mech_attach_spec(self._h, so.encode()))
         self.settings_generation += 1
         self.attached_spec = so

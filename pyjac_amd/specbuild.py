@@ -7,11 +7,15 @@ The text of this file, of the kernel sources and of pj_tables.{h,cpp} is part of
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import fcntl
 import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -23,7 +27,8 @@ SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rblk': ('pj_rblk.hip', 'pj_mat
 # environment overrides that shape a binary (experiments): part of the digest
 ENV = ('PJ_LANE_FLAGS', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE', 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES',
        'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST', 'PJ_RBLK_RATE_GROUPS', 'PJ_RBLK_RATE_DEFINES',
-       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV', 'PJ_RBLK_ECL', 'PJ_RBLK_WIDE', 'PJ_RBLK_FIN')
+       'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV', 'PJ_RBLK_ECL', 'PJ_RBLK_WIDE', 'PJ_RBLK_FIN',
+       'PJ_RBLK_JVD_GEOMETRY', 'PJ_RBLK_JVD_KC_GLOBAL', 'PJ_RBLK_JVD_DEFINES', 'PJ_RBLK_ROW_JV', 'PJ_RBLK_WIDE_SINGLE_RXN')
 
 # reciprocal instead of IEEE division sequences, contraction, no -0 special-casing; NO reassociation (it keeps
 # every product of an accumulation chain live: +40 AGPRs, -5 %); measured on MI355X against -ffast-math and
@@ -84,6 +89,39 @@ def _hipcc():
     return os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 
+@contextlib.contextmanager
+def compiler_slot():
+    """One of os.cpu_count() compiler tokens shared by every build process of this user on this machine (flock on files of a
+    per-user directory): __graft_entry__.build() compiles the libraries of several mechanisms side by side, each with a
+    thread pool of its own, and without a common bound 8 cores would face 40 hipcc processes of 2 - 5 GB each."""
+    n = int(os.environ.get('PJ_BUILD_SLOTS', os.cpu_count() or 1))
+    d = os.path.join(tempfile.gettempdir(), 'pj_build_slots_%d' % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    fds = []
+    try:
+        while True:
+            for i in range(n):
+                fd = os.open(os.path.join(d, 'slot%d' % i), os.O_CREAT | os.O_RDWR, 0o600)
+                try:
+                    fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                    fds.append(fd)
+                    break
+                except OSError:
+                    os.close(fd)
+            if fds:
+                break
+            time.sleep(0.25)
+        yield
+    finally:
+        for fd in fds:
+            os.close(fd)        # (closing the descriptor drops the lock)
+
+
+def compile_call(cmd):
+    with compiler_slot():
+        subprocess.check_call(cmd)
+
+
 def kernel_resources(so: str):
     """[(kernel name, vgpr spills, scratch bytes per lane, LDS bytes)] of the gfx950 code objects embedded in a built
     library (llvm-objcopy + llvm-readelf of the ROCm toolchain; [] when they are not installed)."""
@@ -129,8 +167,8 @@ def build_lane(L, handle, so: str):
     check(L.pj_mech_emit_spec(handle, hdr.encode()))
     flags = os.environ.get('PJ_LANE_FLAGS', LANE_FLAGS).split()
     tmp = so + '.tmp.%d' % os.getpid()
-    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
-                          ['-DPJS_HEADER="%s"' % hdr, '-I', CSRC, '-o', tmp, os.path.join(CSRC, 'pj_lane.hip')])
+    compile_call([_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + flags +
+                 ['-DPJS_HEADER="%s"' % hdr, '-I', CSRC, '-o', tmp, os.path.join(CSRC, 'pj_lane.hip')])
     _finish(tmp, hdr, None, so)
 
 
@@ -159,16 +197,24 @@ def rblk_lds_bytes(nsp: int, block: int, halves: int, kcf: int, single: int, nkc
     return 8 * max(main, epi)
 
 
-def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0):
+WIDE_SINGLE_RXN = 256     # more than 120 species: ONE row kernel up to this many reactions (a kernel's compile time and its
+                          # register pressure grow with the row blocks a lane group runs through: USC-shaped, 784 reactions,
+                          # 64 states x four lane groups: one kernel 8.9 ms and 36 minutes of hipcc, six kernels 5.0 ms)
+
+
+def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0, nrxn: int = None):
     """(block, halves, kcf, single, ecols, coop) of the row kernels of a mechanism; nkc: its K_c groups (polynomial row
-    pairs, 128 bytes each).
+    pairs, 128 bytes each); nrxn: its reactions (None: unknown, as many as it takes).
     * Per-species equilibrium-constant factors available and ONE kernel's columns of 64 states fit the LDS (concentration
       + two 16-byte factor columns + the finished column sums / the vector of the w = J v build: 48 NSP bytes per state,
       NSP <= 53): 64 states per workgroup, four lane groups on them, ONE row kernel (PJQ_KCF, PJQ_SINGLE).
     * Otherwise the concentration columns (8 NSP bytes per lane) + the K_c rows of the kernel's reactions must fit:
-      256 states (up to 56 species), or 128 states and two lane groups, several row kernels -- or (PJ_RBLK_WIDE=1) 64
-      states, four lane groups with a cooperative prologue, and ONE row kernel if every K_c row of the mechanism fits
-      next to the columns (the column sums of the energy row then travel through the hand-over array: PJQ_ECOLS)."""
+      256 states (up to 56 species), or 128 states and two lane groups (57 .. 120 species), several row kernels -- or,
+      beyond 120 species (and on request: PJ_RBLK_WIDE=1), 64 states and FOUR lane groups with a cooperative prologue
+      (64 states with one lane group -- the geometry this size had until round 5 -- is a 64-thread workgroup: three of a
+      CU's four SIMDs idle), as ONE row kernel if every K_c row of the mechanism fits next to the columns and the mechanism
+      is small enough for one translation unit (the column sums of the energy row then travel through the hand-over
+      array: PJQ_ECOLS)."""
     env = os.environ.get
     fits = lambda **kw: rblk_lds_bytes(nsp, **kw) <= LDS_BYTES
     kcf_default = int(kcf_ok and fits(block=64, halves=4, kcf=1, single=1, jv=True))
@@ -182,11 +228,13 @@ def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0):
         single = int(env('PJ_RBLK_SINGLE', 1))
         coop = int(halves > 1)
     else:
-        wide = int(env('PJ_RBLK_WIDE', 0)) and nsp * 256 * 8 > 112 * 1024
+        wide_default = int(nsp * 128 * 8 > 120 * 1024)
+        wide = int(env('PJ_RBLK_WIDE', wide_default)) and nsp * 256 * 8 > 112 * 1024
         if wide:
             block, halves, coop = 64, 4, 1
-            single = int(fits(block=64, halves=4, kcf=0, single=1, nkc_rows=nkc, ecols=True, coop=True))
-            ecols = single
+            small = env('PJ_RBLK_WIDE') is not None or nrxn is None or nrxn <= int(env('PJ_RBLK_WIDE_SINGLE_RXN', WIDE_SINGLE_RXN))
+            single = int(small and fits(block=64, halves=4, kcf=0, single=1, nkc_rows=nkc, ecols=True, coop=True))
+            ecols = 1      # (applied only if the library comes out with ONE row kernel: build_rblk)
         else:
             block = 256 if nsp * 256 * 8 <= 112 * 1024 else 128 if nsp * 128 * 8 <= 120 * 1024 else 64
             single = 0
@@ -230,7 +278,7 @@ def jvd_geometry(nsp: int, nkc: int, rate_block_clds: int = 0):
 
 
 def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = None, rates_per_part: int = None, defines=(),
-               kcf_rows=None, nkc: int = 0):
+               kcf_rows=None, nkc: int = 0, nrxn: int = None):
     """csrc/pj_rblk.hip: row-block kernels that rebuild the rates they need (+ a pre-pass for the falloff / PLOG
     reactions) and the one-pass rate-output kernels (k_rate: pj_spec_rates).  One translation unit per kernel,
     compiled in parallel; which row blocks / reactions a kernel takes is planned by the C side
@@ -245,7 +293,7 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     work = so[:-3] + '.%d.obj' % pid
     os.makedirs(work, exist_ok=True)
     fuse = int(fuse or os.environ.get('PJ_RBLK_FUSE', RBLK_FUSE))
-    block, halves, kcf, single, ecols, coop = rblk_geometry(nsp, kcf_rows is not None, nkc)
+    block, halves, kcf, single, ecols, coop = rblk_geometry(nsp, kcf_rows is not None, nkc, nrxn)
     if kcf_rows is not None:
         rows = np.ascontiguousarray(kcf_rows, dtype=np.float64)
         check(L.pj_mech_set_kc_factors(handle, rows.ctypes.data_as(ct.POINTER(ct.c_double)), rows.size))
@@ -336,7 +384,7 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     jobs.sort(key=lambda j: 0 if (j[1].startswith('rblk') and nker == 1) else 1 if j[1].startswith('rate') else 2 if j[1].startswith('rblk') else 3)
 
     def run(job):
-        subprocess.check_call(job[0] + ['-o', os.path.join(work, job[1])])
+        compile_call(job[0] + ['-o', os.path.join(work, job[1])])
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
     # A row kernel that keeps values in scratch memory reloads them behind its own Jacobian stores (one in-order vmcnt

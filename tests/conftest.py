@@ -33,6 +33,10 @@ MECHS = {
     # with / without their own, a foreign and a repeated card (mech_interpret.py:735-883): three different T_mid
     'fe_septherm': os.path.join(GOLDEN, 'fe_septherm.inp'),
 }
+# planner-geometry sweep (tests/golden/make_sweep_mechs.py): 9 mechanisms around the geometry thresholds of the row kernels
+# (17 .. 140 species) + 5 seeded random ones; sweep_n054 / sweep_n121 have golden vectors of pyJac's generated C
+import glob as _glob
+MECHS.update({os.path.basename(_f)[:-4]: _f for _f in sorted(_glob.glob(os.path.join(GOLDEN, 'sweep', 'sweep_*.inp')))})
 THERMS = {'fe_septherm': os.path.join(GOLDEN, 'fe_septherm.dat')}
 FRONT_END = ('fe_kcal', 'fe_kelvins', 'fe_kjoules', 'fe_joules', 'fe_evolts', 'fe_septherm')
 

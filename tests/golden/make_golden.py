@@ -39,6 +39,9 @@ CASES = {
     'fe_joules': os.path.join(HERE, 'fe_joules.inp'),
     'fe_evolts': os.path.join(HERE, 'fe_evolts.inp'),
     'fe_septherm': os.path.join(HERE, 'fe_septherm.inp'),
+    # planner-geometry sweep (make_sweep_mechs.py): 256 states / one lane group; beyond 120 species
+    'sweep_n054': os.path.join(HERE, 'sweep', 'sweep_n054.inp'),
+    'sweep_n121': os.path.join(HERE, 'sweep', 'sweep_n121.inp'),
 }
 THERM = {'fe_septherm': os.path.join(HERE, 'fe_septherm.dat')}
 
@@ -53,8 +56,8 @@ def states_for(name, nsp):
         sel = slice(3, None, 17)
         P, T = P[sel], T[sel]
         Y = Y[sel, :9] / Y[sel, :9].sum(axis=1, keepdims=True)
-    elif name in ('gri30_shaped', 'usc2_shaped', 'synth_mid24', 'synth_irrev72'):
-        n = {'gri30_shaped': 64, 'usc2_shaped': 16, 'synth_mid24': 40, 'synth_irrev72': 24}[name]
+    elif name in ('gri30_shaped', 'usc2_shaped', 'synth_mid24', 'synth_irrev72', 'sweep_n054', 'sweep_n121'):
+        n = {'gri30_shaped': 64, 'usc2_shaped': 16, 'synth_mid24': 40, 'synth_irrev72': 24, 'sweep_n054': 24, 'sweep_n121': 16}[name]
         P, ysoa = synth.dist_b(n, nsp, seed=77, Tlo=600, Thi=2500)
         return P, np.ascontiguousarray(ysoa.T)
     else:

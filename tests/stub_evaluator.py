@@ -24,6 +24,9 @@ class StubEvaluator:
         self.tables = build_tables(read_mech(mech))
         self._o = Oracle(self.tables)
         self.nsp, self.n_fwd = self.tables.nsp, self.tables.nrxn
+        # (tests/test_bench_gloo.py: one rank without its library -- the ranks must agree to stop)
+        if os.environ.get('STUB_MISSING_RANK') == os.environ.get('RANK', '0'):
+            self.has_spec = False
 
     @property
     def jacobian_bytes_per_state(self):

@@ -14,19 +14,52 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('world', [1, 2, 8])
-def test_bench_multi_rank_branch_over_gloo(world):
+def _launch(world, validate='512', extra_env=None, timeout=600):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, PJ_BENCH_EVALUATOR='stub_evaluator:make', MASTER_ADDR='127.0.0.1', PJ_VALIDATE_CHUNK='100',
                PYTHONPATH=os.path.join(ROOT, 'tests') + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
-                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
-                          '--gpus', str(world), '--steps', '3', '--warmup', '1', '--workload', 'h2', '--states', '700',
-                          '--validate-states', '512', '--no-cpu-baseline'], env=env, capture_output=True, text=True,
-                         timeout=600)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+                           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+                           '--gpus', str(world), '--steps', '3', '--warmup', '1', '--workload', 'h2', '--states', '700',
+                           '--validate-states', validate, '--no-cpu-baseline'], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_validate_all_states_at_world_two():
+    """--validate-states all: the WHOLE per-rank batch goes through the chunked all-gather (700 states in 100-state chunks),
+    every chunk checked, the remote rank's first 512 states recomputed."""
+    out = _launch(2, validate='all')
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    v = j['validation_allgather']
+    assert v['ok'] is True and v['states_per_rank'] == 700 and v['gathered_bytes'] == 2 * 100 * 700 * 8
+    assert v['remote_states_recomputed'] == 512 and v['remote_max_err_over_tolerance'] == 0.0
+
+
+def test_every_rank_stops_when_one_has_no_library():
+    """A rank without an up-to-date library: no rank compiles, none waits in a barrier -- the ranks agree (one all-reduce of a
+    flag, BEFORE any barrier) and all leave with exit code 3 and ONE message; no JSON line."""
+    import time
+    t0 = time.time()
+    out = _launch(2, extra_env={'STUB_MISSING_RANK': '1'}, timeout=300)
+    assert out.returncode != 0 and time.time() - t0 < 120
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert out.stderr.count('no up-to-date mechanism-specific library') == 1, out.stderr[-2000:]
+    assert 'nothing is compiled inside one' in out.stderr
+
+
+def test_process_group_gets_an_explicit_timeout():
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert "kw['timeout'] = datetime.timedelta(seconds=int(os.environ.get('PJ_DIST_TIMEOUT_S', 1800)))" in src
+
+
+@pytest.mark.parametrize('world', [1, 2, 8])
+def test_bench_multi_rank_branch_over_gloo(world):
+    out = _launch(world)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1                   # rank 0 prints ONE JSON line

@@ -98,3 +98,30 @@ def test_bench_under_torchrun_at_world_size_one():
     assert v['ok'] is True and v['states_per_rank'] == 4096 and v['remote_rank_checked'] == 0
     assert v['remote_max_err_over_tolerance'] <= 1.0 and v['gathered_bytes'] == 53 * 53 * 4096 * 8
     assert j['n_gpus'] == 1 and j['evaluator'].startswith('native') and j['config']['kernel'].startswith('pj_rblk')
+
+
+def test_mechanism_handle_belongs_to_one_device():
+    """A handle, its workspaces and the scratch of an attached library live on the device that was current at its first
+    evaluation (one process per GPU is the supported launch, bench.py sets the device from LOCAL_RANK before anything else);
+    a call with another device current is refused with PJ_EINVAL and a message that says so -- not evaluated on the wrong
+    GPU's memory.  Needs two devices: skipped on the one-GPU test box, runs on the driver's 8-GPU node."""
+    import torch
+    import pyjac_amd
+    from pyjac_amd import synth
+    from pyjac_amd._lib import PyjacError
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one visible GPU: the guard needs a second device to be current')
+    torch.cuda.set_device(0)
+    ev = pyjac_amd.Evaluator(MECHS['h2o2_n2'])
+    pres, y = synth.dist_a(256, ev.nsp)
+    j0 = ev.jacobian(torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda())
+    torch.cuda.set_device(1)
+    try:
+        with pytest.raises(PyjacError, match='belongs to HIP device 0'):
+            ev.jacobian(torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda())
+        # a handle of its own on the second device gives the same Jacobians
+        ev1 = pyjac_amd.Evaluator(MECHS['h2o2_n2'])
+        j1 = ev1.jacobian(torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda())
+        assert torch.equal(j0.cpu(), j1.cpu())
+    finally:
+        torch.cuda.set_device(0)

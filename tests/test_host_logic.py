@@ -3,11 +3,12 @@ run through the thread-emulation harness (tests/emu) against the oracle."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import jac_scaled_err, MECHS, ROOT, thresholded_rel_err
+from conftest import GOLDEN, jac_scaled_err, MECHS, ROOT, thresholded_rel_err
 from oracle.oracle import Oracle
 from pyjac_amd import synth
 from pyjac_amd.mechanism import read_mech
@@ -330,6 +331,38 @@ def test_rblk_geometry_fits_the_lds(tmp_path):
                            '-DPJS_HEADER="%s"' % hdr, '-I', specbuild.CSRC, '-DPJQ_SUMSETS=0', '-DPJQ_SINGLE=1', '-DPJQ_ECL=0',
                            '-DPJQ_BLOCK=%d' % geo[0], '-DPJQ_HALVES=%d' % geo[1], '-DPJQ_C_LDS=%d' % geo[2], '-DPJQ_V_LDS=%d' % geo[3],
                            '-DPJQ_PART=5', '-DPJQ_ID=0', os.path.join(specbuild.CSRC, 'pj_rblk.hip')])
+
+
+def test_sweep_mechanisms_cover_every_planner_geometry():
+    """tests/golden/sweep/ (make_sweep_mechs.py): a mechanism on each side of every geometry threshold of the row kernels,
+    and no geometry launches a workgroup of fewer than 256 threads (until round 5 more than 120 species meant 64 states x ONE
+    lane group: three of a CU's four SIMDs idle).  pyJac scales by emitting more files and never refuses a size
+    (create_jacobian.py:2213-2223).  Every file of the sweep has a prebuilt library in __graft_entry__.spec_build_list()."""
+    import glob
+    import pyjac_amd
+    from pyjac_amd import specbuild
+    from pyjac_amd.kcfactors import kc_factor_rows
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    built = {os.path.basename(j[0]) for j in g.spec_build_list() if j[1] == 'rblk'}
+    seen = {}
+    files = sorted(glob.glob(os.path.join(GOLDEN, 'sweep', 'sweep_*.inp')))
+    assert len(files) >= 14
+    for f in files:
+        assert os.path.basename(f) in built
+        ev = pyjac_amd.Evaluator(f, specialize='off')
+        assert ev.spec_kind() == 'rblk'
+        geo = specbuild.rblk_geometry(ev.nsp, kc_factor_rows(ev.tables) is not None, int(ev.tables.I[10]), ev.n_fwd)
+        seen[ev.nsp] = geo[:3]
+        assert geo[0] * geo[1] >= 256, (f, geo)
+    assert seen[17] == (64, 4, 1) and seen[54] == seen[56] == (256, 1, 0) and seen[57] == seen[120] == (128, 2, 0)
+    assert seen[121] == seen[140] == (64, 4, 0), seen
+    for nsp in range(8, 300):
+        block, halves = specbuild.rblk_geometry(nsp, False, 0, 2000)[:2]
+        if 8 * nsp * block <= 150 * 1024:
+            assert block * halves >= 256, nsp
+    # a mechanism of that size with many reactions gets SEVERAL row kernels (one translation unit per kernel stays compilable)
+    assert specbuild.rblk_geometry(140, False, 100, 120)[3] == 1 and specbuild.rblk_geometry(140, False, 100, 1200)[3] == 0
 
 
 def test_jvd_geometry_model():

@@ -13,7 +13,9 @@ KEYS = ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt', 'jac')
 @pytest.mark.parametrize('name', ['h2o2_n2', 'h2o2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24',
                                   'synth_srichb', 'synth_fracnu', 'synth_irrev72',
                                   # front-end corners: units keywords, separate thermo database (conftest.FRONT_END)
-                                  'fe_kcal', 'fe_kelvins', 'fe_kjoules', 'fe_joules', 'fe_evolts', 'fe_septherm'])
+                                  'fe_kcal', 'fe_kelvins', 'fe_kjoules', 'fe_joules', 'fe_evolts', 'fe_septherm',
+                                  # planner-geometry sweep (tests/golden/make_sweep_mechs.py): 54 and 121 species
+                                  'sweep_n054', 'sweep_n121'])
 def test_oracle_matches_reference_golden(name, golden, tables):
     g = golden(name)
     tab = tables(name)
@@ -43,7 +45,7 @@ def test_oracle_writes_full_jacobian_block(tables):
 
 
 @pytest.mark.parametrize('name', ['h2o2_n2', 'synth_alltypes', 'gri30_shaped', 'usc2_shaped', 'synth_mid24', 'synth_srichb',
-                                  'synth_fracnu', 'synth_irrev72'])
+                                  'synth_fracnu', 'synth_irrev72', 'sweep_n054', 'sweep_n121'])
 def test_oracle_matches_reference_live(name, tables):
     if not Reference.available(name):
         pytest.skip('oracle/_ref not built (no /root/reference here)')

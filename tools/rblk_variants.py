@@ -27,7 +27,7 @@ def main():
             t0 = time.time()
             from pyjac_amd import specbuild, _lib
             from pyjac_amd.kcfactors import kc_factor_rows
-            specbuild.build_rblk(_lib.lib(), ev._h, ev.nsp, so, defines=defines, kcf_rows=kc_factor_rows(ev.tables), nkc=int(ev.tables.I[10]), **opts)
+            specbuild.build_rblk(_lib.lib(), ev._h, ev.nsp, so, defines=defines, kcf_rows=kc_factor_rows(ev.tables), nkc=int(ev.tables.I[10]), nrxn=ev.n_fwd, **opts)
             print('built %s in %.0f s' % (so, time.time() - t0), flush=True)
         return
     import numpy as np, torch
