@@ -498,7 +498,10 @@ PJ_DEV void phase2(const DevMech& M, const Batch& B, double* V, int tid, int NT,
         V[(M.v.RQ + i) * TS + s] = q;
         V[(M.v.RTH + i) * TS + s] = theta;
         V[(M.v.RP + i) * TS + s] = rp;
-        V[(M.v.RQQ + i) * TS + s] = rp + gN;
+        // (the dense sums carry QN_k = sum nu gN, not Q_k = P_k + QN_k: for a column whose species weighs what the last species
+        // weighs, P_k - w_j Q_k = -QN_k exactly, and formed from the two sums it carries the rounding error of P_k -- pj_rblk.hip,
+        // near_last())
+        V[(M.v.RQQ + i) * TS + s] = gN;
 
         if (L.valid) {
             if (B.fwd) B.fwd[RI_(RI_ORIG) * B.o_ld + L.gs] = Rf;
@@ -642,8 +645,9 @@ PJ_DEV void phase_out_block(const DevMech& M, const Batch& B, double* V, int tid
         const double Wk = KC[nsp + k];
         const unsigned si = M.smap[k + nsp * j];
         const double Skj = (si != 0xFFFFu) ? T[(M.v.T_S + (int)si) * TS] : 0.0;
-        // d/dT column: W_k sum_i nu_ki theta_i ; species block: (W_k/W_j)(P_k - w_j Q_k + S_kj)
-        const double blk = (Wk * KC[j]) * (T[(M.v.T_P + k) * TS] - KC[2 * nsp + j] * T[(M.v.T_Q + k) * TS] + Skj);
+        // d/dT column: W_k sum_i nu_ki theta_i ; species block: (W_k/W_j)((1 - w_j) P_k - w_j QN_k + S_kj), Q_k = P_k + QN_k
+        const double wj = KC[2 * nsp + j];
+        const double blk = (Wk * KC[j]) * (((1.0 - wj) * T[(M.v.T_P + k) * TS] - wj * T[(M.v.T_Q + k) * TS]) + Skj);
         const double val = (col == 0) ? Wk * T[(M.v.T_JT + k) * TS] : blk;
         if (row > 0 && L.valid) B.jac[e * B.j_si + L.gs * B.j_ss] = val;   // row 0: phase_out_energy
     }
@@ -675,7 +679,7 @@ PJ_DEV void phase_out_energy(const DevMech& M, const Batch& B, double* V, int ti
                 const uint32_t ks = M.ecol[q];
                 hs += V[(M.v.HW + (int)(ks >> 16)) * TS + s] * T[(M.v.T_S + (int)(ks & 0xFFFFu)) * TS];
             }
-            const double tot = V[(M.v.SC + SC_HP) * TS + s] - spj[3] * V[(M.v.SC + SC_HQ) * TS + s] + hs;
+            const double tot = ((1.0 - spj[3]) * V[(M.v.SC + SC_HP) * TS + s] - spj[3] * V[(M.v.SC + SC_HQ) * TS + s]) + hs;
             val = -tot * spj[0] * icp +
                   (V[(M.v.CP + j) * TS + s] - V[(M.v.CP + last) * TS + s]) * H * L.invrho * icp * icp;
         }

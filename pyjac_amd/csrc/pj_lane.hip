@@ -411,7 +411,6 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             }
         }
         const double rp = (Wbar * invrho) * (q_ - a) + bM;
-        const double rq = rp + gN;
         static_for<ncnt>([&](auto qc) PJL_INL {
             constexpr int q = np0 + decltype(qc)::value;
             constexpr int k = pjs::NET_SP[q][0];
@@ -419,7 +418,9 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
             om[k] += nu * q_;
             jt[k] += nu * theta;
             P[k] += nu * rp;
-            if constexpr (ANY_GN) Q[k] += nu * rq;
+            // (Q holds QN_k = sum nu gN, not Q_k = P_k + QN_k: pj_rblk.hip, near_last() -- for a column whose species weighs what
+            // the last species weighs, P_k - w_j Q_k cancels to -QN_k, and formed from the two sums it carries P_k's rounding error)
+            if constexpr (ANY_GN) Q[k] += nu * gN;
             if constexpr (k == LAST && i == pjs::LASTQ) jtq = nu * theta;
         });
     });
@@ -554,12 +555,13 @@ __global__ void __launch_bounds__(PJL_BLOCK) k_lane(Args A)
     static_for<LAST>([&](auto jc) PJL_INL {
         constexpr int j = decltype(jc)::value;
         const double wj = SPT[j][3], iWj = SPT[j][0];
+        const double omwj = 1.0 - wj;
         double tot = 0.0;
         auto mval = [&](auto kc) PJL_INL {
             constexpr int k = decltype(kc)::value;
             constexpr int si = pjs::SIDX[k][j];
             double m;
-            if constexpr (ANY_GN) m = P[k] - wj * Q[k]; else m = P[k] - wj * P[k];
+            if constexpr (ANY_GN) m = omwj * P[k] - wj * Q[k]; else m = omwj * P[k];
             if constexpr (si >= 0) m += S[si];
             tot += hW[k] * m;
             return m;

@@ -209,7 +209,7 @@ constexpr int S_TH = 0, S_KF = 1, S_KR = 2, S_RP = 3, S_BM = 4, S_BC = 5;
 // the general ones) is then read identically and written identically by both, whatever the order the
 // two workgroups run in (in place, the later one could pick up the earlier one's write-back and add this
 // kernel's share twice: seen once two parts of a batch ran on two streams).
-constexpr int NSUM = 5 + (pjs::NSP - 1);   // H, SCP, SJT, HP, HQ, E_j
+constexpr int NSUM = 5 + (pjs::NSP - 1);   // H, SCP, SJT, HP, HQN, E_j
 #ifdef PJQ_ID
 constexpr int SUM_IN = pjs::NSCQ + (PJQ_ID % 2) * NSUM, SUM_OUT = pjs::NSCQ + ((PJQ_ID + 1) % 2) * NSUM;
 #endif
@@ -288,6 +288,43 @@ constexpr bool has_ecl(int i)
     if (fl & F_EFFTYPE) for (int e = 0; e < pjs::RI[i][RI_EFF_CNT]; ++e) mark(pjs::EFF_SP[pjs::RI[i][RI_EFF_PTR] + e][0]);
     if ((fl & F_COLLIDER) && pjs::RI[i][RI_COLLIDER] >= 0) mark(pjs::RI[i][RI_COLLIDER]);
     return any;
+}
+
+// Columns whose species weighs (nearly) what the last species weighs.  Entry (k, j) is (W_k / W_j)(P_k - w_j Q_k + S_kj) with
+// w_j = W_j / W_N and Q_k = P_k + QN_k: for w_j = 1 -- an isomer of the last species; pyJac leaves whatever species the file
+// lists last in that place when it has no N2 / AR / HE (create_jacobian.py:3521-3542) -- the dense parts cancel EXACTLY,
+// P_k - Q_k = -QN_k, and the reference, which forms a_i (1 - W_j / W_N) per reaction (create_jacobian.py:341-489), gets the
+// small remainder right, while (1 / W_j) W_k P_k - (W_k / W_N) Q_k carries the rounding error of P_k: entries 1e-16 of their
+// row scale off by percents (found by the random-mechanism sweep of round 6: sweep_r2, HCNO next to HOCN).  So the blocks
+// accumulate QN_k = sum nu gN instead of Q_k (one addition per visit less, and nothing at all for the reactions that do not
+// see the last species), a row's W_k Q_k / W_N is formed once from P_k + QN_k, and the FEW columns with |1 - w_j| < 1/64 take
+// (1 / W_j - 1 / W_N) W_k P_k - W_k QN_k / W_N [+ (1 / W_j) W_k S_kj]: no cancellation between sums.  The energy row
+// likewise carries HQN = sum hW_k QN_k and forms (1 - w_j) HP - w_j HQN.
+constexpr bool near_last(int j)
+{
+    const double d = 1.0 - pjs::SP[j][3];
+    return d < 1.0 / 64 && d > -1.0 / 64;
+}
+constexpr bool any_near_last()
+{
+    for (int j = 0; j < pjs::NSP - 1; ++j) if (near_last(j)) return true;
+    return false;
+}
+constexpr bool ANY_NEAR = any_near_last();
+// does a visit of reaction i put anything into QN (a molecule slot, general factor or collider that IS the last species, or
+// an enhanced efficiency of the last species)?
+constexpr bool has_gn(int i)
+{
+    const int fl = pjs::RI[i][RI_FLAGS];
+    if (pjs::RD[i][RD_ANM1] != 0.0) return true;
+    for (int c = RI_R0; c <= RI_R2; ++c) if (pjs::RI[i][c] == pjs::NSP - 1) return true;
+    if (fl & F_REV) for (int c = RI_P0; c <= RI_P2; ++c) if (pjs::RI[i][c] == pjs::NSP - 1) return true;
+    if (fl & F_GEN) {
+        const int nf = pjs::RI[i][RI_GEN_NR] + ((fl & F_REV) ? pjs::RI[i][RI_GEN_NP] : 0);
+        for (int f = 0; f < nf; ++f) if (pjs::GEN_SP[pjs::RI[i][RI_GEN_PTR] + f][0] == pjs::NSP - 1) return true;
+    }
+    if ((fl & F_COLLIDER) && pjs::RI[i][RI_COLLIDER] == pjs::NSP - 1) return true;
+    return false;
 }
 
 // reactions evaluated once per state by k_pre and handed over
@@ -750,6 +787,68 @@ constexpr int MAXNET = max_net_cnt();
 template <int i>
 constexpr bool has_anm1() { return pjs::RD[i][RD_ANM1] != 0.0; }
 
+// PJQ_VCT: the real-valued constants of a visit -- ln A, b, T_a, the K_c prefactor, the enhanced third-body efficiencies --
+// through the SCALAR cache instead of the instruction stream.  A 64-bit literal is two s_mov_b32 (or two v_mov_b32 where an
+// instruction would need a second constant: the constant bus of gfx9 carries one), each an issue slot of its own at one
+// wavefront per SIMD: 11.3 k s_mov_b32 + 5.8 k v_mov_b32 of the 112 k issue slots per state of the 53-species kernel
+// (round 6).  Here a reaction's constants are one 32-byte record {ln A, b, T_a, prefactor} of a table in constant memory
+// (10 KB for 325 reactions: resident in the scalar cache from workgroup to workgroup), read by ONE s_load_dwordx8 -- a visit
+// ahead, next to the LDS reads of the look-ahead, so that the single lgkmcnt(0) at the top of a visit covers both (scalar
+// loads return out of order: any wait on them is a wait for everything, which is what killed round 3's PJQ_RD_CONST, whose
+// loads sat next to their uses) -- and enter the arithmetic as SGPR operands.  Efficiencies: a second table, 64-byte
+// records {alpha_N - 1, alpha_0 - 1 .. alpha_6 - 1} for the reactions that have any.
+#ifndef PJQ_VCT
+#define PJQ_VCT 0
+#endif
+#if PJQ_VCT && !defined(PJR_HOST_EMU)
+#define PJQ_VCT_ON 1
+static_assert(PJQ_KC_AHEAD, "PJQ_VCT: the constants travel with the look-ahead reads of the next visit (PJQ_KC_AHEAD)");
+constexpr int VEW = 8;
+constexpr int max_eff_cnt()
+{
+    int m = 0;
+    for (int i = 0; i < NRXN; ++i) if ((pjs::RI[i][RI_FLAGS] & (F_THD | F_EFFTYPE)) && pjs::RI[i][RI_EFF_CNT] > m) m = pjs::RI[i][RI_EFF_CNT];
+    return m;
+}
+static_assert(max_eff_cnt() <= VEW - 1, "PJQ_VCT: more enhanced colliders per reaction than an efficiency record holds");
+constexpr bool vct_has_eff(int i) { return (pjs::RI[i][RI_FLAGS] & (F_THD | F_EFFTYPE)) && (pjs::RI[i][RI_EFF_CNT] > 0 || pjs::RD[i][RD_ANM1] != 0.0); }
+constexpr int vct_eff_index(int i)
+{
+    int c = 0;
+    for (int q = 0; q < i; ++q) c += vct_has_eff(q) ? 1 : 0;
+    return c;
+}
+constexpr int NVE = vct_eff_index(NRXN);
+struct __attribute__((aligned(64))) VctB { double v[NRXN > 0 ? NRXN : 1][4]; };
+struct __attribute__((aligned(64))) VctE { double v[NVE > 0 ? NVE : 1][VEW]; };
+constexpr VctB make_vctb()
+{
+    VctB t{};
+    for (int i = 0; i < NRXN; ++i) {
+        t.v[i][0] = pjs::RD[i][RD_LNA]; t.v[i][1] = pjs::RD[i][RD_B]; t.v[i][2] = pjs::RD[i][RD_TA];
+        t.v[i][3] = PJQ_KCF ? pjs::KCF_PREFINV[i][0] : pjs::RD[i][RD_LNPREF];
+    }
+    return t;
+}
+constexpr VctE make_vcte()
+{
+    VctE t{};
+    int r = 0;
+    for (int i = 0; i < NRXN; ++i) {
+        if (!vct_has_eff(i)) continue;
+        t.v[r][0] = pjs::RD[i][RD_ANM1];
+        for (int e = 0; e < pjs::RI[i][RI_EFF_CNT]; ++e) t.v[r][1 + e] = pjs::EFF_AM1[pjs::RI[i][RI_EFF_PTR] + e][0];
+        ++r;
+    }
+    return t;
+}
+__device__ const VctB VCTB = make_vctb();
+__device__ const VctE VCTE = make_vcte();
+typedef const __attribute__((address_space(4))) double* pjq_vptr;
+#else
+#define PJQ_VCT_ON 0
+#endif
+
 // visits of block b that read hand-over values
 template <int b>
 constexpr int n_pre_visits()
@@ -1188,6 +1287,13 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         });
     };
     rebase_c();
+#if PJQ_VCT_ON
+    // (opaque: the tables are compile-time constants and the optimiser would fold the loads back into literals; renewed per
+    // row block like the column bases, or a reaction's constants are kept in SGPRs from one of its visits to the next)
+    pjq_vptr vtb_ = (pjq_vptr)&VCTB.v[0][0], vte_ = (pjq_vptr)&VCTE.v[0][0];
+    auto rebase_v = [&]() PJR_INL { asm volatile("" : "+s"(vtb_), "+s"(vte_)); };
+    rebase_v();
+#endif
     unsigned vzo = 0;      // opaque zero, renewed per visit (PJQ_CONC_OPAQUE): see the visit loop
     auto conc = [&](auto spc) PJR_INL {
         constexpr int sp = decltype(spc)::value;
@@ -1289,7 +1395,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #endif
     // energy-row partial sums: touched once per block, the register allocator parks them in AGPRs
     double E[LAST > 0 ? LAST : 1];
-    double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
+    double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQN = 0.0;
     // this lane's column of the hand-over array: a wavefront-uniform 64-bit base (the first lane's address: scalar
     // registers, slot offsets by scalar arithmetic) + a 32-bit per-lane byte offset -- as a per-lane 64-bit pointer it is a
     // kernel-long register pair that the allocator parks in scratch memory and reloads in front of every hand-over load
@@ -1349,7 +1455,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         SCP = scr[hset + (long)(SUM_IN + 1) * PJQ_TILE];
         SJT = scr[hset + (long)(SUM_IN + 2) * PJQ_TILE];
         HP = scr[hset + (long)(SUM_IN + 3) * PJQ_TILE];
-        HQ = scr[hset + (long)(SUM_IN + 4) * PJQ_TILE];
+        HQN = scr[hset + (long)(SUM_IN + 4) * PJQ_TILE];
     }
     // Jacobian entry e of this lane's state: wavefront-uniform 64-bit base (entry offset e * j_si and
     // the wavefront's first state: scalar arithmetic) + a 32-bit per-lane byte offset, so that a store
@@ -1401,7 +1507,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     // One row of a block as store instructions: `piece` h of row r is the column pair (2 h, 2 h + 1) of the pair-store builds
     // (the odd last column alone), column h otherwise; WPr / WQNr / JTr: the row's constants, Sb: the block's sparse sums
     constexpr int PIECES = PJQ_PAIR ? (NSP + 1) / 2 : NSP;
-    auto row_piece = [&](auto bc, auto rc, auto hc, const double WPr, const double WQNr, const double JTr, const double* Sb) PJR_INL {
+    auto row_piece = [&](auto bc, auto rc, auto hc, const double WPr, const double WQNr, const double WCNr, const double JTr, const double* Sb) PJR_INL {
         constexpr int b = decltype(bc)::value, r = decltype(rc)::value, h = decltype(hc)::value;
         constexpr int k = pjs::BLK_ROWS[pjs::BLK_ROW_PTR[b][0] + r][0];
         // Jacobian column c of the row: c = 0 is the d/dT column, c = j + 1 belongs to species j
@@ -1412,8 +1518,15 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             } else {
                 constexpr int j = c - 1;
                 constexpr int si = pjs::SLOC[k][j];
-                if constexpr (si >= 0) return INVW(j) * (WPr + pjs::SP[k][1] * Sb[si]) - WQNr;
-                else return INVW(j) * WPr - WQNr;
+                if constexpr (near_last(j)) {
+                    // (1 / W_j - 1 / W_N) W_k P_k - W_k QN_k / W_N [+ (1 / W_j) W_k S_kj]: see near_last()
+                    constexpr double a1 = pjs::SP[j][0] * (1.0 - pjs::SP[j][3]);
+                    if constexpr (si >= 0) return INVW(j) * (pjs::SP[k][1] * Sb[si]) + (a1 * WPr - WCNr);
+                    else return a1 * WPr - WCNr;
+                } else {
+                    if constexpr (si >= 0) return INVW(j) * (WPr + pjs::SP[k][1] * Sb[si]) - WQNr;
+                    else return INVW(j) * WPr - WQNr;
+                }
             }
         };
         if constexpr (k < LAST) {
@@ -1439,7 +1552,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     constexpr int LO_ = decltype(lo_c)::value, HI_ = decltype(hi_c)::value;
     // PJQ_DEFER: what the stores of a block need, kept until the next block has issued them
     constexpr bool DEFER = PJQ_DEFER && !PJQ_JV;
-    double pWP[DEFER ? pjs::BLK_MAXROWS : 1], pWQN[DEFER ? pjs::BLK_MAXROWS : 1], pJT[DEFER ? pjs::BLK_MAXROWS : 1];
+    double pWP[DEFER ? pjs::BLK_MAXROWS : 1], pWQN[DEFER ? pjs::BLK_MAXROWS : 1], pWCN[DEFER ? pjs::BLK_MAXROWS : 1], pJT[DEFER ? pjs::BLK_MAXROWS : 1];
     double pS[DEFER ? pjs::BLK_MAXNNZ : 1];
     static_range<LO_, HI_>([&](auto bc) PJR_INL {
         constexpr int b = decltype(bc)::value;
@@ -1458,6 +1571,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             rebase_c();
 #if PJQ_KCF
             rebase_x();
+#endif
+#if PJQ_VCT_ON
+            rebase_v();
 #endif
 #endif
             // (the powers of T are REBUILT from the opaque copy, six multiplications per block: as opaque copies of their own
@@ -1482,12 +1598,12 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             T2d = 2.0 * T2; T3d = 3.0 * T3; T4d = 4.0 * T4;
         }
 #endif
-        double om[nrows], P[nrows], Q[nrows], JT[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
+        double om[nrows], P[nrows], QN[nrows], JT[nrows], S[pjs::BLK_NNZ[b][0] > 0 ? pjs::BLK_NNZ[b][0] : 1];
         double EA[nrows];           // energy row, column of each row of the block: sum_i Hr_i G_ij over the block's visits
         double JTQ = 0.0;
         static_for<nrows>([&](auto rc) PJR_INL {
             constexpr int r = decltype(rc)::value;
-            om[r] = 0.0; P[r] = 0.0; Q[r] = 0.0; JT[r] = 0.0; EA[r] = 0.0;
+            om[r] = 0.0; P[r] = 0.0; QN[r] = 0.0; JT[r] = 0.0; EA[r] = 0.0;
         });
         static_for<pjs::BLK_NNZ[b][0]>([&](auto ec) PJR_INL { S[decltype(ec)::value] = 0.0; });
         constexpr int npre = n_pre_visits<b>();
@@ -1500,6 +1616,18 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         // from LDS while visit v is computed (software pipelining by hand: a visit's first consumer of LDS data
         // are those values, and at one wavefront per SIMD nothing else covers the ~120-cycle LDS round trip at
         // the top of every visit)
+#if PJQ_VCT_ON
+        double vcb[2][4], veb[2][VEW];
+        auto fetch_vc = [&](auto vc) PJR_INL {
+            constexpr int v = decltype(vc)::value;
+            constexpr int i = pjs::BLK_RX[v0 + v][0];
+            constexpr int fl_ = pjs::RI[i][RI_FLAGS];
+            if constexpr (!is_pre(i) || (fl_ & F_REV))
+                static_for<4>([&](auto cc) PJR_INL { vcb[v & 1][decltype(cc)::value] = vtb_[i * 4 + decltype(cc)::value]; });
+            if constexpr (vct_has_eff(i))
+                static_for<VEW>([&](auto cc) PJR_INL { veb[v & 1][decltype(cc)::value] = vte_[vct_eff_index(i) * VEW + decltype(cc)::value]; });
+        };
+#endif
 #if PJQ_KCF
         d2 xab[2][MAXNET];
         auto fetch_ka = [&](auto vc) PJR_INL {
@@ -1507,6 +1635,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             constexpr int i = pjs::BLK_RX[v0 + v][0];
             constexpr int NN = (pjs::RI[i][RI_FLAGS] & F_REV) ? pjs::RI[i][RI_NET_CNT] : 0;
             static_for<NN>([&](auto qc) PJR_INL { xab[v & 1][decltype(qc)::value] = factor(std::integral_constant<int, i>{}, qc); });
+#if PJQ_VCT_ON
+            fetch_vc(vc);
+#endif
         };
 #else
         double kab[2][MAXKC][7];
@@ -1519,6 +1650,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 const double* a = LTK + KCM.loc[g] * 16 + ((T <= pjs::KCG[g][0]) ? 0 : 8);
                 static_for<7>([&](auto ec) PJR_INL { kab[v & 1][c][decltype(ec)::value] = a[decltype(ec)::value]; });
             });
+#if PJQ_VCT_ON
+            fetch_vc(vc);
+#endif
         };
 #endif
         if constexpr (nv > 0) fetch_ka(std::integral_constant<int, 0>{});
@@ -1545,7 +1679,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             static_for<pnrows>([&](auto rc) PJR_INL {
                 static_for<PIECES>([&](auto hc) PJR_INL {
                     row_piece(std::integral_constant<int, pb>{}, rc, hc, pWP[decltype(rc)::value], pWQN[decltype(rc)::value],
-                              pJT[decltype(rc)::value], pS);
+                              pWCN[decltype(rc)::value], pJT[decltype(rc)::value], pS);
                 });
             });
         }
@@ -1554,6 +1688,21 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             constexpr int i = pjs::BLK_RX[v0 + v][0];
             constexpr int fl = pjs::RI[i][RI_FLAGS];
             constexpr double nr = pjs::RD[i][RD_NR], np_ = pjs::RD[i][RD_NP];
+#if PJQ_VCT_ON
+            // this visit's constants: SGPRs filled a visit ago (fetch_vc); a constant that is zero or free to encode stays a
+            // literal, so that b = 0 / T_a = 0 still fold their terms away
+#define VC_(f_, lit_) (cheap_literal(lit_) ? (lit_) : vcb[v & 1][f_])
+#define VE_(e_) (cheap_literal(pjs::EFF_AM1[e_][0]) ? pjs::EFF_AM1[e_][0] : veb[v & 1][1 + (e_) - pjs::RI[i][RI_EFF_PTR]])
+            const double c_lna = VC_(0, pjs::RD[i][RD_LNA]), c_b = VC_(1, pjs::RD[i][RD_B]), c_ta = VC_(2, pjs::RD[i][RD_TA]);
+            const double c_pref = VC_(3, (PJQ_KCF ? pjs::KCF_PREFINV[i][0] : pjs::RD[i][RD_LNPREF]));
+            const double c_anm1 = cheap_literal(pjs::RD[i][RD_ANM1]) ? pjs::RD[i][RD_ANM1] : veb[v & 1][0];
+#else
+#define VE_(e_) EFC(e_)
+            const double c_lna = RDC(i, RD_LNA), c_b = RDC(i, RD_B), c_ta = RDC(i, RD_TA);
+            const double c_pref = PJQ_KCF ? pjs::KCF_PREFINV[i][0] : RDC(i, RD_LNPREF);
+            const double c_anm1 = RDC(i, RD_ANM1);
+#endif
+            (void)c_lna; (void)c_b; (void)c_ta; (void)c_pref; (void)c_anm1;
 #if PJQ_CONC_OPAQUE && !defined(PJR_HOST_EMU)
             // the concentration columns never change, so the optimiser would merge all reads of a
             // column into one load and keep the value live across the kernel (register pressure)
@@ -1620,11 +1769,21 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             // reversible reaction are evaluated side by side), or -- PJQ_KCF -- as the product of the net
             // species' factors and the sum of their t_k: no polynomial, no second exponential
             double kf = 0.0, ekc = 0.0, td = 0.0, lnk = 0.0, lnKc = 0.0;
-            if constexpr (!is_pre(i))
-                lnk = RDC(i, RD_LNA) + RDC(i, RD_B) * logT - RDC(i, RD_TA) * invT;
+            // (T_a / T first: it is wanted again for d ln k / dT, and every instruction then carries ONE constant -- the
+            // constant bus of gfx9 takes one scalar operand, a second constant is copied into a vector register pair first)
+            double taT = 0.0;
+            if constexpr (!is_pre(i)) {
+#if PJQ_VCT_ON
+                if constexpr (pjs::RD[i][RD_TA] != 0.0) taT = c_ta * invT;
+                if constexpr (pjs::RD[i][RD_B] != 0.0) lnk = (c_b * logT - taT) + c_lna;
+                else lnk = c_lna - taT;
+#else
+                lnk = c_lna + c_b * logT - c_ta * invT;
+#endif
+            }
 #if PJQ_KCF
             if constexpr ((fl & F_REV) != 0) {
-                ekc = pjs::KCF_PREFINV[i][0];
+                ekc = c_pref;
                 static_for<NNET>([&](auto qc) PJR_INL {
                     constexpr int q = decltype(qc)::value;
                     constexpr double nu = pjs::NET_NU[pjs::RI[i][RI_NET_PTR] + q][0];
@@ -1638,7 +1797,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             (void)lnKc;
 #else
             if constexpr ((fl & F_REV) != 0) {
-                lnKc = RDC(i, RD_LNPREF);
+                lnKc = c_pref;
                 static_for<KCNT>([&](auto cc) PJR_INL {
                     constexpr int c = decltype(cc)::value;
                     const double* a = ka[c];
@@ -1683,14 +1842,18 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     double Mc = mconc;
                     static_for<pjs::RI[i][RI_EFF_CNT]>([&](auto ec) PJR_INL {
                         constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
-                        Mc += EFC(e) * conc(std::integral_constant<int, pjs::EFF_SP[e][0]>{});
+                        Mc += VE_(e) * conc(std::integral_constant<int, pjs::EFF_SP[e][0]>{});
                     });
                     c = Mc;
                     lead = -c * R * invT;
                     if constexpr ((fl & F_EFFTYPE) != 0) bM = R;
                 }
                 if constexpr ((fl & F_NO_DT) == 0) {
-                    const double dlnk = RDC(i, RD_B) + RDC(i, RD_TA) * invT;
+#if PJQ_VCT_ON
+                    const double dlnk = c_b + taT;
+#else
+                    const double dlnk = c_b + c_ta * invT;
+#endif
                     double el = R * dlnk + Rf * (1.0 - nr);
                     if constexpr ((fl & F_REV) != 0) el -= Rr * ((1.0 - np_) - td);
                     theta = (lead + c * invT * el) * invrho;
@@ -1709,7 +1872,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             const double q_ = ckf * pr_ - ckr * pp_;
 
             double gN = 0.0;
-            if constexpr (has_anm1<i>()) gN = bM * RDC(i, RD_ANM1);
+            if constexpr (has_anm1<i>()) gN = bM * c_anm1;
             constexpr int np0 = pjs::RI[i][RI_NET_PTR], ncnt = pjs::RI[i][RI_NET_CNT];
             // reaction enthalpy Hr_i = sum_k nu_ki h_kW_k = R T (sum_k nu_ki t_k + sum nu), t_k = h_k/RT - 1
             // (dead code in the visits that add nothing to the energy row)
@@ -1804,10 +1967,13 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     constexpr int e = pjs::RI[i][RI_EFF_PTR] + decltype(ec)::value;
                     constexpr int es = pjs::EFF_SP[e][0];
                     // the last species' enhanced efficiency is already in gN (RD_ANM1)
-                    if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, EFC(e) * bM);
+                    if constexpr (es != LAST) slot(std::integral_constant<int, es>{}, VE_(e) * bM);
                 });
             }
-            const double rq = rp + gN;
+#undef VE_
+#if PJQ_VCT_ON
+#undef VC_
+#endif
             static_for<ncnt>([&](auto qc) PJR_INL {
                 constexpr int q = np0 + decltype(qc)::value;
                 constexpr int k = pjs::NET_SP[q][0];
@@ -1816,7 +1982,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     constexpr double nu = pjs::NET_NU[q][0];
                     om[r] += nu * q_;
                     P[r] += nu * rp;
-                    Q[r] += nu * rq;
+                    if constexpr (has_gn(i)) QN[r] += nu * gN;        // (Q_k = P_k + QN_k: see near_last())
                     JT[r] += nu * theta;
                     // reference quirk (create_jacobian.py:2786-2818): J_nplusone is assigned, not
                     // accumulated -- the last species keeps the d/dT term of one reaction only
@@ -1833,7 +1999,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 static_range<e0, e1>([&](auto ec) PJR_INL {
                     constexpr int e = decltype(ec)::value, r = e / PIECES, h = e % PIECES;
                     row_piece(std::integral_constant<int, pb>{}, std::integral_constant<int, r>{}, std::integral_constant<int, h>{},
-                              pWP[r], pWQN[r], pJT[r], pS);
+                              pWP[r], pWQN[r], pWCN[r], pJT[r], pS);
                 });
                 PJQ_SCHED_BARRIER();
             }
@@ -1850,9 +2016,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         //   J(k, j) = (1 / W_j) (W_k (P_k + S_kj)) - W_k Q_k / W_N:
         // one literal per column (1 / W_j) instead of two, and where S_kj is structurally zero the entry
         // is one fused multiply-add on row constants.  The energy row Sum_k hW_k (P_k - w_j Q_k + S_kj)
-        // travels as the scalars HP = Sum hW_k P_k, HQ = Sum hW_k Q_k and E_j = Sum_k hW_k S_kj
+        // travels as the scalars HP = Sum hW_k P_k, HQN = Sum hW_k Q_k and E_j = Sum_k hW_k S_kj
         // (structural non-zeros only); the last kernel puts them together.
-        double hW[nrows], WP[nrows], WQN[nrows];
+        double hW[nrows], WP[nrows], WQN[nrows], WCN[nrows];
         static_for<nrows>([&](auto rc) PJR_INL {
             constexpr int r = decltype(rc)::value;
             constexpr int k = pjs::BLK_ROWS[r0 + r][0];
@@ -1875,9 +2041,10 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             if constexpr (k == LAST) SJT += hW[r] * (sum_last_ ? JT[r] : JTQ);
             else SJT += hW[r] * JT[r];
             HP += hW[r] * P[r];
-            HQ += hW[r] * Q[r];
+            HQN += hW[r] * QN[r];
             WP[r] = pjs::SP[k][1] * P[r];
-            WQN[r] = (pjs::SP[k][1] * pjs::SP[LAST][0]) * Q[r];
+            WQN[r] = (pjs::SP[k][1] * pjs::SP[LAST][0]) * (P[r] + QN[r]);
+            WCN[r] = ANY_NEAR ? (pjs::SP[k][1] * pjs::SP[LAST][0]) * QN[r] : 0.0;
         });
         // Jacobian column c of a row: c = 0 is the d/dT column, c = j + 1 belongs to species j
         auto col_val = [&](auto rc, auto cc) PJR_INL {
@@ -1893,6 +2060,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 } else {
                     return INVW(j) * WP[r] - WQN[r];
                 }
+                // (only reached for the last species' pseudo-row, whose values are discarded: row_piece holds the accurate form)
             }
         };
         static_for<nrows>([&](auto rc) PJR_INL {
@@ -1910,12 +2078,12 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #else
                 if constexpr (DEFER && b + 1 < HI_) {
                     // (stored during the next block's visits)
-                    pWP[r] = WP[r]; pWQN[r] = WQN[r]; pJT[r] = JT[r];
+                    pWP[r] = WP[r]; pWQN[r] = WQN[r]; pWCN[r] = WCN[r]; pJT[r] = JT[r];
                 } else {
                     // pair stores: two columns per store instruction -- the halves of the wavefront exchange one value each,
                     // the lower half then writes two states of column c, the upper half the same two states of column c + 1
                     // (16 bytes per lane: half the store instructions in flight for the same bytes)
-                    static_for<PIECES>([&](auto hc) PJR_INL { row_piece(bc, rc, hc, WP[r], WQN[r], JT[r], S); });
+                    static_for<PIECES>([&](auto hc) PJR_INL { row_piece(bc, rc, hc, WP[r], WQN[r], WCN[r], JT[r], S); });
                 }
 #endif
             } else {
@@ -1960,7 +2128,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
         scr[hset + (long)(SUM_OUT + 1) * PJQ_TILE] = SCP;
         scr[hset + (long)(SUM_OUT + 2) * PJQ_TILE] = SJT;
         scr[hset + (long)(SUM_OUT + 3) * PJQ_TILE] = HP;
-        scr[hset + (long)(SUM_OUT + 4) * PJQ_TILE] = HQ;
+        scr[hset + (long)(SUM_OUT + 4) * PJQ_TILE] = HQN;
         static_for<LAST>([&](auto jc) PJR_INL {
             constexpr int j = decltype(jc)::value;
 #ifndef PJQ_NO_E
@@ -2034,12 +2202,12 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                         if constexpr (o != g && ELM.slot[j] < 0 && e_live_col(j)) EX[xi][g < o ? g : g - 1][tid] = E[j];
                     });
             });
-            RED[0][grp][tid] = H; RED[1][grp][tid] = SCP; RED[2][grp][tid] = SJT; RED[3][grp][tid] = HP; RED[4][grp][tid] = HQ;
+            RED[0][grp][tid] = H; RED[1][grp][tid] = SCP; RED[2][grp][tid] = SJT; RED[3][grp][tid] = HP; RED[4][grp][tid] = HQN;
             __syncthreads();
-            H = 0.0; SCP = 0.0; SJT = 0.0; HP = 0.0; HQ = 0.0;
+            H = 0.0; SCP = 0.0; SJT = 0.0; HP = 0.0; HQN = 0.0;
             static_for<G_>([&](auto gc) PJR_INL {
                 constexpr int g = decltype(gc)::value;
-                H += RED[0][g][tid]; SCP += RED[1][g][tid]; SJT += RED[2][g][tid]; HP += RED[3][g][tid]; HQ += RED[4][g][tid];
+                H += RED[0][g][tid]; SCP += RED[1][g][tid]; SJT += RED[2][g][tid]; HP += RED[3][g][tid]; HQN += RED[4][g][tid];
             });
         }
         PJQ_TICK(6)
@@ -2097,7 +2265,8 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
             double cpm, dcpm;
             cp_of(jc, Te, cpm, dcpm);
             const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
-            return -((HP + ecol(jc)) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
+            // ((1 - w_j) HP - w_j HQN: HQ = HP + HQN, see near_last())
+            return -(((1.0 - pjs::SP[j][3]) * HP - pjs::SP[j][3] * HQN) + ecol(jc)) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
         };
 #ifndef PJR_HOST_EMU
         asm volatile("" : "+v"(Te));        // (here: behind the barriers, or the columns' polynomials are evaluated in front of them and kept)
@@ -2191,14 +2360,14 @@ __global__ void __launch_bounds__(FINB) k_fin(PjqArgs A)
     const bool valid = s < A.n;
     if (!valid) s = A.n - 1;
     const double* const scr = scr_of(A, s);
-    double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQ = 0.0;
+    double H = 0.0, SCP = 0.0, SJT = 0.0, HP = 0.0, HQN = 0.0;
     static_for<G_>([&](auto gc) PJR_INL {
         const long hset = (long)decltype(gc)::value * (2 * NSUM) * PJQ_TILE;
         H += scr[hset + (long)SUM_FIN * PJQ_TILE];
         SCP += scr[hset + (long)(SUM_FIN + 1) * PJQ_TILE];
         SJT += scr[hset + (long)(SUM_FIN + 2) * PJQ_TILE];
         HP += scr[hset + (long)(SUM_FIN + 3) * PJQ_TILE];
-        HQ += scr[hset + (long)(SUM_FIN + 4) * PJQ_TILE];
+        HQN += scr[hset + (long)(SUM_FIN + 4) * PJQ_TILE];
     });
     const double* const y = A.y + s * A.y_ss;
     const double T = y[0], p = A.pres[s];
@@ -2265,7 +2434,7 @@ __global__ void __launch_bounds__(FINB) k_fin(PjqArgs A)
         double cpm, dcpm;
         cp_of(jc, Te, cpm, dcpm);
         const double cpj = (RU_ * pjs::SP[j][0]) * cpm;
-        return -((HP + e) - pjs::SP[j][3] * HQ) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
+        return -(((1.0 - pjs::SP[j][3]) * HP - pjs::SP[j][3] * HQN) + e) * pjs::SP[j][0] * icp + (cpj - cpN) * H * invrho * icp * icp;
     };
 #if PJQ_JV
     const double* vp = A.v + s * A.v_ss;

@@ -328,7 +328,7 @@ PJ_DEV void tab_reaction(const DevMech& M, const TabTabs& X, const TabLane& Ln, 
             }
         }
     }
-    R.rq = R.rp + gN;
+    R.rq = gN;      // (the blocks accumulate QN_k = sum nu gN; Q_k = P_k + QN_k: pj_rblk.hip, near_last())
 }
 
 // value of general-stoichiometry factor f (0-based: reactant factors, then product factors) of the reaction:
@@ -462,19 +462,22 @@ PJ_DEV void tab_blocks(const DevMech& M, const TabDev& P, const Batch& B, double
             const double Wk = X.sp[k * SPW + 1];
             const long cs = (long)nsp * B.j_si;
             if (k < last) {
-                const double WP = Wk * Pk, WQN = (Wk * X.sp[last * SPW]) * Qk;
+                // (Qk holds QN_k.  (1 / W_j - 1 / W_N) W_k P_k - W_k QN_k / W_N + (1 / W_j) W_k S_kj: for an isomer of the last
+                // species the first coefficient is exactly zero, as the reference's a_i (1 - W_j / W_N) is)
+                const double iWN = X.sp[last * SPW];
+                const double WP = Wk * Pk, WCN = (Wk * iWN) * Qk;
                 double* Jr = B.jac + gs * B.j_ss + (long)(k + 1) * B.j_si;
                 if (first) {
                     Jr[0] = Wk * JT;                                   // d/dT column (create_jacobian.py:2786-2818)
                     P.scr[(long)k * P.scr_ld + gs] = om;
                 }
-                // J(k, j) = (1 / W_j) (W_k (P_k + S_kj)) - W_k Q_k / W_N, TAB_EB entries at a time
+                // TAB_EB entries at a time
                 for (int e = 0; e < ne; e += TAB_EB) {
                     int w[TAB_EB];
                     double sv[TAB_EB];
                     for (int u = 0; u < TAB_EB; ++u) w[u] = en[e + u];
                     for (int u = 0; u < TAB_EB; ++u) sv[u] = A_(w[u] >> 16);
-                    for (int u = 0; u < TAB_EB; ++u) Jr[cs * ((w[u] & 0xFFFF) + 1)] = ed[e + u] * (WP + Wk * sv[u]) - WQN;
+                    for (int u = 0; u < TAB_EB; ++u) Jr[cs * ((w[u] & 0xFFFF) + 1)] = ed[e + u] * (Wk * sv[u]) + ((ed[e + u] - iWN) * WP - WCN);
                 }
             } else {
                 // the last species has no row of its own: its terms open the energy row's column sums
@@ -490,7 +493,7 @@ PJ_DEV void tab_blocks(const DevMech& M, const TabDev& P, const Batch& B, double
                     P.scr[(long)k * P.scr_ld + gs] = om;
                     P.scr[(long)nsp * P.scr_ld + gs] = M.sum_last ? JT : JTQ;
                 }
-                for (int e = 0; e < ne; ++e) J0[cs * ((en[e] & 0xFFFF) + 1)] = hW * (Pk - ed[e] * Qk + A_(en[e] >> 16));
+                for (int e = 0; e < ne; ++e) J0[cs * ((en[e] & 0xFFFF) + 1)] = hW * (((1.0 - ed[e]) * Pk - ed[e] * Qk) + A_(en[e] >> 16));
             }
         }
         // record r + 2 (requested a record ago) lands in the slot after record r + 1's; the request made above
