@@ -276,6 +276,10 @@ struct pj_mech {
     int ts = 0, nt = 0;       // 0 = auto
     int num_cu = 256;
     Workspace ws, ws1;
+    // the host batch driver (pj_run / the per-state calls) works on a stream of its own: copies, kernels and the final wait
+    // are ordered on it, and nothing else of the process is touched (round 5 ended pj_run with a DEVICE-wide synchronisation:
+    // every other stream of the process stalled with it)
+    hipStream_t run_stream = nullptr;
     // attached register-resident specialisation (pj_lane.hip)
     void* spec_lib = nullptr;
     int (*spec_jac)(long, const double*, const double*, long, long, double*, long, long, int, void*) = nullptr;
@@ -655,6 +659,7 @@ void pj_mech_destroy(pj_mech* m)
         if (m->d_bad) (void)hipFree(m->d_bad);
         m->ws.release(); m->ws1.release();
     }
+    if (m->run_stream) { (void)hipStreamSynchronize(m->run_stream); (void)hipStreamDestroy(m->run_stream); m->run_stream = nullptr; }
     detach_spec(m);
     delete m;
 }
@@ -738,7 +743,7 @@ int pj_mech_emit_rblk_spec(const pj_mech* m, const char* header_path, int acc_bu
                            double cost_entry, int* counts)
 {
     if (acc_budget < 8) return fail(PJ_EINVAL, "accumulator budget too small");
-    if (block < 1 || rate_block < 1 || fuse < 1 || (halves != 1 && halves != 2 && halves != 4)) return fail(PJ_EINVAL, "kernel plan options");
+    if (block < 1 || rate_block < 1 || fuse < 1 || (halves != 1 && halves != 2 && halves != 4 && halves != 8)) return fail(PJ_EINVAL, "kernel plan options");
     RblkPlanOpts O;
     O.fuse = fuse; O.block = block; O.halves = halves; O.single = single != 0; O.rate_block = rate_block; O.rate_c_lds = rate_c_lds;
     O.rate_groups = rate_groups;
@@ -1089,8 +1094,13 @@ static int run_ws(pj_mech* m, Workspace& w, int num, const double* pres, const d
                   double* jac, double* aux)
 {
     const size_t nsp = m->P.nsp, n = (size_t)num;
-    HIPCHK(hipMemcpy(w.pres, pres, 8 * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(w.y, y, 8 * n * nsp, hipMemcpyHostToDevice));
+    // (pyjacob.cu:139-187 copies, launches and copies back on the default stream between two cudaDeviceSynchronize-like
+    // points; here everything is ordered on the handle's own non-blocking stream and the call ends with a wait for THAT
+    // stream -- other streams of the process keep running)
+    if (!m->run_stream) HIPCHK(hipStreamCreateWithFlags(&m->run_stream, hipStreamNonBlocking));
+    hipStream_t st = m->run_stream;
+    HIPCHK(hipMemcpyAsync(w.pres, pres, 8 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(w.y, y, 8 * n * nsp, hipMemcpyHostToDevice, st));
     Batch B;
     memset(&B, 0, sizeof(B));
     B.n = num; B.pres = w.pres; B.y = w.y; B.y_si = num; B.y_ss = 1; B.o_ld = num;
@@ -1099,23 +1109,23 @@ static int run_ws(pj_mech* m, Workspace& w, int num, const double* pres, const d
     const bool spec = jac && m->spec_jac && m->use_spec;
     int rc = PJ_OK;
     if (!aux && m->spec_rates && m->use_spec && (spec || !jac)) {
-        if (m->do_spec_rates(num, w.pres, w.y, B.y_si, B.y_ss, w.conc, w.fwd, w.rev, w.pm, w.sr, w.dy, nullptr))
+        if (m->do_spec_rates(num, w.pres, w.y, B.y_si, B.y_ss, w.conc, w.fwd, w.rev, w.pm, w.sr, w.dy, (void*)st))
             return fail(PJ_EHIP, "specialised kernel launch failed");
     } else {
-        rc = launch(m, B, (jac && !spec) ? MODE_JAC : 0, nullptr, nullptr, aux ? w.aux : nullptr, 0);
+        rc = launch(m, B, (jac && !spec) ? MODE_JAC : 0, nullptr, nullptr, aux ? w.aux : nullptr, st);
     }
     if (rc) return rc;
-    if (spec && m->do_spec_jac(num, w.pres, w.y, B.y_si, B.y_ss, w.jac, B.j_si, B.j_ss, m->M.sum_last, nullptr))
+    if (spec && m->do_spec_jac(num, w.pres, w.y, B.y_si, B.y_ss, w.jac, B.j_si, B.j_ss, m->M.sum_last, (void*)st))
         return fail(PJ_EHIP, "specialised kernel launch failed");
-    HIPCHK(hipDeviceSynchronize());
-    if (conc) HIPCHK(hipMemcpy(conc, w.conc, 8 * n * nsp, hipMemcpyDeviceToHost));
-    if (fwd) HIPCHK(hipMemcpy(fwd, w.fwd, 8 * n * m->P.nrxn, hipMemcpyDeviceToHost));
-    if (rev && m->P.nrev) HIPCHK(hipMemcpy(rev, w.rev, 8 * n * m->P.nrev, hipMemcpyDeviceToHost));
-    if (pres_mod && m->P.npres) HIPCHK(hipMemcpy(pres_mod, w.pm, 8 * n * m->P.npres, hipMemcpyDeviceToHost));
-    if (spec_rates) HIPCHK(hipMemcpy(spec_rates, w.sr, 8 * n * nsp, hipMemcpyDeviceToHost));
-    if (dy) HIPCHK(hipMemcpy(dy, w.dy, 8 * n * nsp, hipMemcpyDeviceToHost));
-    if (jac) HIPCHK(hipMemcpy(jac, w.jac, 8 * n * nsp * nsp, hipMemcpyDeviceToHost));
-    if (aux) HIPCHK(hipMemcpy(aux, w.aux, 8 * n * 3, hipMemcpyDeviceToHost));
+    if (conc) HIPCHK(hipMemcpyAsync(conc, w.conc, 8 * n * nsp, hipMemcpyDeviceToHost, st));
+    if (fwd) HIPCHK(hipMemcpyAsync(fwd, w.fwd, 8 * n * m->P.nrxn, hipMemcpyDeviceToHost, st));
+    if (rev && m->P.nrev) HIPCHK(hipMemcpyAsync(rev, w.rev, 8 * n * m->P.nrev, hipMemcpyDeviceToHost, st));
+    if (pres_mod && m->P.npres) HIPCHK(hipMemcpyAsync(pres_mod, w.pm, 8 * n * m->P.npres, hipMemcpyDeviceToHost, st));
+    if (spec_rates) HIPCHK(hipMemcpyAsync(spec_rates, w.sr, 8 * n * nsp, hipMemcpyDeviceToHost, st));
+    if (dy) HIPCHK(hipMemcpyAsync(dy, w.dy, 8 * n * nsp, hipMemcpyDeviceToHost, st));
+    if (jac) HIPCHK(hipMemcpyAsync(jac, w.jac, 8 * n * nsp * nsp, hipMemcpyDeviceToHost, st));
+    if (aux) HIPCHK(hipMemcpyAsync(aux, w.aux, 8 * n * 3, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return PJ_OK;
 }
 
@@ -1191,19 +1201,21 @@ static int rates_from_conc(pj_mech* m, double T, double pres, const double* C, d
     int rc = one(m);
     if (rc) return rc;
     Workspace& w = m->ws1;
-    HIPCHK(hipMemcpy(w.pres, &pres, 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(w.T, &T, 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(w.conc, C, 8 * (size_t)m->P.nsp, hipMemcpyHostToDevice));
+    if (!m->run_stream) HIPCHK(hipStreamCreateWithFlags(&m->run_stream, hipStreamNonBlocking));
+    hipStream_t st = m->run_stream;         // (see run_ws: the handle's own stream, no device-wide synchronisation)
+    HIPCHK(hipMemcpyAsync(w.pres, &pres, 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(w.T, &T, 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(w.conc, C, 8 * (size_t)m->P.nsp, hipMemcpyHostToDevice, st));
     Batch B;
     memset(&B, 0, sizeof(B));
     B.n = 1; B.pres = w.pres; B.y = w.y; B.y_si = 1; B.y_ss = 1; B.o_ld = 1;
     B.fwd = w.fwd; B.rev = w.rev; B.pres_mod = w.pm;
-    rc = launch(m, B, MODE_CONC_IN, w.conc, w.T, nullptr, 0);
+    rc = launch(m, B, MODE_CONC_IN, w.conc, w.T, nullptr, st);
     if (rc) return rc;
-    HIPCHK(hipDeviceSynchronize());
-    if (fwd) HIPCHK(hipMemcpy(fwd, w.fwd, 8 * (size_t)m->P.nrxn, hipMemcpyDeviceToHost));
-    if (rev && m->P.nrev) HIPCHK(hipMemcpy(rev, w.rev, 8 * (size_t)m->P.nrev, hipMemcpyDeviceToHost));
-    if (pm && m->P.npres) HIPCHK(hipMemcpy(pm, w.pm, 8 * (size_t)m->P.npres, hipMemcpyDeviceToHost));
+    if (fwd) HIPCHK(hipMemcpyAsync(fwd, w.fwd, 8 * (size_t)m->P.nrxn, hipMemcpyDeviceToHost, st));
+    if (rev && m->P.nrev) HIPCHK(hipMemcpyAsync(rev, w.rev, 8 * (size_t)m->P.nrev, hipMemcpyDeviceToHost, st));
+    if (pm && m->P.npres) HIPCHK(hipMemcpyAsync(pm, w.pm, 8 * (size_t)m->P.npres, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return PJ_OK;
 }
 
@@ -1223,14 +1235,16 @@ int pj_eval_spec_rates(pj_mech* m, const double* fwd, const double* rev, const d
     int rc = one(m);
     if (rc) return rc;
     Workspace& w = m->ws1;
-    HIPCHK(hipMemcpy(w.fwd, fwd, 8 * (size_t)m->P.nrxn, hipMemcpyHostToDevice));
-    if (m->P.nrev) HIPCHK(hipMemcpy(w.rev, rev, 8 * (size_t)m->P.nrev, hipMemcpyHostToDevice));
-    if (m->P.npres) HIPCHK(hipMemcpy(w.pm, pres_mod, 8 * (size_t)m->P.npres, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_spec_rates, dim3(1), dim3(64), 0, 0, m->M, 1L, w.fwd, w.rev, w.pm, w.sr);
+    if (!m->run_stream) HIPCHK(hipStreamCreateWithFlags(&m->run_stream, hipStreamNonBlocking));
+    hipStream_t st = m->run_stream;
+    HIPCHK(hipMemcpyAsync(w.fwd, fwd, 8 * (size_t)m->P.nrxn, hipMemcpyHostToDevice, st));
+    if (m->P.nrev) HIPCHK(hipMemcpyAsync(w.rev, rev, 8 * (size_t)m->P.nrev, hipMemcpyHostToDevice, st));
+    if (m->P.npres) HIPCHK(hipMemcpyAsync(w.pm, pres_mod, 8 * (size_t)m->P.npres, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_spec_rates, dim3(1), dim3(64), 0, st, m->M, 1L, w.fwd, w.rev, w.pm, w.sr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
     std::vector<double> sr(m->P.nsp);
-    HIPCHK(hipMemcpy(sr.data(), w.sr, 8 * sr.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(sr.data(), w.sr, 8 * sr.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     // eval_spec_rates writes sp_rates[0..NSP-2] and the last species through dy_N
     for (int k = 0; k < m->P.nsp - 1; ++k) sp_rates[k] = sr[k];
     if (dy_N) *dy_N = sr[m->P.nsp - 1];

@@ -139,6 +139,12 @@ using namespace pj;
 #ifndef PJQ_C_LDS
 #define PJQ_C_LDS 0         // k_pre: concentrations in LDS (set for large mechanisms)
 #endif
+#ifndef PJQ_XCD
+#define PJQ_XCD 0           // k_rblk: XCD-aware workgroup -> states mapping (a contiguous eighth of the batch per XCD)
+#endif
+#ifndef PJQ_STAGGER0
+#define PJQ_STAGGER0 0      // default spread of the first round of k_rblk's workgroups (PjqArgs::stagger)
+#endif
 #define PJQ_TILE 256        // states per scratch tile
 #if defined(PJR_HOST_EMU)
 #define PJQ_STORE(ptr, val) (*(ptr) = (val))
@@ -193,6 +199,8 @@ struct PjqArgs {
     // PJQ_TILE again, as a run-time value: slot offsets of the hand-over array formed with it are scalar arithmetic the
     // optimiser cannot fold into the per-lane address (k_rblk: ScrRef)
     long tile_rt;
+    // k_rblk: spread of the first round of workgroups in units of 64 x 128 cycles (0: all start together)
+    int stagger;
 };
 typedef void (*pjq_launch_fn)(const PjqArgs&, void* stream);
 extern "C" void pjq_register(int id, int kind, pjq_launch_fn fn);
@@ -297,13 +305,16 @@ constexpr bool has_ecl(int i)
 // small remainder right, while (1 / W_j) W_k P_k - (W_k / W_N) Q_k carries the rounding error of P_k: entries 1e-16 of their
 // row scale off by percents (found by the random-mechanism sweep of round 6: sweep_r2, HCNO next to HOCN).  So the blocks
 // accumulate QN_k = sum nu gN instead of Q_k (one addition per visit less, and nothing at all for the reactions that do not
-// see the last species), a row's W_k Q_k / W_N is formed once from P_k + QN_k, and the FEW columns with |1 - w_j| < 1/64 take
+// see the last species), a row's W_k Q_k / W_N is formed once from P_k + QN_k, and the columns with w_j = 1 take
 // (1 / W_j - 1 / W_N) W_k P_k - W_k QN_k / W_N [+ (1 / W_j) W_k S_kj]: no cancellation between sums.  The energy row
 // likewise carries HQN = sum hW_k QN_k and forms (1 - w_j) HP - w_j HQN.
 constexpr bool near_last(int j)
 {
+    // (only w_j = 1 -- up to the last bits of two differently ordered element sums -- is special: for w_j = 1 - 1e-4, CO next to
+    // N2, the coefficient 1 - w_j itself is known to eps / (1 - w_j) only, in the reference's arithmetic as in this one, and both
+    // forms lose the same digits)
     const double d = 1.0 - pjs::SP[j][3];
-    return d < 1.0 / 64 && d > -1.0 / 64;
+    return d < 1.0 / (1 << 30) && d > -1.0 / (1 << 30);
 }
 constexpr bool any_near_last()
 {
@@ -869,7 +880,7 @@ constexpr OwnerMap make_owner()
 }
 constexpr OwnerMap OWNER = make_owner();
 #ifdef PJQ_TIMING
-__device__ long long g_tim[8][1024][4];
+__device__ long long g_tim[8][1024][8];
 #endif
 
 // Lane groups (PJQ_HALVES = G: 1, 2 or 4).  The workgroup is G groups of PJQ_BLOCK lanes ON THE SAME PJQ_BLOCK
@@ -882,7 +893,7 @@ __device__ long long g_tim[8][1024][4];
 // then free columns and share the columns of the energy row.
 constexpr int G_ = PJQ_HALVES;
 constexpr int NTHR = PJQ_BLOCK * G_;
-static_assert(G_ == 1 || G_ == 2 || G_ == 4, "PJQ_HALVES: 1, 2 or 4 lane groups");
+static_assert(G_ == 1 || G_ == 2 || G_ == 4 || G_ == 8, "PJQ_HALVES: 1, 2, 4 or 8 lane groups (8: two wavefronts per SIMD, 256 registers each)");
 // a column of the energy row has a long-lived sum only if something outside its own row's block contributes (BCOL) --
 // or, with one lane group, always: the block's finished column sum is then kept there until the epilogue
 // (PJQ_ECL: those contributions come from k_pre -- no long-lived sums with several lane groups)
@@ -932,7 +943,29 @@ constexpr bool kcf_used(int k)
 // non-zeros in LDS -- one slot per lane group, column and lane: a single writer each, so the order of the additions is
 // fixed; an update is ONE ds_add_f64 instead of five instructions on an AGPR pair -- brought that to 5.9 ms; since the
 // energy row is finished column by column (BCOL) far fewer long-lived sums exist and they fit the registers.
-constexpr int SM_CL = 0;
+// PJQ_EXPT: the exponentials of k_rblk through the 64-entry table of pj_math.h (exp_tab), which sits in front of everything
+// else so that its reads carry their offset in the instruction
+#ifndef PJQ_EXPT
+#define PJQ_EXPT 0
+#endif
+#if PJQ_EXPT && !defined(PJR_HOST_EMU)
+#define PJQ_EXPT_ON 1
+#define PJQ_EXP1(x_) exp_tab((x_), SM)
+#define PJQ_EXP2(x0_, x1_, y0_, y1_) exp_tab_pair((x0_), (x1_), (y0_), (y1_), SM)
+#else
+#define PJQ_EXPT_ON 0
+#define PJQ_EXP1(x_) exp_one(x_)
+#define PJQ_EXP2(x0_, x1_, y0_, y1_) exp_pair((x0_), (x1_), (y0_), (y1_))
+#endif
+__device__ const double EXPT_G[64] = {PJM_EXPT[0], PJM_EXPT[1], PJM_EXPT[2], PJM_EXPT[3], PJM_EXPT[4], PJM_EXPT[5], PJM_EXPT[6], PJM_EXPT[7],
+    PJM_EXPT[8], PJM_EXPT[9], PJM_EXPT[10], PJM_EXPT[11], PJM_EXPT[12], PJM_EXPT[13], PJM_EXPT[14], PJM_EXPT[15],
+    PJM_EXPT[16], PJM_EXPT[17], PJM_EXPT[18], PJM_EXPT[19], PJM_EXPT[20], PJM_EXPT[21], PJM_EXPT[22], PJM_EXPT[23],
+    PJM_EXPT[24], PJM_EXPT[25], PJM_EXPT[26], PJM_EXPT[27], PJM_EXPT[28], PJM_EXPT[29], PJM_EXPT[30], PJM_EXPT[31],
+    PJM_EXPT[32], PJM_EXPT[33], PJM_EXPT[34], PJM_EXPT[35], PJM_EXPT[36], PJM_EXPT[37], PJM_EXPT[38], PJM_EXPT[39],
+    PJM_EXPT[40], PJM_EXPT[41], PJM_EXPT[42], PJM_EXPT[43], PJM_EXPT[44], PJM_EXPT[45], PJM_EXPT[46], PJM_EXPT[47],
+    PJM_EXPT[48], PJM_EXPT[49], PJM_EXPT[50], PJM_EXPT[51], PJM_EXPT[52], PJM_EXPT[53], PJM_EXPT[54], PJM_EXPT[55],
+    PJM_EXPT[56], PJM_EXPT[57], PJM_EXPT[58], PJM_EXPT[59], PJM_EXPT[60], PJM_EXPT[61], PJM_EXPT[62], PJM_EXPT[63]};
+constexpr int SM_CL = PJQ_EXPT_ON ? 64 : 0;
 constexpr int SM_XT = SM_CL + NSP * PJQ_BLOCK;
 constexpr int SM_IXT = SM_XT + (PJQ_KCF ? 2 * NSP * PJQ_BLOCK : 0);
 constexpr int SM_LTK = SM_IXT + (PJQ_KCF ? 2 * NSP * PJQ_BLOCK : 0);
@@ -1041,19 +1074,48 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
 #endif
     const int tid = (int)threadIdx.x - grp * PJQ_BLOCK;
     // lanes past the end repeat the last state (same values to the same addresses): no divergence
+    // Workgroup -> states.  Workgroups are dealt to the eight XCDs round-robin (workgroup b runs on XCD b % 8), so with states
+    // b * BLOCK .. neighbouring 512-byte pieces of every Jacobian entry are written by eight different L2s.  PJQ_XCD: XCD x
+    // takes a CONTIGUOUS eighth of the batch instead -- the pieces that one L2 collects at a time are neighbours.
+#if PJQ_XCD && !defined(PJR_HOST_EMU)
+    long wgid;
+    {
+        const unsigned b = blockIdx.x, g = gridDim.x, q = g / 8u, r = g % 8u, x = b % 8u;
+        wgid = (long)(x * q + (x < r ? x : r) + b / 8u);
+    }
+#else
+    const long wgid = (long)blockIdx.x;
+#endif
 #if PJQ_PAIR
     // pair stores need whole lane pairs: the last workgroup is shifted back over states its neighbour
     // also evaluates (n >= PJQ_BLOCK, host-checked)
-    long s0_wg = (long)blockIdx.x * PJQ_BLOCK;
+    long s0_wg = wgid * PJQ_BLOCK;
     if (s0_wg + PJQ_BLOCK > A.n) s0_wg = A.n - PJQ_BLOCK;
     // lanes 0..31 of a wavefront: its even states, lanes 32..63: the odd ones (swap_halves)
     const long s = s0_wg + (tid & ~63) + 2 * (tid & 31) + ((tid >> 5) & 1);
 #else
-    long s = (long)blockIdx.x * PJQ_BLOCK + tid;
+    long s = wgid * PJQ_BLOCK + tid;
     if (s >= A.n) s = A.n - 1;
 #endif
 #ifdef PJQ_NO_STORE
     double pjq_sink = 0.0;
+#endif
+#if PJQ_EXPT_ON
+    if (threadIdx.x < 64) SM[threadIdx.x] = EXPT_G[threadIdx.x];
+    if constexpr (G_ == 1 || !PJQ_KCF) __syncthreads();      // (the factor-column prologue has a barrier in front of its exponentials)
+#endif
+#ifndef PJR_HOST_EMU
+    // Every workgroup of a launch runs the same instruction stream on the same schedule, and the first round of workgroups
+    // (one per CU) starts at the same moment: lane group g of ALL 256 CUs reaches the output phase of its block b together,
+    // the chip asks for 256 x 27 KB at once, and between those bursts the memory system idles -- the later rounds inherit the
+    // lockstep, a workgroup starts when one ends.  Phase map of the 53-species kernel (round 6): 231 k cycles per wavefront
+    // with stores, 161 k without, while the stores alone need 130 k at the achievable 6.1 TB/s: neither overlapped (161 k)
+    // nor serialised (291 k).  So the FIRST round is spread out: workgroup i < stagger_wgs sleeps (i * 37 mod 128) x 64 x
+    // A.stagger cycles (at A.stagger = 1 up to 8 k cycles, about one row block's period; once per launch, 0.03 % of it).
+    if (A.stagger > 0 && blockIdx.x < 256u) {
+        const int ph = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 37u) & 127u)) * A.stagger;
+        for (int q = 0; q < ph; ++q) __builtin_amdgcn_s_sleep(1);
+    }
 #endif
     double T, rho, invrho, Wbar, mconc;
     double cpa = 0.0, dcpa = 0.0;       // sum_k C_k cp_k / R and its d/dT: PJQ_KCF prologue, else the last kernel's epilogue
@@ -1155,7 +1217,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                             b[c] = lx ? pjs::KCF_ROW[k][1 + c] : pjs::KCF_ROW[k][8 + c];
                         });
                         const double lnX = b[0] + b[1] * logT_ + T * (b[2] + T * (b[3] + T * (b[4] + b[5] * T))) - b[6] * invT_;
-                        exp_pair(lnX, -lnX, X, IX);
+                        PJQ_EXP2(lnX, -lnX, X, IX);
                     }
                     d2 v; v.x = X; v.y = tq;
                     XT[k][tid] = v;
@@ -1476,7 +1538,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
     long jsi = A.j_si;
     int sum_last_ = A.sum_last;
 #ifndef PJR_HOST_EMU
-    asm volatile("" : "+s"(jsi), "+s"(sum_last_));
+    // (real moves: an empty asm with "+s" operands is coalesced with the tuple's sub-registers again, and the 16 SGPRs stay one
+    // live value -- measured, round 6: 3 884 v_readlane_b32 with it, as many as without)
+    asm volatile("s_mov_b64 %0, %2\n\ts_mov_b32 %1, %3" : "=&s"(jsi), "=&s"(sum_last_) : "s"(A.j_si), "s"(A.sum_last));
 #endif
 #define J_(e) (*(double*)((char*)(Jw + (long)(e) * jsi) + jvo))
 #if PJQ_PAIR
@@ -1539,7 +1603,16 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                 d2s out;
                 out.x = v0;
                 out.y = v1;
+#if defined(PJQ_ST_BITS) && !defined(PJQ_NO_STORE)
+                // experiment: the pair store with explicit cache-policy bits (sc0 / sc1 / nt in any combination) instead of the
+                // compiler's "nt": scalar base + 32-bit lane offset, as the compiler forms it
+                {
+                    double* const sb_ = Jw + (long)(k + 1 + NSP * c) * jsi;
+                    asm volatile("global_store_dwordx4 %0, %1, %2 " PJQ_ST_BITS :: "v"(jvo2), "v"(out), "s"(sb_) : "memory");
+                }
+#else
                 PJQ_STORE2((d2s*)((char*)(Jw + (long)(k + 1 + NSP * c) * jsi) + jvo2), out);
+#endif
             } else {
                 PJQ_STORE(&J_(k + 1 + NSP * c), cv(std::integral_constant<int, c>{}));
             }
@@ -1793,7 +1866,7 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                     if constexpr (!is_pre(i)) td += nu * xf[q].y;
                 });
             }
-            if constexpr (!is_pre(i)) kf = exp_one(lnk);
+            if constexpr (!is_pre(i)) kf = PJQ_EXP1(lnk);
             (void)lnKc;
 #else
             if constexpr ((fl & F_REV) != 0) {
@@ -1806,9 +1879,9 @@ __global__ void __launch_bounds__(NTHR) k_rblk(PjqArgs A)
                         td += a[1] + a[2] * T + a[3] * T2d + a[4] * T3d + a[5] * T4d + a[6] * invT;
                 });
             }
-            if constexpr (!is_pre(i) && (fl & F_REV) != 0) exp_pair(lnk, -lnKc, kf, ekc);
-            else if constexpr (!is_pre(i)) kf = exp_one(lnk);
-            else if constexpr ((fl & F_REV) != 0) ekc = exp_one(-lnKc);
+            if constexpr (!is_pre(i) && (fl & F_REV) != 0) PJQ_EXP2(lnk, -lnKc, kf, ekc);
+            else if constexpr (!is_pre(i)) kf = PJQ_EXP1(lnk);
+            else if constexpr ((fl & F_REV) != 0) ekc = PJQ_EXP1(-lnKc);
 #endif
             if constexpr (pjs::RD[i][RD_SGN] < 0.0) kf = -kf;
 
@@ -3280,8 +3353,10 @@ struct Ctx {
     long cfg_chunk = 0;                  // < 256: the build's default (PJQ_CHUNK)
     int cfg_split = 1;                   // two unequal parts on two streams for a partially filled last round
     int cfg_aos_direct = 0;              // AoS Jacobians by strided lane stores instead of SoA chunks + transpose
+    int cfg_stagger = PJQ_STAGGER0;      // k_rblk: spread of the first round of workgroups (PjqArgs::stagger; PJ_RBLK_STAGGER)
     Ctx()
     {
+        if (const char* e = getenv("PJ_RBLK_STAGGER")) cfg_stagger = atoi(e);
         if (const char* e = getenv("PJ_RBLK_STREAMS")) cfg_streams = atoi(e);
         if (const char* e = getenv("PJ_RBLK_CHUNK")) cfg_chunk = atol(e);
         if (const char* e = getenv("PJ_RBLK_SPLIT")) cfg_split = atoi(e) != 0;
@@ -3463,6 +3538,7 @@ static int run_batch(Ctx& C, long n, const double* pres, const double* y, long y
         PjqArgs A{m, pres + s0, y + s0 * y_ss, y_si, y_ss, jv ? nullptr : jac + s0 * j_ss, j_si, j_ss, C.scr[b], sum_last,
                   jv ? v + s0 * v_ss : nullptr, v_si, v_ss, jv ? w + s0 * w_ss : nullptr, w_si, w_ss};
         A.tile_rt = PJQ_TILE;
+        A.stagger = C.cfg_stagger;
         const bool fast = fast_ok && m >= PJQ_BLOCK;
         if (!jv && !fast && !have_gen) return -5;
         if (jvd) {

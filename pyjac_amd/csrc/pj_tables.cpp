@@ -873,7 +873,7 @@ std::string emit_rows_tables(const Programs& p, int budget, const RblkPlanOpts* 
     if (plan_opts) {
         // ---- kernel plan of a pj_rblk.hip library (which row blocks / reactions each kernel takes) ----
         const RblkPlanOpts& O = *plan_opts;
-        const int halves = (O.halves == 2 || O.halves == 4) ? O.halves : 1, fuse = O.fuse > 0 ? O.fuse : 13;
+        const int halves = (O.halves == 2 || O.halves == 4 || O.halves == 8) ? O.halves : 1, fuse = O.fuse > 0 ? O.fuse : 13;
         // K_c groups a row block / a reaction needs (a kernel stages their polynomial rows in LDS, 128 bytes each)
         auto groups_of_rxn = [&](int i, std::vector<char>& g) {
             const int32_t* ri = &p.ri[(size_t)i * RIW];

@@ -197,9 +197,12 @@ def rblk_lds_bytes(nsp: int, block: int, halves: int, kcf: int, single: int, nkc
     return 8 * max(main, epi)
 
 
-WIDE_SINGLE_RXN = 256     # more than 120 species: ONE row kernel up to this many reactions (a kernel's compile time and its
-                          # register pressure grow with the row blocks a lane group runs through: USC-shaped, 784 reactions,
-                          # 64 states x four lane groups: one kernel 8.9 ms and 36 minutes of hipcc, six kernels 5.0 ms)
+WIDE_SINGLE_RXN = 0       # more than 120 species: ONE row kernel only up to this many reactions.  A kernel's compile time and
+                          # register pressure grow with the row blocks a lane group runs through (USC-shaped, 784 reactions,
+                          # 64 states x four lane groups: one kernel 8.9 ms and 36 minutes of hipcc, six kernels 5.0 ms), and
+                          # where one kernel is compilable it gains nothing: 140 species / 120 reactions, 65 536 states: 2.132 ms
+                          # as one kernel (655 s of hipcc), 2.128 ms as two (profiles/r06_n140_geometries.txt).  So: never by
+                          # default; PJ_RBLK_WIDE_SINGLE_RXN=<n> asks for it (a test geometry)
 
 
 def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0, nrxn: int = None):

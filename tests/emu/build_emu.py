@@ -17,8 +17,18 @@ CSRC = os.path.join(ROOT, 'pyjac_amd', 'csrc')
 def cache_path(files, extra: bytes):
     """Path of a library in the build cache (test infrastructure, like ccache), keyed by the CONTENT of `files` and of
     `extra` (options, generated header text) and the compiler version; None if the cache is off (PJ_EMU_CACHE=off)."""
-    cache_dir = os.environ.get('PJ_EMU_CACHE', os.path.join(tempfile.gettempdir(), 'pj_emu_cache'))
+    # (a per-user directory with mode 0700, not a world-writable predictable path under the system temp directory: the cached
+    # libraries are loaded with ctypes.CDLL)
+    default = os.path.join(os.path.expanduser('~'), '.cache', 'pyjac_amd', 'emu') if os.path.expanduser('~') not in ('', '/') or os.access('/root', os.W_OK) \
+        else os.path.join(ROOT, '.emu_cache')
+    cache_dir = os.environ.get('PJ_EMU_CACHE', default)
     if cache_dir == 'off':
+        return None
+    try:
+        os.makedirs(cache_dir, mode=0o700, exist_ok=True)
+        if os.stat(cache_dir).st_uid != os.getuid():
+            return None             # somebody else's directory: no cache
+    except OSError:
         return None
     h = hashlib.sha256()
     for f in files:
@@ -26,6 +36,13 @@ def cache_path(files, extra: bytes):
     h.update(extra)
     h.update(subprocess.run(['g++', '--version'], capture_output=True).stdout)
     return os.path.join(cache_dir, h.hexdigest()[:32] + '.so')
+
+
+def _report(what, out):
+    """One line per emulation library (pytest -s / PJ_EMU_VERBOSE=1): was g++ run or did the library come from the cache?  A
+    warm-cache run never invokes the compiler, so compiler or flag breakage would otherwise stay hidden."""
+    if os.environ.get('PJ_EMU_VERBOSE', '1') != '0':
+        print('emu build cache %s (%s)' % (what, os.path.basename(out)))
 
 
 def cache_store(cached, out):
@@ -61,7 +78,9 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
                                            pre_halves, fin, tuple(jvd), only_jvd, only_rows)).encode())
     if cached and os.path.exists(cached):
         shutil.copyfile(cached, out)
+        _report('hit', out)
         return out
+    _report('miss: g++' if cached else 'off: g++', out)
     work = out + '.obj'
     os.makedirs(work, exist_ok=True)
     nblk = int(re.search(r'NBLK = (\d+)', t).group(1))

@@ -13,9 +13,10 @@ RTOL = 1e-6
 # 53- / 111-species mechanisms: a few entries per state (~1e-13 of their row / column scale) differ from pyJac's
 # generated C by more than RTOL.  Two independent pieces of evidence say whose rounding error that is:
 #  (a) pyJac's generated C does not reproduce ITSELF there: the same emitted C compiled with -O3 -mfma
-#      -ffp-contract=fast differs from the reference-flags build by 7.2e-7 (GRI-shaped) / 8.6e-4 (USC-shaped) / 9.6e-4
-#      (72 species) -- tests/golden/self_noise.json, measured by tests/golden/make_self_noise.py, live in
-#      tests/test_conditioning.py.  MX_BIG, the bound on kernel-vs-reference under the reference tester's metric, is
+#      -ffp-contract=fast differs from the reference-flags build -- by how much is MEASURED, not typed here:
+#      tests/golden/self_noise.json (written by tests/golden/make_self_noise.py, checked live by
+#      tests/test_conditioning.py; DESIGN.md section 2 shows the same numbers in a block that tools/refresh_docs.py
+#      generates from that file).  MX_BIG, the bound on kernel-vs-reference under the reference tester's metric, is
 #      10x that self-noise; and when the variant libraries travelled with the snapshot (oracle/_ref) the same states
 #      are checked entry by entry: where pyJac reproduces itself to 1e-11 the kernel is within RTOL of pyJac.
 #  (b) the TRUTH -- the reference's formulas evaluated in binary128 (oracle/pyjac_oracle_quad.c, `_truth` below):

@@ -6,7 +6,7 @@ row-block kernels change GEOMETRY with the species count instead (pyjac_amd/spec
     <= 53 species (with factor rows)  64 states x four lane groups, factor columns, ONE row kernel
     54 .. 56                          256 states, one lane group, several row kernels
     57 .. 120                         128 states x two lane groups, several row kernels
-    > 120                             64 states x four lane groups, cooperative prologue, one or several row kernels
+    > 120                             64 states x four lane groups, cooperative prologue, several row kernels (one on request)
 
 The shipped mechanisms sit at 24, 53, 72 and 111 species.  tests/golden/make_sweep_mechs.py puts a small mechanism on each
 side of every threshold (17, 54, 56, 57, 64, 65, 120, 121, 140 species) and adds five seeded random ones (20-60 species);
@@ -31,8 +31,8 @@ SWEEP = {os.path.basename(f)[:-4]: f for f in sorted(glob.glob(os.path.join(GOLD
 GEOMETRY = [k for k in SWEEP if k.startswith('sweep_n')]
 RANDOM = [k for k in SWEEP if k.startswith('sweep_r')]
 # (name, build-time environment, options) of every prebuilt library: __graft_entry__.spec_build_list
-VARIANTS = [(k, {}, {}) for k in SWEEP] + [('sweep_n140', {'PJ_RBLK_SINGLE': '0'}, dict(fuse=8))]
-VIDS = [v[0] + ('-kernels' if v[1] else '') for v in VARIANTS]
+VARIANTS = [(k, {}, {}) for k in SWEEP] + [('sweep_n121', {'PJ_RBLK_WIDE_SINGLE_RXN': '1000'}, {})]
+VIDS = [v[0] + ('-onekernel' if v[1] else '') for v in VARIANTS]
 RTOL = 1e-6
 
 
@@ -67,23 +67,6 @@ def _ev(name, env, opts, monkeypatch):
     assert ev.specialize(build=False, kind='rblk', **opts) and ev.spec_kernel == 'pj_rblk'
     ev.use_spec(2)
     return ev
-
-
-def test_sweep_covers_every_geometry():
-    """(no GPU needed, but it belongs with the sweep) the mechanisms really land in the four geometries, from both sides of
-    every threshold."""
-    import pyjac_amd
-    from pyjac_amd import specbuild
-    from pyjac_amd.kcfactors import kc_factor_rows
-    seen = {}
-    for name in GEOMETRY:
-        ev = pyjac_amd.Evaluator(SWEEP[name], specialize='off')
-        geo = specbuild.rblk_geometry(ev.nsp, kc_factor_rows(ev.tables) is not None, int(ev.tables.I[10]), ev.n_fwd)
-        seen[ev.nsp] = geo[:3]
-        # no geometry launches a workgroup of fewer than 256 threads (64 states x ONE lane group left three SIMDs of a CU idle)
-        assert geo[0] * geo[1] >= 256, (name, geo)
-    assert seen[17] == (64, 4, 1) and seen[54] == seen[56] == (256, 1, 0) and seen[57] == seen[120] == (128, 2, 0)
-    assert seen[121] == seen[140] == (64, 4, 0), seen
 
 
 @pytest.mark.parametrize('variant', VARIANTS, ids=VIDS)
@@ -217,3 +200,32 @@ def test_sweep_vs_reference_golden(name, torch_cuda, monkeypatch):
     assert mixed_err(r['spec_rates'], g['spec_rates'], gross[:, None]) <= 1.0
     assert mixed_err(r['dydt'], g['dydt'], sdy) <= 1.0
     ev.close()
+
+
+@pytest.mark.parametrize('layout', ['soa', 'aos'])
+def test_isomer_of_the_last_species_on_the_register_resident_kernel(layout, torch_cuda):
+    """iso_n012 (CH2 next to CH2(S), which is last: W_j / W_N = 1, the dense parts of that column cancel exactly) through
+    pj_lane and through the table-driven kernels: entry-wise rtol 1e-6 against the binary128 evaluation (tests/
+    test_isomer_columns.py holds the same on the CPU emulation of all four kernel families; sweep_r2 above is the row-block case)."""
+    import pyjac_amd
+    from oracle.oracle import OracleQuad
+    from pyjac_amd import synth
+    from pyjac_amd.mechanism import read_mech
+    from pyjac_amd.tables import build_tables
+    torch = torch_cuda
+    mech = os.path.join(GOLDEN, 'sweep', 'iso_n012.inp')
+    ev = pyjac_amd.Evaluator(mech)
+    assert ev.has_spec and ev.spec_kernel == 'pj_lane', 'pj_lane library of iso_n012 missing: run __graft_entry__.build()'
+    n = 4099
+    pres, y = synth.dist_b(n, ev.nsp, seed=663, Tlo=500, Thi=2600)
+    truth = OracleQuad(build_tables(read_mech(mech))).batch_jacob(pres[:256], np.ascontiguousarray(y.T[:256]))
+    L = pyjac_amd.LAYOUT_SOA if layout == 'soa' else pyjac_amd.LAYOUT_AOS
+    d_p = torch.from_numpy(pres).cuda()
+    d_y = torch.from_numpy(y if layout == 'soa' else np.ascontiguousarray(y.T)).cuda()
+    for use in (2, 0):
+        ev.use_spec(use)
+        jac = ev.jacobian(d_p, d_y, y_layout=L, jac_layout=L).cpu().numpy()
+        jac = jac.T if layout == 'soa' else jac
+        r = float(rel_err_entries(jac[:256], truth).max())
+        print('iso_n012 %s %s: max entry-wise relative error vs binary128 %.3g' % (layout, 'pj_lane' if use else 'table-driven', r))
+        assert np.isfinite(jac).all() and r < RTOL, (layout, use, r)

@@ -75,6 +75,10 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     # several lane groups per workgroup on the same states (each an OS thread in the emulation, a real barrier behind
     # __syncthreads): groups split the row blocks of a kernel, exchange the energy-row sums and share its columns
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, halves=2)),
+    # ... four lane groups over SEVERAL row kernels (buildable through PJ_RBLK_HALVES / what more than 120 species get), and a
+    # factor-column build with another look-ahead depth of the hand-over ring than specbuild's default (PJQ_DEPTH = 3)
+    ('synth_mid24', 40, dict(blocks_per_part=8, rates_per_part=40, halves=4, defines=('-DPJQ_COOP=1',))),
+    ('synth_mid24', 40, dict(rates_per_part=40, kcf=1, halves=4, single=1, defines=('-DPJQ_DEPTH=1',))),
     # the energy-row terms a row block cannot see (enhanced colliders, a falloff collider, a species on both sides): summed
     # once per state by the pre-pass (PJQ_ECL, the default with several lane groups -- the cases above and below) -- here
     # with a two-group pre-pass (the 111-species geometry) and with one lane group

@@ -10,7 +10,11 @@ mech, n, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 kind = sys.argv[4] if len(sys.argv) > 4 else None
 what = sys.argv[5] if len(sys.argv) > 5 else 'jac'
 ev = pyjac_amd.Evaluator(mech, specialize='off')
-if kind != 'table':
+if os.environ.get('PJ_ONE_STEP_LIB'):       # an explicit library (a variant of tools/rblk_variants.py)
+    from pyjac_amd import _lib
+    _lib.check(_lib.lib().pj_mech_attach_spec(ev._h, os.environ['PJ_ONE_STEP_LIB'].encode()))
+    ev.attached_spec = os.environ['PJ_ONE_STEP_LIB']
+elif kind != 'table':
     assert ev.specialize(build=False, kind=kind), 'no prebuilt specialisation'
 pres, y = (synth.dist_a if 'h2o2_n2' in mech else synth.dist_b)(n, ev.nsp)
 d_p = torch.from_numpy(pres).cuda(); d_y = torch.from_numpy(y).cuda()
@@ -42,4 +46,4 @@ else:
                                                 p('pres_mod'), p('spec_rates'), p('dy'), st))
     out = bufs['dy']
 torch.cuda.synchronize()
-print(ev.spec_kernel or 'k_eval', n, steps, bool(torch.isfinite(out[:, ::997]).all()))
+print(ev.spec_kernel or 'k_eval', n, steps, bool(torch.isfinite(out[:, ::997]).all()), 'library', os.path.basename(ev.attached_spec or '-'))

@@ -20,12 +20,12 @@ lib = ctypes.CDLL(so)
 names = ['prologue', 'visits', 'pre-visits', 'output', 'epilogue', 'ep:cp', 'ep:fence', 'ep:loads']
 tot = np.zeros(8)
 for part in range(64):
-    buf = np.zeros((8, 1024, 4), dtype=np.int64)
+    buf = np.zeros((8, 1024, 8), dtype=np.int64)
     if lib.pj_spec_debug_timing(part, buf.ctypes.data_as(ctypes.c_void_p)) != 0:
         break
     # per lane group (several groups per workgroup: index = group; one group: index = wavefront of the workgroup)
     g = buf.mean(axis=1)                    # [phase][group]
-    for q in range(4):
+    for q in range(8):
         if g[:, q].sum() > 0:
             print('   group/wave %d: ' % q + '  '.join('%s %7.0f' % (nm, v) for nm, v in zip(names, g[:, q])) + '   sum %8.0f' % g[:, q].sum())
     m = buf.reshape(8, -1).mean(axis=1)

@@ -3,9 +3,11 @@
 runs of tools/one_step.py).  Sums over all kernels of the step (the pj_rows path has several);
 gfx950: FETCH_SIZE counts half (MI355X_MICROARCH.md HBM section), both counters are in KiB... as
 reported by rocprofv3 (units of 1 KB).
-usage: traffic_pmc.py <fetch_dir> <write_dir> <steps> <states> <bytes_per_state> <label> > profiles/traffic_X.json"""
+usage: traffic_pmc.py <fetch_dir> <write_dir> <steps> <states> <bytes_per_state> <label> [library file name] > profiles/traffic_X.json
+(the library file name carries the digest of kernel sources + build options: bench.py compares it with the attached library)"""
 import csv, glob, json, re, sys
 fd, wd, steps, states, bps, label = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+library = sys.argv[7] if len(sys.argv) > 7 and sys.argv[7] not in ('', '-') else None
 
 
 def total(d, counter):
@@ -24,7 +26,7 @@ w, wper = total(wd, 'WRITE_SIZE')
 hbm = (2.0 * f + w) * 1024.0 / steps
 alg = states * bps
 print(json.dumps({
-    'workload': label, 'states_per_launch': states, 'steps_profiled': steps,
+    'workload': label, 'library': library, 'states_per_launch': states, 'steps_profiled': steps,
     'FETCH_SIZE_KB_per_step': f / steps, 'WRITE_SIZE_KB_per_step': w / steps,
     'per_kernel_KB_per_step': {k: {'FETCH_SIZE': fper.get(k, 0) / steps, 'WRITE_SIZE': wper.get(k, 0) / steps}
                                for k in sorted(set(fper) | set(wper))},

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/valu_<wl>.json from an SQ-counter summary (tools/pmc_summarize.py): VALU instructions per state
 and step, and the share of wave-cycles that issue / wait, summed over the kernels of a Jacobian step.
-usage: valu_roof.py <sq_counters.json> <states per launch> <launches per kernel name:count,...> <label>"""
+usage: valu_roof.py <sq_counters.json> <states per launch> <launches per kernel name:count,...> <label> [library file name]"""
 import json
 import sys
 
@@ -18,7 +18,7 @@ for name, cnt in kernels.items():
                      issue_frac=m('SQ_ACTIVE_INST_ANY') / m('SQ_WAVE_CYCLES'), wait_frac=m('SQ_WAIT_INST_ANY') / m('SQ_WAVE_CYCLES'))
     tot['valu'] += cnt * m('SQ_INSTS_VALU'); tot['salu'] += cnt * m('SQ_INSTS_SALU')
     tot['any'] += cnt * m('SQ_ACTIVE_INST_ANY'); tot['cyc'] += cnt * m('SQ_WAVE_CYCLES'); tot['wait'] += cnt * m('SQ_WAIT_INST_ANY')
-print(json.dumps(dict(source=sys.argv[4], states_per_launch=n,
+print(json.dumps(dict(source=sys.argv[4], library=(sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] not in ('', '-') else None), states_per_launch=n,
                       valu_instr_per_state=tot['valu'] / (n / 64.0),      # per lane = per state
                       salu_instr_per_state=tot['salu'] / (n / 64.0), issue_frac=tot['any'] / tot['cyc'],
                       wait_frac=tot['wait'] / tot['cyc'], kernels=per), indent=1))
