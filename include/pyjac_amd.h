@@ -204,7 +204,9 @@ int pj_debug_phase_cycles(pj_mech* m, long n, const double* d_pres, const double
 /* returns padded (>= 1, multiple of 64; may be < num when device memory is
  * short, the caller then chunks as test.py:709-714 does) or a negative code */
 int pj_init(pj_mech* m, int num);
-/* pyjacob.cu:134-188: all arrays SoA with leading dimension num */
+/* pyjacob.cu:134-188: all arrays SoA with leading dimension num.  Blocking like the reference's run(), but it copies,
+ * launches and copies back on a stream that belongs to the handle and returns after a wait for THAT stream: no device-wide
+ * synchronisation, other streams of the process keep running (the per-state functions below do the same). */
 int pj_run(pj_mech* m, int num, int padded, const double* pres, const double* y,
            double* conc, double* fwd_rxn_rates, double* rev_rxn_rates, double* pres_mod,
            double* spec_rates, double* dy, double* jac);

@@ -365,6 +365,19 @@ def test_sweep_mechanisms_cover_every_planner_geometry():
     assert specbuild.rblk_geometry(140, False, 100, 120)[3] == 0 and specbuild.rblk_geometry(140, False, 100, 1200)[3] == 0
 
 
+def test_prose_tolerances_are_generated_from_the_measurements():
+    """DESIGN.md quotes pyJac's distance from itself (the bound of the GPU parity tests) in a block that tools/refresh_docs.py
+    generates from tests/golden/self_noise.json: a hand-typed or stale number fails here."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'refresh_docs.py'), '--check'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    import json
+    sn = json.load(open(os.path.join(GOLDEN, 'self_noise.json')))
+    assert '%.3g' % sn['usc2_shaped']['self_noise'] in txt and '%.3g' % (10 * sn['gri30_shaped']['self_noise']) in txt
+    assert len(txt.encode()) <= 40 * 1024, 'DESIGN.md: current sections only, at most 40 KB (history: docs/history/)'
+
+
 def test_jvd_geometry_model():
     """specbuild.jvd_geometry: columns + the K_c rows a kernel may have to stage (at most what the rate-kernel plan leaves
     room for) fit the LDS, for every size the row-block family serves."""
