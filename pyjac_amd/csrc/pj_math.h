@@ -95,3 +95,29 @@ __device__ __forceinline__ void exp_tab_pair(const double x0, const double x1, d
     y0 = expt_finish(r0, n0, t0);
     y1 = expt_finish(r1, n1, t1);
 }
+
+// Natural logarithm of a positive NORMAL double (callers clamp with fmax(x, 1e-300)): fdlibm's __ieee754_log without its
+// special cases (< 1 ulp) -- mantissa in [sqrt(1/2), sqrt(2)), s = f / (2 + f), a 7-term polynomial in s^2, the exponent's
+// share of ln 2 in two pieces.  ~40 instructions; the device library's log() is 92 and its exp() 36: a Troe reaction of the
+// pre-pass calls them twice / seven times, which was ALL of that kernel's work (round 6).
+__device__ __forceinline__ double log_lean(const double x)
+{
+    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    constexpr double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01, LG3 = 2.857142874366239149e-01,
+                     LG4 = 2.222219843214978396e-01, LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
+                     LG7 = 1.479819860511658591e-01;
+    int e;
+    double m = __builtin_frexp(x, &e);              // [0.5, 1)
+    const bool lo = m < 0x1.6a09e667f3bcdp-1;       // sqrt(1/2)
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    // (a reciprocal and a product: under -freciprocal-math v_rcp_f64 + two Newton steps, where f / (2 + f) is a 14-instruction
+    // IEEE division sequence)
+    const double s = f * (1.0 / (2.0 + f));
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, LG6, LG4), LG2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, LG7, LG5), LG3), LG1);
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)e;
+    return __builtin_fma(dk, LN2_HI, -((hfsq - __builtin_fma(s, hfsq + R, dk * LN2_LO)) - f));
+}

@@ -371,6 +371,20 @@ __device__ __forceinline__ void group_dispatch(const int grp, F&& f)
 
 #include "pj_math.h"
 
+// exponentials and logarithms of the falloff / PLOG / Chebyshev body (pj_rate_pre.inc: k_pre, k_rate, k_jvd): the lean forms of
+// pj_math.h (18 / 40 instructions) instead of the device library's (36 / 92) -- a Troe reaction calls them seven times / twice,
+// which is where the 427 instructions per hand-over reaction of round 5's k_pre went
+#ifndef PJR_LEAN_MATH
+#define PJR_LEAN_MATH 1
+#endif
+#if PJR_LEAN_MATH && !defined(PJR_HOST_EMU)
+#define PJR_EXP(x_) exp_one(x_)
+#define PJR_LOG(x_) log_lean(x_)
+#else
+#define PJR_EXP(x_) exp(x_)
+#define PJR_LOG(x_) log(x_)
+#endif
+
 // General stoichiometry (F_GEN: a fractional coefficient or more than three molecules on a side; pj_tables.h):
 // C^nu of factor F of the header's GEN_SP / GEN_NU lists -- whole-number coefficients by repeated multiplication,
 // as the reference emits them, fractional ones through pow() (rate_subs.py:634-658) -- and nu C^(nu-1), where the

@@ -312,8 +312,11 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     # concentrations in LDS -- 128 states and two lane groups
     p_block, p_halves = (128, 2) if c_lds else (256, 1)
     # balance of the lane groups: time of a visit / of a Jacobian entry of the output phase (0: the planner's defaults,
-    # measured on the 111-species kernels; one-kernel factor-column builds, GRI-shaped, -DPJQ_TIMING: 412 / 115 cycles)
-    cv, ce = (float(x) for x in os.environ.get('PJ_RBLK_HALF_COST', '0.206,0.0575' if kcf else '0,0').split(','))
+    # measured on the 111-species kernels).  One-kernel factor-column builds, GRI-shaped, -DPJQ_TIMING with the stores flowing
+    # (round 6, profiles/r06_rblk_gri_phase_cycles_timing.txt): 420 - 435 cycles per visit, 94 per entry, and two lane groups
+    # waiting 23 - 25 k of 231 k cycles for the other two under round 4's 0.206 : 0.0575; with the visits weighted 0.5 : 0.094 the
+    # planner moves two blocks and the step goes 5.82 - 5.85 -> 5.71 ms on the same box (profiles/r06_gri_variants_g.txt)
+    cv, ce = (float(x) for x in os.environ.get('PJ_RBLK_HALF_COST', '0.5,0.094' if kcf else '0,0').split(','))
     counts = (ctypes.c_int * 5)()
     check(L.pj_mech_emit_rblk_spec(handle, hdr.encode(), budget, fuse, block, halves, single, r_block, r_clds,
                                    int(rates_per_part or os.environ.get('PJ_RBLK_RATE_GROUPS', 0)), cv, ce, counts))
