@@ -210,7 +210,8 @@ def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0, nrxn: int = None):
     pairs, 128 bytes each); nrxn: its reactions (None: unknown, as many as it takes).
     * Per-species equilibrium-constant factors available and ONE kernel's columns of 64 states fit the LDS (concentration
       + two 16-byte factor columns + the finished column sums / the vector of the w = J v build: 48 NSP bytes per state,
-      NSP <= 53): 64 states per workgroup, four lane groups on them, ONE row kernel (PJQ_KCF, PJQ_SINGLE).
+      NSP <= 53): 64 states per workgroup, four lane groups on them, ONE row kernel (PJQ_KCF, PJQ_SINGLE) -- and where
+      128 states fit (NSP <= 26), 128 states and two lane groups (round 6).
     * Otherwise the concentration columns (8 NSP bytes per lane) + the K_c rows of the kernel's reactions must fit:
       256 states (up to 56 species), or 128 states and two lane groups (57 .. 120 species), several row kernels -- or,
       beyond 120 species (and on request: PJ_RBLK_WIDE=1), 64 states and FOUR lane groups with a cooperative prologue
@@ -226,8 +227,14 @@ def rblk_geometry(nsp: int, kcf_ok: bool, nkc: int = 0, nrxn: int = None):
         raise ValueError('PJ_RBLK_KCF=1: the mechanism has no per-species factor rows (pyjac_amd/kcfactors.py)')
     ecols, coop = 0, 0
     if kcf:
-        block = int(env('PJ_RBLK_BLOCK', 64))
-        halves = int(env('PJ_RBLK_HALVES', 4))
+        # small mechanisms (up to 26 species: the columns of 128 states fit): 128 states x TWO lane groups.  A lane group's
+        # prologue share, its per-state scalars and its epilogue are per-wavefront work that does not shrink with the
+        # mechanism, and with four groups on 64 states it is done twice as often per state: 17 - 24 species, 1e6 states,
+        # same box (profiles/r06_small_variants_m*.txt) 0.32 - 0.34 -> 0.36, 0.35 -> 0.38, 0.39 -> 0.45, 0.34 -> 0.39 - 0.40 of
+        # the roofline (a larger accumulator budget on top is a lottery: 0.40 / 0.45 here, scratch memory and 0.34 there)
+        small = fits(block=128, halves=2, kcf=1, single=1, jv=True)
+        block = int(env('PJ_RBLK_BLOCK', 128 if small else 64))
+        halves = int(env('PJ_RBLK_HALVES', 2 if small else 4))
         single = int(env('PJ_RBLK_SINGLE', 1))
         coop = int(halves > 1)
     else:

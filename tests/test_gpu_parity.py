@@ -603,10 +603,12 @@ def test_large_mechanisms_vs_reference_golden(name, golden, tables, torch_cuda):
 
 @pytest.mark.parametrize('layout', ['soa', 'aos'])
 @pytest.mark.parametrize('n', [4099, 256, 100])
-# build geometry (pyjac_amd/specbuild.py rblk_geometry): the default -- per-species factor columns, 64 states and four
-# lane groups per workgroup, ONE row kernel -- and the per-reaction polynomial form with one lane group on 256 states and
-# several row kernels (energy-row sums handed from kernel to kernel through the scratch slots)
-@pytest.mark.parametrize('geometry', [{}, {'PJ_RBLK_KCF': '0'}], ids=['factors-4groups-1kernel', 'polynomials-1group'])
+# build geometry (pyjac_amd/specbuild.py rblk_geometry): the default of a mechanism this small -- per-species factor
+# columns, 128 states and two lane groups per workgroup, ONE row kernel --, what 27 .. 53 species get (64 states and four
+# lane groups), and the per-reaction polynomial form with one lane group on 256 states and several row kernels (energy-row
+# sums handed from kernel to kernel through the scratch slots)
+@pytest.mark.parametrize('geometry', [{}, {'PJ_RBLK_BLOCK': '64', 'PJ_RBLK_HALVES': '4'}, {'PJ_RBLK_KCF': '0'}],
+                         ids=['factors-2groups-1kernel', 'factors-4groups-1kernel', 'polynomials-1group'])
 def test_rblk_kernels_all_reaction_types(layout, n, geometry, tables, torch_cuda, monkeypatch):
     """csrc/pj_rblk.hip (row blocks that rebuild their rates, falloff / PLOG pre-pass, energy-row
     partials handed from kernel to kernel) on the mechanism that holds every supported reaction type,

@@ -355,7 +355,8 @@ def test_sweep_mechanisms_cover_every_planner_geometry():
         geo = specbuild.rblk_geometry(ev.nsp, kc_factor_rows(ev.tables) is not None, int(ev.tables.I[10]), ev.n_fwd)
         seen[ev.nsp] = geo[:3]
         assert geo[0] * geo[1] >= 256, (f, geo)
-    assert seen[17] == (64, 4, 1) and seen[54] == seen[56] == (256, 1, 0) and seen[57] == seen[120] == (128, 2, 0)
+    assert seen[17] == (128, 2, 1) and seen[54] == seen[56] == (256, 1, 0) and seen[57] == seen[120] == (128, 2, 0)
+    assert specbuild.rblk_geometry(26, True)[:4] == (128, 2, 1, 1) and specbuild.rblk_geometry(27, True)[:4] == (64, 4, 1, 1)
     assert seen[121] == seen[140] == (64, 4, 0), seen
     for nsp in range(8, 300):
         block, halves = specbuild.rblk_geometry(nsp, False, 0, 2000)[:2]

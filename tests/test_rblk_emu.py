@@ -102,6 +102,8 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, kcf=1)),
     ('synth_alltypes', 16, dict(rates_per_part=7, kcf=1, halves=4, single=1)),
     ('h2o2_n2', 12, dict(blocks_per_part=2, rates_per_part=5, kcf=1, halves=2)),
+    # ... two groups and ONE kernel (what mechanisms of up to 26 species get: specbuild.rblk_geometry)
+    ('synth_mid24', 56, dict(rates_per_part=40, kcf=1, halves=2, single=1)),
     # ... with species of three different T_mid (range select per species instead of per K_c group)
     ('fe_septherm', 16, dict(rates_per_part=9, kcf=1, halves=4, single=1)),
     # ... with SRI / Chebyshev reactions (reversible hand-over visits take their 1 / K_c from the factors too)
