@@ -2844,6 +2844,14 @@ struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_FULL ? 8 : 7, launch_rate); } } re
 #ifndef PJQ_JVD_SB
 #define PJQ_JVD_SB 2        // visits between scheduling barriers
 #endif
+#ifndef PJQ_JVD_DYDT
+#define PJQ_JVD_DYDT 0      // 1: the same kernel WITHOUT the vector -- q_i instead of d_i is scattered to the net species, the
+                            // derivative parts of a visit are dead code, and the outputs are pyJac's dydt / eval_spec_rates /
+                            // eval_conc arrays (k_rate's lean kernel in k_jvd's geometry: several lane groups on shared
+                            // concentration columns, two wavefronts per SIMD); registered as the fast lean rate kernel when the
+                            // library has ONE such kernel (nothing travels through `sr`)
+#endif
+constexpr bool DYDT_ = PJQ_JVD_DYDT != 0;
 #ifndef PJQ_JVD_KC_GLOBAL
 #define PJQ_JVD_KC_GLOBAL 0 // 1: the K_c rows are read from the mechanism table in global memory (L1 / L2 resident, a 16-byte load per
                             // lane at one of two addresses) instead of from a copy in LDS: the vector memory path idles in this
@@ -2914,7 +2922,7 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
 #if PJQ_C_LDS
     __shared__ double CL[NSP][PJQ_BLOCK];
 #endif
-#if PJQ_V_LDS
+#if PJQ_V_LDS && !PJQ_JVD_DYDT
     __shared__ double VL[NSP][PJQ_BLOCK];
 #endif
     __shared__ double RED[G_ > 1 ? 4 : 1][PJQ_BLOCK];
@@ -2934,7 +2942,7 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
 #if !PJQ_C_LDS
     State L;
 #endif
-#if !PJQ_V_LDS
+#if !PJQ_V_LDS && !PJQ_JVD_DYDT
     double VR[NSP];                     // vs_c: v_0, v_c / W_{c-1}
 #endif
     double SV0 = 0.0, SV1 = 0.0;
@@ -2953,8 +2961,11 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
                 Hs = A.sr[(SR_SC + 2) * A.sr_ld + s]; SCP = A.sr[(SR_SC + 3) * A.sr_ld + s];
             }
         }
+#if !PJQ_JVD_DYDT
         const double* vp = A.v + s * A.v_ss;
-#if PJQ_V_LDS
+#endif
+#if PJQ_JVD_DYDT
+#elif PJQ_V_LDS
         // the groups fill the vector columns together: group g the components g, g + G_, ... (ONE branch per group with all
         // of its loads in flight -- a test per component is a load, a wait and a store per component, NSP / G_ memory round
         // trips in a row)
@@ -2987,7 +2998,22 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
 #else
 #define CC(idx) L.C[idx]
 #endif
-#if PJQ_V_LDS
+#if PJQ_JVD_DYDT
+#define VS(c_) 0.0
+    static_assert(FIRST_ && LASTK_, "PJQ_JVD_DYDT: one kernel for the mechanism (nothing travels through sr)");
+    // output addresses as in k_rate: wavefront-uniform 64-bit base + a 32-bit per-lane byte offset
+#ifdef PJR_HOST_EMU
+    const long s_wave = s;
+#else
+    const long s_wave = ((long)__builtin_amdgcn_readfirstlane((int)((unsigned long)s >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s);
+#endif
+    const unsigned lvo = (unsigned)(s - s_wave) * 8u;
+#define OUT_(base, row) (*(double*)((char*)((base) + (long)(row) * A.o_ld + s_wave) + lvo))
+    // eval_conc (rate_subs.py:1625-1710)
+    if (A.conc && grp == 0)
+        static_for<NSP>([&](auto kc) PJR_INL { PJQ_STORE(&OUT_(A.conc, decltype(kc)::value), CC(decltype(kc)::value)); });
+#elif PJQ_V_LDS
 #define VS(c_) (*(const double*)((const char*)&VL[c_][0] + lo_))
     static_range<1, NSP>([&](auto cc) PJR_INL {
         constexpr int c = decltype(cc)::value;
@@ -3176,7 +3202,9 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
             q_ = gkf * pr_ - gkr * pp_;
         }
         // H and SCP: the reaction's enthalpy and its temperature derivative times q_i
-        if constexpr ((FL & F_REV) != 0) {
+        if constexpr (DYDT_) {
+            // (the dydt build takes H from the species, as k_rate does)
+        } else if constexpr ((FL & F_REV) != 0) {
             Hs += ((RU_ * T) * (hrt + nsum)) * q_;
             SCP += (RU_ * (dcr + nsum)) * q_;
         } else {
@@ -3234,7 +3262,7 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
             });
         }
         const double rq = rp + gN;
-        const double del = theta * v0 + rp * SV1 - rq * SV0N + dot;
+        const double del = DYDT_ ? q_ : theta * v0 + rp * SV1 - rq * SV0N + dot;
         static_for<ncnt>([&](auto qc) PJR_INL {
             constexpr int q = np0 + decltype(qc)::value;
             constexpr int k = pjs::NET_SP[q][0];
@@ -3282,12 +3310,12 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
         __syncthreads();
         if (grp == g) {
             static_for<NSP>([&](auto kc) PJR_INL { CL[decltype(kc)::value][tid] = acc[decltype(kc)::value]; });
-            RED[0][tid] = JTN; RED[1][tid] = JTQ; RED[2][tid] = Hs; RED[3][tid] = SCP;
+            if constexpr (!DYDT_) { RED[0][tid] = JTN; RED[1][tid] = JTQ; RED[2][tid] = Hs; RED[3][tid] = SCP; }
         }
         __syncthreads();
         if (grp == 0) {
             static_for<NSP>([&](auto kc) PJR_INL { acc[decltype(kc)::value] += CL[decltype(kc)::value][tid]; });
-            JTN += RED[0][tid]; JTQ += RED[1][tid]; Hs += RED[2][tid]; SCP += RED[3][tid];
+            if constexpr (!DYDT_) { JTN += RED[0][tid]; JTQ += RED[1][tid]; Hs += RED[2][tid]; SCP += RED[3][tid]; }
         }
     });
     if (grp != 0) return;
@@ -3296,6 +3324,27 @@ __global__ void __launch_bounds__(NTHR) k_jvd(PjqArgs A)
         static_for<NSP>([&](auto kc) PJR_INL { A.sr[(SR_D + decltype(kc)::value) * A.sr_ld + s] = acc[decltype(kc)::value]; });
         A.sr[(SR_SC + 0) * A.sr_ld + s] = JTN; A.sr[(SR_SC + 1) * A.sr_ld + s] = JTQ;
         A.sr[(SR_SC + 2) * A.sr_ld + s] = Hs; A.sr[(SR_SC + 3) * A.sr_ld + s] = SCP;
+    } else if constexpr (DYDT_) {
+#if PJQ_JVD_DYDT
+        // eval_spec_rates output (rate_subs.py:1297-1542) and dydt (rate_subs.py:2171-2335): k_rate's epilogue
+        if (A.spec_rates)
+            static_for<NSP>([&](auto kc) PJR_INL { PJQ_STORE(&OUT_(A.spec_rates, decltype(kc)::value), acc[decltype(kc)::value]); });
+        if (A.dy) {
+            PJQ_SCHED_BARRIER();
+            fresh();
+            const double cpavg = cpa * (RU_ * invrho);
+            double Hd = 0.0;
+            static_for<NSP>([&](auto kc) PJR_INL {
+                constexpr int k = decltype(kc)::value;
+                double hW, cpm, dcpm;
+                nasa(kc, hW, cpm, dcpm);
+                Hd += hW * acc[k];
+                if constexpr (k < LAST) PJQ_STORE(&OUT_(A.dy, k + 1), acc[k] * pjs::SP[k][1] * invrho);
+            });
+            PJQ_STORE(&OUT_(A.dy, 0), -Hd / (rho * cpavg));
+        }
+#undef OUT_
+#endif
     } else {
         double* wp = A.w + s * A.w_ss;
         double HD = 0.0, hWN = 0.0;
@@ -3325,13 +3374,13 @@ void launch_jvd(const PjqArgs& A, void* stream)
     const long blocks = (A.n + PJQ_BLOCK - 1) / PJQ_BLOCK;
     hipLaunchKernelGGL(k_jvd, dim3((unsigned)blocks), dim3(NTHR), 0, (hipStream_t)stream, A);
 }
-struct Reg { Reg() { pjq_register(PJQ_ID, 9, launch_jvd); } } reg_;     // 9: w = J v, every reaction once
+struct Reg { Reg() { pjq_register(PJQ_ID, PJQ_JVD_DYDT ? 10 : 9, launch_jvd); } } reg_;     // 9: w = J v, every reaction once; 10: its dydt build
 #endif  // PJQ_PART == 5
 
 #if PJQ_PART == 0
 constexpr int MAXPARTS = 256;
 pjq_launch_fn g_pre = nullptr, g_rows[MAXPARTS], g_rows_gen[MAXPARTS], g_rows_jv[MAXPARTS], g_timing[MAXPARTS];
-pjq_launch_fn g_rate_lean[MAXPARTS], g_rate_full[MAXPARTS], g_jvd[MAXPARTS];
+pjq_launch_fn g_rate_lean[MAXPARTS], g_rate_full[MAXPARTS], g_jvd[MAXPARTS], g_rate_fast[MAXPARTS];
 constexpr int MAXSTREAMS = 8;
 // Everything a batch needs beyond the caller's arrays belongs to a CONTEXT: hand-over arrays, internal streams and
 // events, the AoS staging block, the rate kernels' scratch, and the launch settings.  pj_api.hip creates one per
@@ -3360,6 +3409,7 @@ struct Ctx {
     double* jvd_scr[MAXSTREAMS] = {};    // D_k and four scalars between the k_jvd kernels of a library that has several
     long jvd_scr_ld[MAXSTREAMS] = {};
     int cfg_row_jv = 0;                  // w = J v through the row kernels' PJQ_JV builds (if the library has them)
+    int cfg_rate_fast = 1;               // conc / spec_rates / dydt through k_jvd's dydt build (if the library has one) instead of k_rate
     long cfg_aos_chunk = 0;              // states per SoA staging block of the AoS path (0: 65536; PJ_RBLK_AOS_CHUNK)
     // launch settings: the environment is read ONCE, when the context is created (PJ_RBLK_STREAMS, PJ_RBLK_CHUNK,
     // PJ_RBLK_SPLIT, PJ_RBLK_AOS_DIRECT); pj_spec_ctx_config overrides them
@@ -3376,6 +3426,7 @@ struct Ctx {
         if (const char* e = getenv("PJ_RBLK_SPLIT")) cfg_split = atoi(e) != 0;
         cfg_aos_direct = getenv("PJ_RBLK_AOS_DIRECT") != nullptr;
         cfg_row_jv = getenv("PJ_RBLK_ROW_JV") != nullptr;
+        if (const char* e = getenv("PJ_RBLK_RATE_FAST")) cfg_rate_fast = atoi(e) != 0;
         if (const char* e = getenv("PJ_RBLK_AOS_CHUNK")) cfg_aos_chunk = atol(e);
     }
     void release()
@@ -3417,7 +3468,7 @@ void pjq_register(int id, int kind, pjq_launch_fn fn)
 {
     if (kind == 1) g_pre = fn;
     else if (id >= 0 && id < MAXPARTS)
-        (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : kind == 6 ? g_rows_jv : kind == 7 ? g_rate_lean : kind == 8 ? g_rate_full : kind == 9 ? g_jvd : g_rows)[id] = fn;
+        (kind == 5 ? g_timing : kind == 4 ? g_rows_gen : kind == 6 ? g_rows_jv : kind == 7 ? g_rate_lean : kind == 8 ? g_rate_full : kind == 9 ? g_jvd : kind == 10 ? g_rate_fast : g_rows)[id] = fn;
 }
 
 // debug builds (-DPJQ_TIMING): cycles per phase of row kernel `part`, [5][1024 workgroups][4 wavefronts]
@@ -3636,6 +3687,16 @@ int pj_spec_ctx_row_jv(void* ctx, int on)
     return (C.cfg_row_jv && g_rows_jv[0]) || !g_jvd[0] ? 1 : 0;
 }
 
+// conc / spec_rates / dydt through k_jvd's dydt build (on = 1, the default where the library has one) or through k_rate's lean
+// kernels (on = 0; also the environment: PJ_RBLK_RATE_FAST=0); returns what is in force afterwards
+int pj_spec_ctx_rate_fast(void* ctx, int on)
+{
+    Ctx& C = ctx ? *(Ctx*)ctx : default_ctx();
+    std::lock_guard<std::mutex> lock(C.batch_mutex);
+    if (on >= 0) C.cfg_rate_fast = on != 0;
+    return C.cfg_rate_fast && g_rate_fast[0] && !g_rate_fast[1] ? 1 : 0;
+}
+
 int pj_spec_jacobian_ctx(void* ctx, long n, const double* pres, const double* y, long y_si, long y_ss, double* jac,
                          long j_si, long j_ss, int sum_last, void* stream)
 {
@@ -3696,7 +3757,10 @@ int pj_spec_rates_ctx(void* ctx, long n, const double* pres, const double* y, lo
     if (n <= 0) return 0;
     Ctx& C = ctx ? *(Ctx*)ctx : default_ctx();
     const bool full = fwd || rev || pres_mod;
-    pjq_launch_fn* parts = full ? g_rate_full : g_rate_lean;
+    // the lean outputs (conc / spec_rates / dydt): k_jvd's dydt build where the library has one (several lane groups on
+    // shared concentration columns; PJ_RBLK_RATE_FAST=0: k_rate's lean kernels)
+    const bool fast = !full && g_rate_fast[0] && !g_rate_fast[1] && C.cfg_rate_fast;
+    pjq_launch_fn* parts = full ? g_rate_full : fast ? g_rate_fast : g_rate_lean;
     if (!parts[0]) return -5;
     std::lock_guard<std::mutex> lock(C.batch_mutex);
     if (const int rc = enter_batch(C, stream)) return rc;

@@ -25,7 +25,7 @@ SPEC_DIR = os.path.join(HERE, 'spec')
 STEM = {'lane': 'libpj_spec_%016x', 'rblk': 'libpj_rblk_%016x'}
 SOURCES = {'lane': ('pj_lane.hip', 'pj_math.h'), 'rblk': ('pj_rblk.hip', 'pj_math.h', 'pj_rate_pre.inc')}
 # environment overrides that shape a binary (experiments): part of the digest
-ENV = ('PJ_LANE_FLAGS', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE', 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES',
+ENV = ('PJ_RBLK_NO_RATE_FAST', 'PJ_LANE_FLAGS', 'PJ_RBLK_BUDGET', 'PJ_RBLK_FUSE', 'PJ_RBLK_BLOCK', 'PJ_RBLK_FLAGS', 'PJ_RBLK_DEFINES',
        'PJ_RBLK_PAIR_MODES', 'PJ_RBLK_HALVES', 'PJ_RBLK_HALF_COST', 'PJ_RBLK_RATE_GROUPS', 'PJ_RBLK_RATE_DEFINES',
        'PJ_RBLK_KCF', 'PJ_RBLK_SINGLE', 'PJ_RBLK_NO_JV', 'PJ_RBLK_ECL', 'PJ_RBLK_WIDE', 'PJ_RBLK_FIN',
        'PJ_RBLK_JVD_GEOMETRY', 'PJ_RBLK_JVD_KC_GLOBAL', 'PJ_RBLK_JVD_DEFINES', 'PJ_RBLK_ROW_JV', 'PJ_RBLK_WIDE_SINGLE_RXN')
@@ -390,6 +390,10 @@ def build_rblk(L, handle, nsp: int, so: str, budget: int = None, fuse: int = Non
     if jvd is not None and not no_jv:
         for i in range(1 if jvd_kcg else nrate):
             jobs.append((jvd + ['-DPJQ_PART=5', '-DPJQ_ID=%d' % i], 'jvd%d.o' % i))
+    # ... and the same kernel without the vector as the lean rate kernel (conc / spec_rates / dydt), where ONE kernel covers the
+    # mechanism (nothing then travels from kernel to kernel): the lean k_rate kernels stay in the library as the fallback
+    if jvd is not None and (jvd_kcg or nrate == 1) and not os.environ.get('PJ_RBLK_NO_RATE_FAST'):
+        jobs.append((jvd + ['-DPJQ_PART=5', '-DPJQ_ID=0', '-DPJQ_JVD_DYDT=1'], 'jvd_dydt.o'))
     for i in range(nrate):
         for full in (0, 1):
             jobs.append((rate + ['-DPJQ_PART=3', '-DPJQ_ID=%d' % i, '-DPJQ_FULL=%d' % full], 'rate%d_%d.o' % (i, full)))

@@ -130,6 +130,10 @@ def build_rblk(hdr: str, out: str, blocks_per_part: int = 4, rates_per_part: int
         jobs.append((jflags + ['-DPJQ_PART=5', '-DPJQ_ID=%d' % n, '-DPJQ_R0=%d' % r0, '-DPJQ_R1=%d' % min(nrxn, r0 + rates_per_part),
                                '-DPJQ_FIRST=%d' % (n == 0), '-DPJQ_LAST=%d' % (n == len(rstarts) - 1)], 'jvd%d.o' % n))
 
+    # k_jvd's dydt build (the fast lean rate kernel): ONE kernel for the mechanism
+    if not only_jvd:
+        jobs.append((jflags + ['-DPJQ_PART=5', '-DPJQ_ID=0', '-DPJQ_R0=0', '-DPJQ_R1=%d' % nrxn, '-DPJQ_FIRST=1', '-DPJQ_LAST=1',
+                               '-DPJQ_JVD_DYDT=1'], 'jvd_dydt.o'))
     if only_rows:
         jobs = [j for j in jobs if j[1] in ('qhost.o', 'pre.o', 'fin.o') or (j[1].startswith('rblk') and not j[1].endswith('_jv.o'))]
 

@@ -348,8 +348,7 @@ def test_lane_rate_kernel(name, layout, golden, tables, torch_cuda):
 def test_row_block_rate_outputs(name, n, layout, tables, torch_cuda):
     """k_rate of the row-block libraries (pj_eval_rates_dev for the larger mechanisms: one pass over the
     reactions, omega_k in registers; the 111-species library has several kernels and hands omega_k on through
-    memory): every output against the table-driven kernel, dydt also alone (the lean kernels, omega_k then
-    travels through the library's scratch array)."""
+    memory): every output against the table-driven kernel, dydt also alone (the lean path)."""
     import ctypes
     import pyjac_amd
     from pyjac_amd import _lib, synth
@@ -366,7 +365,10 @@ def test_row_block_rate_outputs(name, n, layout, tables, torch_cuda):
     dy = torch.full((ev.nsp, n), float('nan'), dtype=torch.float64, device='cuda')
     _lib.check(_lib.lib().pj_eval_rates_dev(ev._h, n, d_p.data_ptr(), d_y.data_ptr(), L, None, None, None, None, None,
                                             dy.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    assert np.array_equal(dy.cpu().numpy(), lane['dydt'])
+    # (dydt alone: k_jvd's dydt build where the library has one -- another order of summation than the full pass; both are
+    # held against the oracle in test_lean_rate_outputs_fast_kernel_and_fallback)
+    sc0 = np.abs(lane['dydt']).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(dy.cpu().numpy() - lane['dydt']) / (1e-6 * np.abs(lane['dydt']) + 1e-9 * sc0)).max() <= 1.0
     ev.use_spec(False)
     gen = {k: v.cpu().numpy() for k, v in ev.rates(d_p, d_y, y_layout=L).items()}
     for k in ('conc', 'fwd', 'rev', 'pres_mod'):
@@ -711,6 +713,45 @@ def test_large_mechanism_rate_outputs_vs_oracle(name, n, tables, torch_cuda):
             assert mx < 1e-9, (name, use, k, mx)
         assert mixed_err(r['spec_rates'], g['spec_rates'], gross[:, None]) <= 1.0, (name, use)
         assert mixed_err(r['dydt'], g['dydt'], sdy) <= 1.0, (name, use)
+
+
+@pytest.mark.parametrize('name,n', [('gri30_shaped', 4099), ('usc2_shaped', 2053), ('synth_irrev72', 1031), ('synth_mid24', 63)])
+def test_lean_rate_outputs_fast_kernel_and_fallback(name, n, tables, torch_cuda, monkeypatch):
+    """conc / spec_rates / dydt WITHOUT the per-reaction arrays (what an integrator's right-hand side asks for; pyjacob.cu's
+    k_dydt pass, rate_subs.py:1297-1542, 1625-1710, 2171-2335): through k_jvd's dydt build -- every reaction once, several lane
+    groups on shared concentration columns, the default where the library has ONE such kernel -- and through k_rate's lean
+    kernels (PJ_RBLK_RATE_FAST=0), both against the oracle; dydt alone is bit-identical to dydt with the other arrays."""
+    import ctypes
+    import pyjac_amd
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    orc = Oracle(tables(name))
+    got = {}
+    for fast in ('1', '0'):
+        monkeypatch.setenv('PJ_RBLK_RATE_FAST', fast)
+        ev = pyjac_amd.Evaluator(MECHS[name])
+        assert ev.spec_kernel == 'pj_rblk'
+        lib = ctypes.CDLL(ev.attached_spec)
+        lib.pj_spec_ctx_rate_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        if fast == '1' and name != 'synth_mid24':
+            assert lib.pj_spec_ctx_rate_fast(None, 1) == 1, 'the library has no fast lean rate kernel'
+        pres, y = synth.dist_b(n, ev.nsp, seed=77, Tlo=600, Thi=2600)
+        y_aos = np.ascontiguousarray(y.T)
+        o = [orc.eval_all(float(pres[s]), y_aos[s]) for s in range(n)]
+        g = {k: np.array([x[k] for x in o]) for k in ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt')}
+        gross, sdy = rate_scales(tables(name), pres, y_aos, g['conc'], g['fwd'], g['rev'], g['pres_mod'])
+        d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+        r = {k: v.cpu().numpy().T for k, v in ev.rates(d_p, d_y, want=('conc', 'spec_rates', 'dydt')).items()}
+        mx, _ = thresholded_rel_err(r['conc'], g['conc'])
+        assert mx < 1e-9, (name, fast, mx)
+        assert mixed_err(r['spec_rates'], g['spec_rates'], gross[:, None]) <= 1.0, (name, fast)
+        assert mixed_err(r['dydt'], g['dydt'], sdy) <= 1.0, (name, fast)
+        only = ev.rates(d_p, d_y, want=('dydt',))['dydt'].cpu().numpy().T
+        assert np.array_equal(only, r['dydt']), (name, fast)
+        got[fast] = r['dydt']
+        ev.close()
+    assert mixed_err(got['1'], got['0'], sdy) <= 1.0
 
 
 @pytest.mark.parametrize('name,n', [('gri30_shaped', 1_000_000), ('usc2_shaped', 200_000)])

@@ -29,6 +29,10 @@ def _rblk_emu_lib(name, budget, tmp, **kw):
     ('synth_srichb', 16, dict(blocks_per_part=2, rates_per_part=5)),
     # N1: fractional stoichiometric coefficients, more than three molecules / species per side
     ('synth_fracnu', 16, dict(blocks_per_part=2, rates_per_part=6)),
+    # the lean outputs' fast kernel (k_jvd's dydt build) in the GPU geometry: four lane groups on shared concentration columns,
+    # K_c rows from LDS copies / from the table in global memory
+    ('synth_mid24', 40, dict(blocks_per_part=4, rates_per_part=40, jvd=(4, 1, 1))),
+    ('synth_alltypes', 16, dict(blocks_per_part=2, rates_per_part=7, jvd=(4, 1, 1, 1))),
 ])
 def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     """k_rate (pj_spec_rates of the row-block library): conc, fwd, rev, pres_mod, spec_rates handed from
@@ -57,13 +61,30 @@ def test_rate_outputs_vs_oracle(name, budget, kw, tmp_path, tables):
     gross, sdy = rate_scales(tab, pres, y_aos, g['conc'], g['fwd'], g['rev'], g['pres_mod'])
     assert mixed_err(bufs['spec_rates'].T, g['spec_rates'], gross[:, None]) <= 1.0
     assert mixed_err(bufs['dy'].T, g['dydt'], sdy) <= 1.0
-    dy2 = np.full((nsp, n), np.nan)
-    assert L.pj_spec_rates(n, P(pres), P(y), n, 1, None, None, None, None, None, P(dy2), None) == 0
-    assert np.array_equal(dy2, bufs['dy'])
-    # layouts: AoS states (y_si = 1, y_ss = NSP)
-    dy3 = np.full((nsp, n), np.nan)
-    assert L.pj_spec_rates(n, P(pres), P(y_aos), 1, nsp, None, None, None, None, None, P(dy3), None) == 0
-    assert np.array_equal(dy3, bufs['dy'])
+    # the lean outputs (conc / spec_rates / dydt): through k_jvd's dydt build (every reaction once, several lane groups; the
+    # default where the library has one) and through k_rate's lean kernels
+    L.pj_spec_ctx_rate_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert L.pj_spec_ctx_rate_fast(None, -1) == 1
+    for fast in (1, 0):
+        assert L.pj_spec_ctx_rate_fast(None, fast) == fast
+        dy2, sr2, c2 = np.full((nsp, n), np.nan), np.full((nsp, n), np.nan), np.full((nsp, n), np.nan)
+        assert L.pj_spec_rates(n, P(pres), P(y), n, 1, P(c2), None, None, None, P(sr2), P(dy2), None) == 0
+        assert not np.isnan(dy2).any() and not np.isnan(sr2).any() and not np.isnan(c2).any()
+        if fast:
+            mx, _ = thresholded_rel_err(c2.T, g['conc'])
+            assert mx < 1e-9, mx
+            assert mixed_err(sr2.T, g['spec_rates'], gross[:, None]) <= 1.0
+            assert mixed_err(dy2.T, g['dydt'], sdy) <= 1.0
+        else:
+            assert np.array_equal(dy2, bufs['dy']) and np.array_equal(sr2, bufs['spec_rates']) and np.array_equal(c2, bufs['conc'])
+        dy4 = np.full((nsp, n), np.nan)
+        assert L.pj_spec_rates(n, P(pres), P(y), n, 1, None, None, None, None, None, P(dy4), None) == 0
+        assert np.array_equal(dy4, dy2)
+        # layouts: AoS states (y_si = 1, y_ss = NSP)
+        dy3 = np.full((nsp, n), np.nan)
+        assert L.pj_spec_rates(n, P(pres), P(y_aos), 1, nsp, None, None, None, None, None, P(dy3), None) == 0
+        assert np.array_equal(dy3, dy2)
+    L.pj_spec_ctx_rate_fast(None, 1)
 
 
 @pytest.mark.parametrize('name,budget,kw', [
