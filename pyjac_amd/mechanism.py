@@ -14,8 +14,8 @@ Reference behaviours reproduced on purpose (each cited where it is done):
   * last species = first of N2/AR/HE     create_jacobian.py:3521-3563
   * element weights / RU / PA            chem_utilities.py:16-24, 51-99
 
-Not supported (pyJac reads it):
-Cantera input is not read.
+Cantera input: .cti files through pyjac_amd/cti.py (its own reader of the format: no Cantera needed); .xml / a live
+cantera.Solution (mech_interpret.py:886-1137) are not read.
 """
 from __future__ import annotations
 
@@ -254,9 +254,13 @@ def _read_thermo_lines(lines: List[str], specs: List[Species], elem_wt: dict):
 
 def read_mech(mech_filename: str, therm_filename: Optional[str] = None,
               last_spec: Optional[str] = None) -> Mechanism:
-    """Parse a Chemkin mechanism (and optional thermo database)."""
+    """Parse a Chemkin mechanism (and optional thermo database) -- or, by its extension, a Cantera .cti file
+    (create_jacobian.py:3490-3493 dispatches the same way)."""
     with open(mech_filename, 'r') as f:
         text = f.read()
+    if mech_filename.lower().endswith('.cti'):
+        from .cti import parse_cti
+        return parse_cti(text, last_spec)
     therm_text = None
     if therm_filename:
         with open(therm_filename, 'r') as f:
@@ -516,6 +520,13 @@ def parse_mech(text: str, therm_text: Optional[str] = None,
                 start = i + 1
                 break
         _read_thermo_lines(tl[start:], specs, elem_wt)
+    return finish_mechanism(elems, specs, reacs, last_spec)
+
+
+def finish_mechanism(elems: List[str], specs: List[Species], reacs: List[Reaction],
+                     last_spec: Optional[str] = None) -> Mechanism:
+    """Common tail of the front ends (Chemkin: parse_mech; Cantera .cti: pyjac_amd/cti.py): checks, the last-species
+    rule, species names -> indices."""
     missing = [s.name for s in specs if not s.mw]
     if missing:
         raise ValueError('missing thermo data for ' + ', '.join(missing))
