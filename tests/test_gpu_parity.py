@@ -796,6 +796,34 @@ def test_full_size_large_mechanism_properties(name, n, tables, torch_cuda, monke
     assert torch.equal(cs, jac2.sum(dim=1))
 
 
+@pytest.mark.parametrize('name,n', [('gri30_shaped', 1_000_000), ('usc2_shaped', 200_000)])
+def test_full_size_dydt_properties(name, n, tables, torch_cuda):
+    """The right-hand side (dydt alone: the lean rate path, k_jvd's dydt build in these libraries) on the full batches of
+    BASELINE.json's configs 3 and 5: finite everywhere, a strided sample and the last 300 states bit-identical to the same
+    states evaluated as batches of their own, the sample within tolerance of the oracle."""
+    from oracle.oracle import Oracle
+    from pyjac_amd import synth
+    torch = torch_cuda
+    ev = _ev(name)
+    assert ev.spec_kernel == 'pj_rblk'
+    pres, y = synth.dist_b(n, ev.nsp, seed=20241001)
+    d_p, d_y = torch.from_numpy(pres).cuda(), torch.from_numpy(y).cuda()
+    dy = ev.rates(d_p, d_y, want=('dydt',))['dydt']
+    assert bool(torch.isfinite(dy).all())
+    idx = torch.arange(5, n, 4093, device='cuda')
+    small = ev.rates(d_p[idx].contiguous(), d_y[:, idx].contiguous(), want=('dydt',))['dydt']
+    assert torch.equal(small, dy[:, idx])
+    tail = ev.rates(d_p[n - 300:].contiguous(), d_y[:, n - 300:].contiguous(), want=('dydt',))['dydt']
+    assert torch.equal(tail, dy[:, n - 300:])
+    ii = idx.cpu().numpy()
+    orc = Oracle(tables(name))
+    y_aos = np.ascontiguousarray(y[:, ii].T)
+    o = [orc.eval_all(float(pres[s]), y_aos[k]) for k, s in enumerate(ii)]
+    g = {k: np.array([x[k] for x in o]) for k in ('conc', 'fwd', 'rev', 'pres_mod', 'spec_rates', 'dydt')}
+    _, sdy = rate_scales(tables(name), pres[ii], y_aos, g['conc'], g['fwd'], g['rev'], g['pres_mod'])
+    assert mixed_err(small.cpu().numpy().T, g['dydt'], sdy) <= 1.0
+
+
 def test_table_file_through_c_abi_only(tmp_path, tables, torch_cuda):
     """N1: a mechanism written as a .pjtab table file is loaded by pj_mech_load and evaluated
     through the C ABI alone (no Python parser, no Evaluator): Jacobian and dydt against the oracle."""
